@@ -1,0 +1,193 @@
+/*
+ * include/mllm_hip.h -- C ABI of libmllm_hip.so: the MI355X (gfx950) backend for mllm's Op/Layer hot path.
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b): plain `extern "C"` launchers over raw device pointers, sizes and
+ * a stream; no C++ or torch types in any signature.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference tree).  The reference-side adapter (`mllm/backends/hip/HIPBackend` + `HIP*Op`,
+ * INTEGRATION.md) calls these from `Op::execute`; this repo's own engine (the mllm_hip_qwen2vl_* block at the end)
+ * reproduces the reference's model graphs on top of the same launchers.
+ *
+ * Conventions
+ *  - every function returns 0 (MLLM_HIP_OK) or a negative MLLM_HIP_ERR_*; nothing throws, nothing falls back to CPU.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Launchers never synchronise.
+ *  - activations are row-major fp32 `[M][K]`, which is the reference's BSHD tensor `[B,1,S,K]` with M = B*S, or
+ *    `[S][H][D]` for per-head tensors (mllm/Tensor.hpp:264-311 offset rule for BSHD).
+ *  - weight bytes are the on-disk == in-memory block layouts of mllm/DataType.hpp (block_q4_K :93-98, 144 B / 256 w;
+ *    block_q4_0 :75-78, 18 B / 32 w), `[N][K/blk]` per output row, except where a *_planes layout is named.
+ *  - "q8k planes" is this backend's device layout of the reference's activation format block_q8_K
+ *    (mllm/DataType.hpp:159-163): qs int8 `[M][K]`, d fp32 `[M][K/256]`, bsums int16 `[M][K/16]` -- the same
+ *    values, stored as three planes so every access is 16-byte aligned.  "q80 planes": qs int8 `[M][K]`, d fp16
+ *    `[M][K/32]` (block_q8_0 :137-140).
+ */
+#ifndef MLLM_HIP_H
+#define MLLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes (the reference's ErrorCode, mllm/Types.hpp:54-61, is 0 = OK and positive kinds; we keep 0 = OK) */
+#define MLLM_HIP_OK 0
+#define MLLM_HIP_ERR_HIP (-1)    /* a HIP runtime call failed; see mllm_hip_last_error() */
+#define MLLM_HIP_ERR_SHAPE (-2)  /* shape not supported by the kernel (the adapter must refuse at opCreate/reshape) */
+#define MLLM_HIP_ERR_DTYPE (-3)
+#define MLLM_HIP_ERR_IO (-4)
+#define MLLM_HIP_ERR_ARG (-5)
+
+/* DataType values of mllm/Types.hpp:63-97 that occur on this path */
+#define MLLM_HIP_F32 0
+#define MLLM_HIP_F16 1
+#define MLLM_HIP_Q4_0 2
+#define MLLM_HIP_Q8_0 8
+#define MLLM_HIP_Q4_K 12
+#define MLLM_HIP_Q8_K 15
+
+/* ---- device context / memory: Backend::{alloc_device,free_device,copy_from_host,copy_to_host} (mllm/Backend.hpp:60-73),
+ *      OpenCL precedent mllm/backends/opencl/OpenCLBackend.cpp:670-787 -------------------------------------------- */
+int mllm_hip_init(int device);
+const char *mllm_hip_last_error(void);
+int mllm_hip_alloc(void **dptr, size_t nbytes);
+int mllm_hip_free(void *dptr);
+int mllm_hip_h2d(void *dst, const void *src, size_t nbytes, void *stream);
+int mllm_hip_d2h(void *dst, const void *src, size_t nbytes, void *stream);
+int mllm_hip_sync(void *stream);
+
+/* ---- host-side weight tooling (tools/quantizer/QuantWriter.cpp:288-300; ggml QuantizeQ4.cpp:31-64,187-293) -------- */
+int64_t mllm_hip_quantized_nbytes(int dtype, int64_t n_elem);
+int mllm_hip_quantize_host(int dtype, const float *x, void *y, int64_t n_elem);
+
+/* ---- A4: activation quantisation. quantize_row_q8_K_reference (ggml QuantizeQ8.cpp:216-251), quantize_row_q8_0_reference
+ *      (:32-55), as called by mat_mul (compute/Matmul.cpp:77-120) ----------------------------------------------------- */
+int mllm_hip_quantize_q8k(const float *x, int8_t *qs, float *d, int16_t *bsums, int M, int K, void *stream);
+int mllm_hip_quantize_q80(const float *x, int8_t *qs, uint16_t *d, int M, int K, void *stream);
+
+/* ---- A1/A2/A5/A6: Linear / mat_mul on pre-quantised activations.
+ *      y[m][n] = vec_dot(W[n], xq[m]) (+ bias[n]); y fp32 or fp16 (Matmul.cpp:257-268), row stride ldy elements.
+ *      q4k: vec_dot_q4_K_q8_K (ggml VecDotQ4.cpp:32-346); q40: vec_dot_q4_0_q8_0 (:514-545, weights as planes);
+ *      f32: vec_dot_fp32 (ggml VecDotFP32.cpp:31-58). `residual` (optional, fp32 [M][N] with stride ldy) is added after
+ *      the bias: the `x + inputs[0]` of the decoder blocks (models/qwen2_vl/modeling_qwen2_vl.hpp:320-323) fused in. --- */
+int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums,
+                            void *y, int y_dtype, int64_t ldy, const float *residual, int M, int N, int K, void *stream);
+int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, const float *bias, const int8_t *xqs, const uint16_t *xd,
+                            float *y, int64_t ldy, int M, int N, int K, void *stream);
+int mllm_hip_linear_f32(const float *W, const float *bias, const float *x, float *y, int64_t ldy, int M, int N, int K, void *stream);
+/* one-call forms = CPULinear::execute (backends/cpu/op/CPULinear.cpp:98-234): fp32 x in, quantise, dot, bias.
+ * `workspace` must hold mllm_hip_linear_workspace_bytes(wdtype, M, K) bytes of device memory. */
+size_t mllm_hip_linear_workspace_bytes(int wdtype, int M, int K);
+int mllm_hip_linear(const void *W, int wdtype, const float *bias, const float *x, void *y, int y_dtype, int64_t ldy,
+                    int M, int N, int K, void *workspace, void *stream);
+/* Q4_0 rows `[N][K/32]` of 18-B blocks -> nibble plane `[N][K/2]` + fp16 scale plane `[N][K/32]` (load-time repack;
+ * Backend::load_from_file hook, mllm/Backend.hpp:118) */
+int mllm_hip_repack_q40(const void *raw_blocks, uint8_t *qs, uint16_t *d, int64_t n_blocks, void *stream);
+
+/* ---- A8: CPUEmbedding::execute (backends/cpu/op/CPUEmbedding.cpp:38-80); ids travel as fp32 (tokenizers/Tokenizer.hpp:78-88) */
+int mllm_hip_embedding_q40(const float *ids, const uint8_t *Wqs, const uint16_t *Wd, float *out, int S, int hidden, int vocab, void *stream);
+
+/* ---- A9: CPURMSNorm::execute (backends/cpu/op/CPURMSNorm.cpp:31-136). y may be NULL when only the q8k planes are wanted;
+ *      qs/d/bsums may be NULL when only y is wanted (fusion of A9 with the A4 of the following Linear). --------------- */
+int mllm_hip_rmsnorm(const float *x, const float *w, float *y, int8_t *qs, float *d, int16_t *bsums, int M, int dim,
+                     float eps, int add_unit_offset, void *stream);
+/* ---- A18: CPULayerNorm::execute (backends/cpu/op/CPULayerNorm.cpp:49-88), same optional fused outputs ------------- */
+int mllm_hip_layernorm(const float *x, const float *w, const float *b, float *y, int8_t *qs, float *d, int16_t *bsums,
+                       int M, int dim, float eps, void *stream);
+
+/* ---- A14/A18/A20: activations and elementwise -------------------------------------------------------------------- */
+/* CPUSiLU (op/CPUSiLU.cpp:24-52 -> mllm_v_expf polynomial, compute/ActivationFunction.hpp:96-134) */
+int mllm_hip_silu(const float *x, float *y, int64_t n, void *stream);
+/* silu(gate)*up of QWen2MLP (modeling_qwen2_vl.hpp:205-208): gu is `[M][2*I]` with gate in cols [0,I), up in [I,2I) */
+int mllm_hip_silu_mul(const float *gu, float *y, int M, int I, void *stream);
+/* CPUGELU / CPUQuickGELU through the fp16 LUTs (ggml Quantize.hpp:74-131). `lut` = 65536 fp16 entries on device;
+ * mllm_hip_build_act_luts fills host tables with the reference's libm formulas. kind: 0 GELU(tanh), 1 QuickGELU */
+int mllm_hip_build_act_luts(uint16_t *gelu_host, uint16_t *quickgelu_host);
+int mllm_hip_act_lut(const float *x, float *y, int64_t n, const uint16_t *lut, void *stream);
+/* CPUBinaryFunc F_TTADD / F_TTMUL (op/CPUBinaryFunc.hpp) */
+int mllm_hip_add(const float *a, const float *b, float *y, int64_t n, void *stream);
+int mllm_hip_mul(const float *a, const float *b, float *y, int64_t n, void *stream);
+/* CPUSoftMax (op/CPUSoftMax.cpp:28-65): rows of n, `valid` leading columns un-masked (valid == NULL: all) */
+int mllm_hip_softmax(const float *x, float *y, int rows, int n, const int *valid, void *stream);
+/* CPUIndexPutFunc (op/CPUIndexPutFunc.hpp:25-92): rows of `value` replace rows idx[i] of `dst` */
+int mllm_hip_index_put_rows(float *dst, const float *value, const int *idx, int n_rows, int dim, void *stream);
+/* host argmax of the logits row (processing_qwen2_vl.hpp:284-289), moved to device */
+int mllm_hip_argmax(const float *x, int n, int *out_index, void *stream);
+
+/* ---- A10/A11/A19: rotary embeddings. Tables are built on the host with the reference's libm formulas
+ *      (CPURoPE.cpp:22-31,100-128; CPUMultimodalRoPE.cpp:26-36,84-118,37-82; CPUVisionRoPE.cpp:19-55) and uploaded;
+ *      the rotate is rope_hf (CPUMultimodalRoPE.cpp:153-221): out[d] = x[d]c - x[d+half]s, out[d+half] = x[d]s + x[d+half]c.
+ *      x `[S][H][D]` with row stride ldx (elements, per s); out fp32 or fp16 with row stride ldo: writing K straight
+ *      into the fp16 cache slab is A12's zero-copy append (CPUKVCache.cpp:253-275). sin/cos `[S][ld_tab]`, cols < D/2. - */
+int mllm_hip_rope_table_hf(float base, int dim, int n_pos, float *sin_host, float *cos_host);
+int mllm_hip_mrope_table(float base, int dim, const float *pos3xS_host, int S, const int *section, int n_section,
+                         float *sin_host, float *cos_host);
+int mllm_hip_vision_rope_table(int t, int h, int w, int merge, int rot_dim, float *sin_host, float *cos_host);
+int mllm_hip_rope_apply(const float *x, int64_t ldx, const float *sin_t, const float *cos_t, int ld_tab, void *out,
+                        int out_dtype, int64_t ldo, int S, int H, int D, void *stream);
+/* fp32 -> fp16 strided copy: V rows into the cache slab (the fp16 store branch of mat_mul, Matmul.cpp:262-268) */
+int mllm_hip_store_f16(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *stream);
+
+/* ---- A13: flash_attention_2_forward (compute/FlashAttention2.hpp:2236-2284; fp16-KV impl :1212, fp32-KV impl :87).
+ *      O = softmax(Q K^T / sqrt(D) + causal) V, GQA kv_head = q_head / (Hq/Hkv), causal offset Sk - Sq, fp32 accumulate.
+ *      Q `[Sq][Hq][D]` fp32 (row stride ldq), K/V `[Sk][Hkv][D]` fp16 or fp32 (row strides ldk/ldv), O `[Sq][Hq][D]` fp32.
+ *      `sk_dev` (optional device int) overrides Sk at run time so one captured graph serves every decode step. ---------- */
+int mllm_hip_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *V, int64_t ldv, int kv_dtype, float *O,
+                 int64_t ldo, int Sq, int Sk, int Hq, int Hkv, int D, int causal, const int *sk_dev, void *workspace,
+                 void *stream);
+size_t mllm_hip_fa2_workspace_bytes(int Sq, int Hq, int D, int max_sk);
+
+/* ---- A16/A17: patch-embedding convolution with kernel == stride as a GEMM over flattened receptive fields
+ *      (compute/Convolution.cpp:35-82,179-235): out[n][oc] = vec_dot_fp32(W[oc], patch[n]) + bias ------------------- */
+int mllm_hip_patch_gemm_f32(const float *patches, const float *W, const float *bias, float *out, int N, int KK, int OC, void *stream);
+/* gather of conv2d receptive fields from the `[H][C][W]` image into `[oh*ow][kh*C*kw]` rows (Convolution.cpp:8-33 order) */
+int mllm_hip_im2patch_hcw(const float *img, float *patches, int H, int C, int W, int p, void *stream);
+
+/* ================================================================================================================
+ * Engine: the reference's model graphs for the hot-path configs, reproduced on top of the launchers above.
+ * Mirrors demo_qwen2_vl.cpp:32-66 (load -> get_position_ids -> model(input) -> argmax -> next token) and
+ * Module::profiling()'s timing definition (mllm/Module.cpp:35-42).
+ * ============================================================================================================== */
+typedef struct mllm_hip_qwen2vl_config {
+    int hidden, inter, layers, heads, kv_heads, vocab;
+    float rms_eps, rope_theta;
+    int mrope_section[3];
+    int cache_limit;       /* KV slab length, `-l` of the demo (default 800) */
+    int tie_embedding;
+    int v_dim, v_heads, v_blocks, v_patch, v_merge;
+    int image_token_id, vision_start_token_id, vision_end_token_id, video_token_id;
+} mllm_hip_qwen2vl_config;
+
+typedef struct mllm_hip_qwen2vl mllm_hip_qwen2vl;
+
+/* Module::load (mllm/Module.hpp:215-225) + ParamLoader (mllm/ParamLoader.cpp:88-141,157-286): mmap the .mllm, upload */
+int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const char *mllm_path, mllm_hip_qwen2vl **out);
+void mllm_hip_qwen2vl_destroy(mllm_hip_qwen2vl *m);
+/* Qwen2VLModel::clear_kvcache (modeling_qwen2_vl.hpp:405-412) */
+int mllm_hip_qwen2vl_clear_kvcache(mllm_hip_qwen2vl *m);
+/* One prefill forward (modeling_qwen2_vl.hpp:381-404). ids: n_ids host ints; pixel_values: host fp32 `[n_patch][3*2*14*14]`
+ * or NULL; grid_thw: 3 host ints. Outputs (each optional): logits_host `[vocab]` of the last token, next_token (greedy
+ * argmax, first maximum like std::max_element), elapsed_ms (wall, device-synchronised both sides). */
+int mllm_hip_qwen2vl_prefill(mllm_hip_qwen2vl *m, const int32_t *ids, int n_ids, const float *pixel_values,
+                             const int32_t *grid_thw, float *logits_host, int32_t *next_token, float *elapsed_ms);
+/* One decode forward for `token` at the next position (get_position_ids' decode branch, modeling_qwen2_vl.hpp:423-432) */
+int mllm_hip_qwen2vl_decode(mllm_hip_qwen2vl *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms);
+/* `steps` greedy decode forwards back to back on the device (argmax on device, no per-token D2H): SURVEY N2.
+ * tokens_host receives the `steps` generated ids. elapsed_ms covers all steps. */
+int mllm_hip_qwen2vl_generate(mllm_hip_qwen2vl *m, int32_t first_token, int steps, int32_t *tokens_host, float *elapsed_ms);
+/* Vision tower only (Qwen2VisionModel::Forward, modeling_qwen2_vl.hpp:177-190) on `n_img` images of the same grid,
+ * pixel_values host `[n_img][n_patch][1176]`; embeds_dev receives `[n_img][n_patch/4][hidden]` fp32 ON DEVICE
+ * (so the multi-GPU shard can all-gather it without a host hop). */
+int mllm_hip_qwen2vl_vision(mllm_hip_qwen2vl *m, const float *pixel_values_host, const int32_t *grid_thw, int n_img,
+                            float *embeds_dev, float *elapsed_ms);
+/* bytes of weights streamed per decode token (SURVEY §8d algorithmic bytes) and ViT FLOPs per image, for bench.py */
+int64_t mllm_hip_qwen2vl_decode_weight_bytes(const mllm_hip_qwen2vl *m);
+/* the stream the engine launches on (hipStream_t as void*), for event timing around it */
+void *mllm_hip_qwen2vl_stream(mllm_hip_qwen2vl *m);
+/* time (ms) of the dominant kernel measured with HIP events on the engine's stream: runs `iters` launches of the
+ * gate/up Q4_K GEMV of layer 0 on the live decode state; returns mean ms per launch and its algorithmic bytes. */
+int mllm_hip_qwen2vl_time_gemv(mllm_hip_qwen2vl *m, int which, int iters, float *ms_per_launch, int64_t *bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLLM_HIP_H */

@@ -1,0 +1,526 @@
+// mllm_amd/csrc/kernels_elem.hip -- the HBM-bound families of the hot path for gfx950:
+//   A4  activation quantisation (Q8_K / Q8_0 planes)         A9/A18 RMSNorm / LayerNorm (+ fused A4)
+//   A14 SiLU, silu*up, A18 GELU/QuickGELU LUT, A20 add/mul    A8 embedding gather (Q4_0 planes)
+//   A10/A11/A19 rotary apply (+ fp16 KV-slab store = A12 append), softmax, index_put, argmax
+// All are row- or element-parallel: one 64-lane wave owns one 256-value quant block (4 consecutive values per lane,
+// 16-B coalesced loads), reductions are wavefront shuffles, nothing is staged through LDS except cross-wave sums.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace mllm_hip {
+
+// ------------------------------------------------------------------------------------------------------------------
+// A4 core: one wave quantises one 256-value block held as 4 consecutive values per lane.
+// quantize_row_q8_K_reference (ggml QuantizeQ8.cpp:216-251): max = x[first j with largest |x|]; iscale = -128/max;
+// q = min(127, nearest_int(iscale*x)); bsums over 16; d = 1/iscale.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_quant_q8k(float4 v, int lane, int8_t *qs_blk, float *d_out, int16_t *bsums_blk) {
+    float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+    float amax = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+    amax = wave_max(amax);
+    // first index (in element order) that attains amax -- the reference's strict `>` scan keeps the first
+    int idx = 1 << 20;
+    if (a3 == amax) idx = lane * 4 + 3;
+    if (a2 == amax) idx = lane * 4 + 2;
+    if (a1 == amax) idx = lane * 4 + 1;
+    if (a0 == amax) idx = lane * 4 + 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) idx = min(idx, __shfl_xor(idx, m, 64));
+    const int sub = idx & 3;
+    float mine = sub == 0 ? v.x : (sub == 1 ? v.y : (sub == 2 ? v.z : v.w));
+    const float mx = __shfl(mine, idx >> 2, 64);
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    float dd = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = __fdiv_rn(-128.0f, mx);
+        q0 = min(127, nearest_int(__fmul_rn(iscale, v.x)));
+        q1 = min(127, nearest_int(__fmul_rn(iscale, v.y)));
+        q2 = min(127, nearest_int(__fmul_rn(iscale, v.z)));
+        q3 = min(127, nearest_int(__fmul_rn(iscale, v.w)));
+        dd = __fdiv_rn(1.0f, iscale);
+    }
+    const uint32_t packed = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+    reinterpret_cast<uint32_t *>(qs_blk)[lane] = packed;
+    int s = q0 + q1 + q2 + q3;
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((lane & 3) == 0) bsums_blk[lane >> 2] = (int16_t)s;
+    if (lane == 0) *d_out = dd;
+}
+
+__global__ __launch_bounds__(256) void quantize_q8k_kernel(const float *__restrict__ x, int8_t *__restrict__ qs, float *__restrict__ d,
+                                                           int16_t *__restrict__ bsums, int64_t n_blocks) {
+    const int lane = threadIdx.x & 63;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= n_blocks) return;
+    const float4 v = reinterpret_cast<const float4 *>(x + blk * 256)[lane];
+    wave_quant_q8k(v, lane, qs + blk * 256, d + blk, bsums + blk * 16);
+}
+
+// quantize_row_q8_0_reference (ggml QuantizeQ8.cpp:32-55): d = amax/127 (stored fp16), q = roundf(x * (1/d)).
+// One lane per 32-block would serialise; use 8 lanes per block (4 values each), 8 blocks per wave.
+__global__ __launch_bounds__(256) void quantize_q80_kernel(const float *__restrict__ x, int8_t *__restrict__ qs, uint16_t *__restrict__ d, int64_t n_blocks) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t blk = wave * 8 + (lane >> 3);
+    const bool ok = blk < n_blocks;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (ok) v = reinterpret_cast<const float4 *>(x + blk * 32)[lane & 7];
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float dd = __fdiv_rn(amax, 127.0f);
+    const float id = dd != 0.0f ? __fdiv_rn(1.0f, dd) : 0.0f;
+    if (!ok) return;
+    const int q0 = (int)roundf(__fmul_rn(v.x, id)), q1 = (int)roundf(__fmul_rn(v.y, id));
+    const int q2 = (int)roundf(__fmul_rn(v.z, id)), q3 = (int)roundf(__fmul_rn(v.w, id));
+    const uint32_t packed = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+    reinterpret_cast<uint32_t *>(qs + blk * 32)[lane & 7] = packed;
+    if ((lane & 7) == 0) d[blk] = f2h(dd);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// A9 RMSNorm (op/CPURMSNorm.cpp:31-136) / A18 LayerNorm (op/CPULayerNorm.cpp:49-88), one 256-thread workgroup per row.
+// Optional fused A4: the normalised row is quantised to q8k planes in the same pass (wave w owns blocks w, w+4, ...).
+// ------------------------------------------------------------------------------------------------------------------
+template <bool LAYERNORM>
+__global__ __launch_bounds__(256) void norm_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+                                                   float *__restrict__ y, int8_t *__restrict__ qs, float *__restrict__ qd,
+                                                   int16_t *__restrict__ bsums, int dim, float eps, int add_unit_offset) {
+    __shared__ double red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float *xr = x + (int64_t)row * dim;
+    float mean = 0.0f, inv = 0.0f;
+    if (!LAYERNORM) {
+        double ss = 0.0;
+        for (int d = tid; d < dim; d += 256) { const float v = xr[d]; ss += (double)v * (double)v; }
+        ss = wave_sum_d(ss);
+        if (lane == 0) red[wid] = ss;
+        __syncthreads();
+        ss = red[0] + red[1] + red[2] + red[3];
+        const float m = (float)(ss / (double)dim);
+        inv = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(m, eps)));
+    } else {
+        double s = 0.0;
+        for (int d = tid; d < dim; d += 256) s += (double)xr[d];
+        s = wave_sum_d(s);
+        if (lane == 0) red[wid] = s;
+        __syncthreads();
+        mean = __fdiv_rn((float)(red[0] + red[1] + red[2] + red[3]), (float)dim);
+        double ss = 0.0;
+        for (int d = tid; d < dim; d += 256) { const float c = __fsub_rn(xr[d], mean); ss += (double)__fmul_rn(c, c); }
+        ss = wave_sum_d(ss);
+        if (lane == 0) red[4 + wid] = ss;
+        __syncthreads();
+        const float var = __fdiv_rn((float)(red[4] + red[5] + red[6] + red[7]), (float)dim);
+        inv = __fsqrt_rn(__fadd_rn(var, eps));  // "rms" of the reference: the divisor
+    }
+    const bool quant = qs != nullptr;
+    if (quant || (dim & 255) == 0) {
+        const int nblk = dim >> 8;
+        for (int blk = wid; blk < nblk; blk += 4) {
+            const int d0 = blk * 256 + lane * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(xr + d0);
+            const float4 ww = *reinterpret_cast<const float4 *>(w + d0);
+            float4 o;
+            if (!LAYERNORM) {
+                const float w0 = add_unit_offset ? 1.0f + ww.x : ww.x, w1 = add_unit_offset ? 1.0f + ww.y : ww.y;
+                const float w2 = add_unit_offset ? 1.0f + ww.z : ww.z, w3 = add_unit_offset ? 1.0f + ww.w : ww.w;
+                o.x = __fmul_rn(__fmul_rn(v.x, inv), w0);
+                o.y = __fmul_rn(__fmul_rn(v.y, inv), w1);
+                o.z = __fmul_rn(__fmul_rn(v.z, inv), w2);
+                o.w = __fmul_rn(__fmul_rn(v.w, inv), w3);
+            } else {
+                float4 bb = make_float4(0, 0, 0, 0);
+                if (b) bb = *reinterpret_cast<const float4 *>(b + d0);
+                o.x = __fdiv_rn(__fmul_rn(ww.x, __fsub_rn(v.x, mean)), inv);
+                o.y = __fdiv_rn(__fmul_rn(ww.y, __fsub_rn(v.y, mean)), inv);
+                o.z = __fdiv_rn(__fmul_rn(ww.z, __fsub_rn(v.z, mean)), inv);
+                o.w = __fdiv_rn(__fmul_rn(ww.w, __fsub_rn(v.w, mean)), inv);
+                if (b) { o.x = __fadd_rn(o.x, bb.x); o.y = __fadd_rn(o.y, bb.y); o.z = __fadd_rn(o.z, bb.z); o.w = __fadd_rn(o.w, bb.w); }
+            }
+            if (y) *reinterpret_cast<float4 *>(y + (int64_t)row * dim + d0) = o;
+            if (quant) {
+                const int64_t gblk = (int64_t)row * nblk + blk;
+                wave_quant_q8k(o, lane, qs + gblk * 256, qd + gblk, bsums + gblk * 16);
+            }
+        }
+    } else {
+        for (int d = tid; d < dim; d += 256) {
+            float o;
+            if (!LAYERNORM) o = __fmul_rn(__fmul_rn(xr[d], inv), add_unit_offset ? 1.0f + w[d] : w[d]);
+            else { o = __fdiv_rn(__fmul_rn(w[d], __fsub_rn(xr[d], mean)), inv); if (b) o = __fadd_rn(o, b[d]); }
+            y[(int64_t)row * dim + d] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// A14: x/(1+exp(-x)) with the reference's AVX2 polynomial expf, one fp32 lane of it
+// (compute/ActivationFunction.hpp:96-134 mllm_v_expf, :137-146 mllm_v_silu): same constants, same fma placement.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float v_expf(float x) {
+    const float r = 0x1.8p23f;
+    const float z = __fmaf_rn(x, 0x1.715476p+0f, r);
+    const float n = __fsub_rn(z, r);
+    const float b = __fmaf_rn(-n, 0x1.7f7d1cp-20f, __fmaf_rn(-n, 0x1.62e4p-1f, x));
+    const uint32_t e = __float_as_uint(z) << 23;
+    const float k = __uint_as_float(e + __float_as_uint(1.0f));
+    const bool c = fabsf(n) > 126.0f;
+    const float u = __fmul_rn(b, b);
+    const float j = __fmaf_rn(__fmaf_rn(__fmaf_rn(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, __fmaf_rn(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u,
+                              __fmul_rn(0x1.ffffecp-1f, b));
+    if (!c) return __fmaf_rn(j, k, k);
+    const uint32_t g = (n <= 0.0f) ? 0x82000000u : 0u;
+    const float s1 = __uint_as_float(g + 0x7f000000u);
+    const float s2 = __uint_as_float(e - g);
+    if (fabsf(n) > 192.0f) return __fmul_rn(s1, s1);
+    return __fmul_rn(__fmaf_rn(s2, j, s2), s1);
+}
+__device__ __forceinline__ float silu_ref(float x) { return __fdiv_rn(x, __fadd_rn(1.0f, v_expf(__fsub_rn(0.0f, x)))); }
+
+__global__ __launch_bounds__(256) void silu_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (; i + 3 < n; i += stride) {
+        float4 v = *reinterpret_cast<const float4 *>(x + i);
+        v.x = silu_ref(v.x); v.y = silu_ref(v.y); v.z = silu_ref(v.z); v.w = silu_ref(v.w);
+        *reinterpret_cast<float4 *>(y + i) = v;
+    }
+    if (i < n) for (int64_t j = i; j < n && j < i + 4; ++j) y[j] = silu_ref(x[j]);
+}
+// silu(gate)*up of QWen2MLP (modeling_qwen2_vl.hpp:205-208) on a fused [M][2I] gate|up buffer
+__global__ __launch_bounds__(256) void silu_mul_kernel(const float *__restrict__ gu, float *__restrict__ y, int M, int I) {
+    const int64_t total = (int64_t)M * I / 4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t e = t * 4;
+        const int m = (int)(e / I), c = (int)(e % I);
+        const float4 g = *reinterpret_cast<const float4 *>(gu + (int64_t)m * 2 * I + c);
+        const float4 u = *reinterpret_cast<const float4 *>(gu + (int64_t)m * 2 * I + I + c);
+        float4 o;
+        o.x = __fmul_rn(silu_ref(g.x), u.x); o.y = __fmul_rn(silu_ref(g.y), u.y);
+        o.z = __fmul_rn(silu_ref(g.z), u.z); o.w = __fmul_rn(silu_ref(g.w), u.w);
+        *reinterpret_cast<float4 *>(y + e) = o;
+    }
+}
+// A18: y = f16->f32(lut[f32->f16(x)])  (mllm_vec_gelu_f32 / mllm_vec_gelu_quick_f32, ggml Quantize.hpp:92-131)
+__global__ __launch_bounds__(256) void act_lut_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n, const uint16_t *__restrict__ lut) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = h2f(lut[f2h(x[i])]);
+}
+template <int OP>
+__global__ __launch_bounds__(256) void binary_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (; i + 3 < n; i += stride) {
+        const float4 p = *reinterpret_cast<const float4 *>(a + i), q = *reinterpret_cast<const float4 *>(b + i);
+        float4 o;
+        if (OP == 0) { o.x = __fadd_rn(p.x, q.x); o.y = __fadd_rn(p.y, q.y); o.z = __fadd_rn(p.z, q.z); o.w = __fadd_rn(p.w, q.w); }
+        else { o.x = __fmul_rn(p.x, q.x); o.y = __fmul_rn(p.y, q.y); o.z = __fmul_rn(p.z, q.z); o.w = __fmul_rn(p.w, q.w); }
+        *reinterpret_cast<float4 *>(y + i) = o;
+    }
+    if (i < n) for (int64_t j = i; j < n && j < i + 4; ++j) y[j] = OP == 0 ? __fadd_rn(a[j], b[j]) : __fmul_rn(a[j], b[j]);
+}
+
+// CPUSoftMax (op/CPUSoftMax.cpp:28-65): one wave per row; exp through the same polynomial as the reference's vector path
+__global__ __launch_bounds__(64) void softmax_kernel(const float *__restrict__ x, float *__restrict__ y, int n, const int *__restrict__ valid) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const int v = valid ? valid[row] : n;
+    const float *xr = x + (int64_t)row * n;
+    float *yr = y + (int64_t)row * n;
+    float mx = -INFINITY;
+    for (int i = lane; i < v; i += 64) mx = fmaxf(mx, xr[i]);
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int i = lane; i < v; i += 64) { const float e = v_expf(__fsub_rn(xr[i], mx)); yr[i] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = __fdiv_rn(1.0f, sum);
+    for (int i = lane; i < v; i += 64) yr[i] = __fmul_rn(yr[i], inv);
+    for (int i = v + lane; i < n; i += 64) yr[i] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void index_put_rows_kernel(float *__restrict__ dst, const float *__restrict__ value, const int *__restrict__ idx, int dim) {
+    const int r = blockIdx.x;
+    const float4 *src = reinterpret_cast<const float4 *>(value + (int64_t)r * dim);
+    float4 *out = reinterpret_cast<float4 *>(dst + (int64_t)idx[r] * dim);
+    for (int i = threadIdx.x; i < dim / 4; i += 256) out[i] = src[i];
+}
+
+// first-maximum argmax of one row (std::max_element semantics, processing_qwen2_vl.hpp:284-289), single workgroup
+__global__ __launch_bounds__(1024) void argmax_kernel(const float *__restrict__ x, int n, int *__restrict__ out) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) { const float v = x[i]; if (v > best) { best = v; bi = i; } }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        *out = bi;
+    }
+}
+
+// A8: dequantize_row_q4_0 (ggml QuantizeQ4.cpp:74-93) of row ids[s] from the nibble/scale planes: y = (nib-8)*d
+__global__ __launch_bounds__(256) void embedding_q40_kernel(const float *__restrict__ ids, const uint8_t *__restrict__ Wqs, const uint16_t *__restrict__ Wd,
+                                                            float *__restrict__ out, int hidden, int vocab) {
+    const int s = blockIdx.x;
+    int id = (int)ids[s];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const uint8_t *q = Wqs + (int64_t)id * (hidden / 2);
+    const uint16_t *dd = Wd + (int64_t)id * (hidden / 32);
+    float *o = out + (int64_t)s * hidden;
+    for (int t = threadIdx.x; t < hidden / 2; t += 256) {
+        const int blk = t >> 4, j = t & 15;
+        const float d = h2f(dd[blk]);
+        const uint8_t b = q[t];
+        o[blk * 32 + j] = __fmul_rn((float)((int)(b & 0xF) - 8), d);
+        o[blk * 32 + j + 16] = __fmul_rn((float)((int)(b >> 4) - 8), d);
+    }
+}
+
+__global__ __launch_bounds__(256) void repack_q40_kernel(const uint8_t *__restrict__ raw, uint8_t *__restrict__ qs, uint16_t *__restrict__ d, int64_t n_blocks) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n_blocks * 16; t += (int64_t)gridDim.x * 256) {
+        const int64_t blk = t >> 4;
+        const int j = (int)(t & 15);
+        const uint8_t *src = raw + blk * 18;
+        qs[blk * 16 + j] = src[2 + j];
+        if (j == 0) d[blk] = (uint16_t)src[0] | ((uint16_t)src[1] << 8);
+    }
+}
+
+// A10/A11/A19 rope_hf rotate (CPUMultimodalRoPE.cpp:153-221). The reference is built with GCC -O2 -mfma, whose default
+// contraction turns `a*c - b*s` into fma(a, c, -(b*s)) and `a*s + b*c` into fma(a, s, b*c).
+template <bool OUT_F16>
+__global__ __launch_bounds__(256) void rope_apply_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ sin_t, const float *__restrict__ cos_t,
+                                                         int ld_tab, void *__restrict__ out, int64_t ldo, int S, int H, int D) {
+    const int half = D >> 1;
+    const int64_t total = (int64_t)S * H * half;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int d = (int)(t % half);
+        const int h = (int)((t / half) % H);
+        const int s = (int)(t / ((int64_t)half * H));
+        const float a = x[(int64_t)s * ldx + h * D + d], b = x[(int64_t)s * ldx + h * D + d + half];
+        const float sv = sin_t[(int64_t)s * ld_tab + d], cv = cos_t[(int64_t)s * ld_tab + d];
+        const float v1 = __fmaf_rn(a, cv, -__fmul_rn(b, sv));
+        const float v2 = __fmaf_rn(a, sv, __fmul_rn(b, cv));
+        const int64_t o = (int64_t)s * ldo + h * D + d;
+        if (OUT_F16) { reinterpret_cast<uint16_t *>(out)[o] = f2h(v1); reinterpret_cast<uint16_t *>(out)[o + half] = f2h(v2); }
+        else { reinterpret_cast<float *>(out)[o] = v1; reinterpret_cast<float *>(out)[o + half] = v2; }
+    }
+}
+__global__ __launch_bounds__(256) void store_f16_kernel(const float *__restrict__ x, int64_t ldx, uint16_t *__restrict__ out, int64_t ldo, int S, int n) {
+    const int64_t total = (int64_t)S * n;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int s = (int)(t / n), c = (int)(t % n);
+        out[(int64_t)s * ldo + c] = f2h(x[(int64_t)s * ldx + c]);
+    }
+}
+// conv2d receptive-field gather, [H][C][W] image -> [oh*ow][kh][C][kw] rows (Convolution.cpp:8-33 / :45-60 order)
+__global__ __launch_bounds__(256) void im2patch_hcw_kernel(const float *__restrict__ img, float *__restrict__ patches, int H, int C, int W, int p) {
+    const int ow = W / p, KK = p * C * p;
+    const int64_t total = (int64_t)(H / p) * ow * KK;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int k = (int)(t % KK);
+        const int pix = (int)(t / KK);
+        const int kw = k % p, c = (k / p) % C, kh = k / (p * C);
+        const int oy = pix / ow, ox = pix % ow;
+        patches[t] = img[((int64_t)(oy * p + kh) * C + c) * W + ox * p + kw];
+    }
+}
+
+static inline int grid_for(int64_t n_items, int per_block, int cap = 4096) {
+    int64_t g = (n_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+}  // namespace mllm_hip
+
+using namespace mllm_hip;
+
+extern "C" int mllm_hip_quantize_q8k(const float *x, int8_t *qs, float *d, int16_t *bsums, int M, int K, void *stream) {
+    if (K % 256 != 0 || M < 0) return MLLM_HIP_ERR_SHAPE;
+    const int64_t nb = (int64_t)M * (K / 256);
+    if (nb == 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(quantize_q8k_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, as_stream(stream), x, qs, d, bsums, nb);
+    return MH_LAUNCH_OK("quantize_q8k");
+}
+extern "C" int mllm_hip_quantize_q80(const float *x, int8_t *qs, uint16_t *d, int M, int K, void *stream) {
+    if (K % 32 != 0 || M < 0) return MLLM_HIP_ERR_SHAPE;
+    const int64_t nb = (int64_t)M * (K / 32);
+    if (nb == 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(quantize_q80_kernel, dim3((unsigned)((nb + 31) / 32)), dim3(256), 0, as_stream(stream), x, qs, d, nb);
+    return MH_LAUNCH_OK("quantize_q80");
+}
+extern "C" int mllm_hip_rmsnorm(const float *x, const float *w, float *y, int8_t *qs, float *d, int16_t *bsums, int M, int dim,
+                                float eps, int add_unit_offset, void *stream) {
+    if (M <= 0) return MLLM_HIP_OK;
+    if (qs && (dim % 256 != 0 || !d || !bsums)) return MLLM_HIP_ERR_SHAPE;
+    if (!qs && !y) return MLLM_HIP_ERR_ARG;
+    hipLaunchKernelGGL(norm_kernel<false>, dim3(M), dim3(256), 0, as_stream(stream), x, w, (const float *)nullptr, y, qs, d, bsums, dim, eps, add_unit_offset);
+    return MH_LAUNCH_OK("rmsnorm");
+}
+extern "C" int mllm_hip_layernorm(const float *x, const float *w, const float *b, float *y, int8_t *qs, float *d, int16_t *bsums,
+                                  int M, int dim, float eps, void *stream) {
+    if (M <= 0) return MLLM_HIP_OK;
+    if (qs && (dim % 256 != 0 || !d || !bsums)) return MLLM_HIP_ERR_SHAPE;
+    if (!qs && !y) return MLLM_HIP_ERR_ARG;
+    hipLaunchKernelGGL(norm_kernel<true>, dim3(M), dim3(256), 0, as_stream(stream), x, w, b, y, qs, d, bsums, dim, eps, 0);
+    return MH_LAUNCH_OK("layernorm");
+}
+extern "C" int mllm_hip_silu(const float *x, float *y, int64_t n, void *stream) {
+    if (n <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, as_stream(stream), x, y, n);
+    return MH_LAUNCH_OK("silu");
+}
+extern "C" int mllm_hip_silu_mul(const float *gu, float *y, int M, int I, void *stream) {
+    if (I % 4 != 0) return MLLM_HIP_ERR_SHAPE;
+    if (M <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3(grid_for((int64_t)M * I / 4, 256)), dim3(256), 0, as_stream(stream), gu, y, M, I);
+    return MH_LAUNCH_OK("silu_mul");
+}
+extern "C" int mllm_hip_build_act_luts(uint16_t *gelu_host, uint16_t *quickgelu_host) {
+    // init_table_gelu_f16 / init_table_gelu_quick_f16 (ggml Quantize.hpp:74-131): libm tanhf/expf on the host, like the reference
+    for (int i = 0; i < (1 << 16); ++i) {
+        const _Float16 hv = *reinterpret_cast<const _Float16 *>(&(const uint16_t &)(uint16_t)i);
+        const float f = (float)hv;
+        if (gelu_host) {
+            const _Float16 g = (_Float16)(0.5f * f * (1.0f + tanhf(0.79788456080286535587989211986876f * f * (1.0f + 0.044715f * f * f))));
+            memcpy(&gelu_host[i], &g, 2);
+        }
+        if (quickgelu_host) {
+            const _Float16 q = (_Float16)(f * (1.0f / (1.0f + expf(-1.702f * f))));
+            memcpy(&quickgelu_host[i], &q, 2);
+        }
+    }
+    return MLLM_HIP_OK;
+}
+extern "C" int mllm_hip_act_lut(const float *x, float *y, int64_t n, const uint16_t *lut, void *stream) {
+    if (n <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(act_lut_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), x, y, n, lut);
+    return MH_LAUNCH_OK("act_lut");
+}
+extern "C" int mllm_hip_add(const float *a, const float *b, float *y, int64_t n, void *stream) {
+    if (n <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(binary_kernel<0>, dim3(grid_for(n, 1024)), dim3(256), 0, as_stream(stream), a, b, y, n);
+    return MH_LAUNCH_OK("add");
+}
+extern "C" int mllm_hip_mul(const float *a, const float *b, float *y, int64_t n, void *stream) {
+    if (n <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(binary_kernel<1>, dim3(grid_for(n, 1024)), dim3(256), 0, as_stream(stream), a, b, y, n);
+    return MH_LAUNCH_OK("mul");
+}
+extern "C" int mllm_hip_softmax(const float *x, float *y, int rows, int n, const int *valid, void *stream) {
+    if (rows <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(softmax_kernel, dim3(rows), dim3(64), 0, as_stream(stream), x, y, n, valid);
+    return MH_LAUNCH_OK("softmax");
+}
+extern "C" int mllm_hip_index_put_rows(float *dst, const float *value, const int *idx, int n_rows, int dim, void *stream) {
+    if (dim % 4 != 0) return MLLM_HIP_ERR_SHAPE;
+    if (n_rows <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(index_put_rows_kernel, dim3(n_rows), dim3(256), 0, as_stream(stream), dst, value, idx, dim);
+    return MH_LAUNCH_OK("index_put_rows");
+}
+extern "C" int mllm_hip_argmax(const float *x, int n, int *out_index, void *stream) {
+    if (n <= 0) return MLLM_HIP_ERR_SHAPE;
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n, out_index);
+    return MH_LAUNCH_OK("argmax");
+}
+extern "C" int mllm_hip_embedding_q40(const float *ids, const uint8_t *Wqs, const uint16_t *Wd, float *out, int S, int hidden, int vocab, void *stream) {
+    if (hidden % 32 != 0) return MLLM_HIP_ERR_SHAPE;
+    if (S <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(embedding_q40_kernel, dim3(S), dim3(256), 0, as_stream(stream), ids, Wqs, Wd, out, hidden, vocab);
+    return MH_LAUNCH_OK("embedding_q40");
+}
+extern "C" int mllm_hip_repack_q40(const void *raw_blocks, uint8_t *qs, uint16_t *d, int64_t n_blocks, void *stream) {
+    if (n_blocks <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(repack_q40_kernel, dim3(grid_for(n_blocks * 16, 256, 65535)), dim3(256), 0, as_stream(stream), (const uint8_t *)raw_blocks, qs, d, n_blocks);
+    return MH_LAUNCH_OK("repack_q40");
+}
+extern "C" int mllm_hip_rope_apply(const float *x, int64_t ldx, const float *sin_t, const float *cos_t, int ld_tab, void *out,
+                                   int out_dtype, int64_t ldo, int S, int H, int D, void *stream) {
+    if (D % 2 != 0) return MLLM_HIP_ERR_SHAPE;
+    if (S <= 0) return MLLM_HIP_OK;
+    const int g = grid_for((int64_t)S * H * (D / 2), 256);
+    if (out_dtype == MLLM_HIP_F16)
+        hipLaunchKernelGGL(rope_apply_kernel<true>, dim3(g), dim3(256), 0, as_stream(stream), x, ldx, sin_t, cos_t, ld_tab, out, ldo, S, H, D);
+    else if (out_dtype == MLLM_HIP_F32)
+        hipLaunchKernelGGL(rope_apply_kernel<false>, dim3(g), dim3(256), 0, as_stream(stream), x, ldx, sin_t, cos_t, ld_tab, out, ldo, S, H, D);
+    else return MLLM_HIP_ERR_DTYPE;
+    return MH_LAUNCH_OK("rope_apply");
+}
+extern "C" int mllm_hip_store_f16(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *stream) {
+    if (S <= 0 || n <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(store_f16_kernel, dim3(grid_for((int64_t)S * n, 256)), dim3(256), 0, as_stream(stream), x, ldx, out, ldo, S, n);
+    return MH_LAUNCH_OK("store_f16");
+}
+extern "C" int mllm_hip_im2patch_hcw(const float *img, float *patches, int H, int C, int W, int p, void *stream) {
+    if (H % p || W % p) return MLLM_HIP_ERR_SHAPE;
+    hipLaunchKernelGGL(im2patch_hcw_kernel, dim3(grid_for((int64_t)H * C * W, 256)), dim3(256), 0, as_stream(stream), img, patches, H, C, W, p);
+    return MH_LAUNCH_OK("im2patch_hcw");
+}
+
+// ---- host-side rotary tables: the reference's own libm formulas ------------------------------------------------------
+extern "C" int mllm_hip_rope_table_hf(float base, int dim, int n_pos, float *sin_host, float *cos_host) {
+    // CPURoPE.cpp:22-31 (theta in double -> float), :100-128 (HF half-split table, both halves filled)
+    const int half = dim / 2;
+    for (int i = 0; i < half; ++i) {
+        const float theta = (float)(1.0 / pow((double)base, 2.0 * i / dim));
+        for (int s = 0; s < n_pos; ++s) {
+            const float v = (float)s * theta;
+            sin_host[(size_t)s * dim + i] = sin_host[(size_t)s * dim + i + half] = sinf(v);
+            cos_host[(size_t)s * dim + i] = cos_host[(size_t)s * dim + i + half] = cosf(v);
+        }
+    }
+    return MLLM_HIP_OK;
+}
+extern "C" int mllm_hip_mrope_table(float base, int dim, const float *pos, int S, const int *section, int n_section, float *sin_host, float *cos_host) {
+    // CPUMultimodalRoPE.cpp:26-36 theta, :84-118 per-axis sin/cos, :37-82 stitch by mrope_section; tables [S][dim/2]
+    const int half = dim / 2;
+    int c0 = 0;
+    for (int j = 0; j < n_section; ++j) {
+        const int axis = j % 3;
+        for (int c = c0; c < c0 + section[j] && c < half; ++c) {
+            const float theta = (float)(1.0 / pow((double)base, 2.0 * c / dim));
+            for (int s = 0; s < S; ++s) {
+                const float v = theta * pos[(size_t)axis * S + s];
+                sin_host[(size_t)s * half + c] = sinf(v);
+                cos_host[(size_t)s * half + c] = cosf(v);
+            }
+        }
+        c0 += section[j];
+    }
+    return MLLM_HIP_OK;
+}
+extern "C" int mllm_hip_vision_rope_table(int t, int h, int w, int merge, int rot_dim, float *sin_host, float *cos_host) {
+    // CPUVisionRoPE.cpp:19-28 inv_freq (float pow), :56-103 merge-block ordered (h,w), :29-55 angle = pos*inv_freq;
+    // CPUVisionRoPEFunc.hpp:21-60 evaluates std::sin/std::cos of the angle per use: tabulated here. Tables [t*h*w][rot_dim]
+    const int q = rot_dim / 2;
+    float inv[256];
+    if (q > 256) return MLLM_HIP_ERR_SHAPE;
+    for (int i = 0; i < q; ++i) inv[i] = 1.0f / powf(10000.0f, (2.0f * i) / (float)rot_dim);
+    const int nhb = h / merge, nwb = w / merge;
+    size_t p = 0;
+    for (int ti = 0; ti < t; ++ti)
+        for (int bh = 0; bh < nhb; ++bh)
+            for (int bw = 0; bw < nwb; ++bw)
+                for (int jh = 0; jh < merge; ++jh)
+                    for (int jw = 0; jw < merge; ++jw, ++p) {
+                        const int ph = bh * merge + jh, pw = bw * merge + jw;
+                        for (int i = 0; i < q; ++i) {
+                            const float ah = (float)ph * inv[i], aw = (float)pw * inv[i];
+                            sin_host[p * rot_dim + i] = sinf(ah); cos_host[p * rot_dim + i] = cosf(ah);
+                            sin_host[p * rot_dim + q + i] = sinf(aw); cos_host[p * rot_dim + q + i] = cosf(aw);
+                        }
+                    }
+    return MLLM_HIP_OK;
+}

@@ -1,0 +1,172 @@
+"""Seeded synthetic weights / inputs for the hot-path configs (SURVEY §8d "Synthetic inputs").
+
+No model weights ship with the reference and there is no network, so every measurement and parity case runs on
+synthetic tensors: ``W ~ N(0, 0.02^2)`` fp32, norm weights = 1, biases = ``0.01*N(0,1)``, each tensor drawn from
+``numpy.random.default_rng(20251031 + crc32(name))``.  Tensor names follow the reference's name configs
+(mllm/models/qwen/configuration_qwen.hpp:28-47, mllm/models/qwen2_vl/configuration_qwen2_vl.hpp:20-32).
+The per-name storage dtype policy restates tools/quantizer/QuantWriter.cpp:10-35,123-157 for a Q4_K target.
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, field
+from typing import Iterator, List, Tuple
+
+import numpy as np
+
+from . import mllmfile as mf
+
+SEED0 = 20251031
+
+
+@dataclass
+class Qwen2VLConfig:
+    """Shape subset of Qwen2VLConfig/QWenConfig (configuration_qwen.hpp:152-166 "1.5b", configuration_qwen2_vl.hpp:34-56)."""
+    hidden: int = 1536
+    inter: int = 8960
+    layers: int = 28
+    heads: int = 12
+    kv_heads: int = 2
+    vocab: int = 151936
+    rms_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    max_pos: int = 32768
+    mrope_section: Tuple[int, int, int] = (16, 24, 24)
+    cache_limit: int = 800
+    tie_embedding: bool = True
+    # vision tower (modeling_qwen2_vl.hpp:371: 16 heads, mlp = 4*dim, QuickGELU, patch 14, 32 blocks, merge 2)
+    v_dim: int = 1280
+    v_heads: int = 16
+    v_blocks: int = 32
+    v_patch: int = 14
+    v_merge: int = 2
+    image_token_id: int = 151655
+    vision_start_token_id: int = 151652
+    vision_end_token_id: int = 151653
+    video_token_id: int = 151656
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def v_head_dim(self) -> int:
+        return self.v_dim // self.v_heads
+
+    @property
+    def v_mlp(self) -> int:
+        return self.v_dim * 4
+
+    @property
+    def patch_elems(self) -> int:
+        return 3 * 2 * self.v_patch * self.v_patch
+
+
+def qwen2vl_2b() -> Qwen2VLConfig:
+    return Qwen2VLConfig()
+
+
+def qwen2vl_tiny() -> Qwen2VLConfig:
+    """Smallest shape the reference's Qwen2VLModel accepts with Q4_K weights: head_dim must stay 128 (mrope_section sums
+    to 64), every Linear K a multiple of 256, and the vision tower is hard-wired to 16 heads x 32 blocks."""
+    return Qwen2VLConfig(hidden=256, inter=512, layers=2, heads=2, kv_heads=1, vocab=2048, cache_limit=96,
+                         v_dim=256, image_token_id=2040, vision_start_token_id=2041, vision_end_token_id=2042,
+                         video_token_id=2043)
+
+
+FP32_LAYERS = ["norm", "rope", "bias", "rotary_emb", "_GN", "class_embedding", "embeddings", "logit_scale",
+               "modality_preprocessors", "modality_heads", "modality_postprocessors", "pre_transformer_layer",
+               "pos_embed.inv_freq", "ln_q", "patch_embed.proj"]
+Q40_LAYERS = ["embed_tokens", "word_embeddings"]
+
+
+def storage_dtype(name: str, target: int = mf.Q4_K) -> int:
+    """QuantWriter::getQuantizationTypeFor (tools/quantizer/QuantWriter.cpp:123-157) for K-quant / Q4_0 targets."""
+    if target == mf.F32:
+        return mf.F32
+    if any(s in name for s in Q40_LAYERS):
+        return mf.Q4_0
+    if any(s in name for s in FP32_LAYERS):
+        return mf.F32
+    return target
+
+
+def tensor_f32(name: str, shape: Tuple[int, ...], kind: str) -> np.ndarray:
+    rng = np.random.default_rng(SEED0 + zlib.crc32(name.encode()))
+    n = int(np.prod(shape))
+    if kind == "norm":
+        return np.ones(n, dtype=np.float32)
+    x = rng.standard_normal(n, dtype=np.float32)
+    x *= np.float32(0.01 if kind == "bias" else 0.02)
+    return x
+
+
+def qwen2vl_tensors(c: Qwen2VLConfig, vision: bool = True) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
+    """(name, shape, kind) in file order. Linear weights are [out, in] row-major (CPULinear.cpp:50-51)."""
+    H, I, D = c.hidden, c.inter, c.head_dim
+    yield "model.embed_tokens.weight", (c.vocab, H), "w"
+    for i in range(c.layers):
+        p = f"model.layers.{i}."
+        yield p + "input_layernorm.weight", (H,), "norm"
+        yield p + "self_attn.q_proj.weight", (c.heads * D, H), "w"
+        yield p + "self_attn.q_proj.bias", (c.heads * D,), "bias"
+        yield p + "self_attn.k_proj.weight", (c.kv_heads * D, H), "w"
+        yield p + "self_attn.k_proj.bias", (c.kv_heads * D,), "bias"
+        yield p + "self_attn.v_proj.weight", (c.kv_heads * D, H), "w"
+        yield p + "self_attn.v_proj.bias", (c.kv_heads * D,), "bias"
+        yield p + "self_attn.o_proj.weight", (H, c.heads * D), "w"
+        yield p + "post_attention_layernorm.weight", (H,), "norm"
+        yield p + "mlp.gate_proj.weight", (I, H), "w"
+        yield p + "mlp.up_proj.weight", (I, H), "w"
+        yield p + "mlp.down_proj.weight", (H, I), "w"
+    yield "model.norm.weight", (H,), "norm"
+    if not c.tie_embedding:
+        yield "lm_head.weight", (c.vocab, H), "w"
+    if not vision:
+        return
+    V, M = c.v_dim, c.v_mlp
+    yield "visual.patch_embed.proj.weight", (V, 3, 2, c.v_patch, c.v_patch), "w"
+    for i in range(c.v_blocks):
+        p = f"visual.blocks.{i}."
+        yield p + "norm1.weight", (V,), "norm"
+        yield p + "norm1.bias", (V,), "bias"
+        yield p + "attn.qkv.weight", (3 * V, V), "w"
+        yield p + "attn.qkv.bias", (3 * V,), "bias"
+        yield p + "attn.proj.weight", (V, V), "w"
+        yield p + "attn.proj.bias", (V,), "bias"
+        yield p + "norm2.weight", (V,), "norm"
+        yield p + "norm2.bias", (V,), "bias"
+        yield p + "mlp.fc1.weight", (M, V), "w"
+        yield p + "mlp.fc1.bias", (M,), "bias"
+        yield p + "mlp.fc2.weight", (V, M), "w"
+        yield p + "mlp.fc2.bias", (V,), "bias"
+    m2 = V * c.v_merge * c.v_merge
+    yield "visual.merger.ln_q.weight", (V,), "norm"
+    yield "visual.merger.ln_q.bias", (V,), "bias"
+    yield "visual.merger.mlp.0.weight", (m2, m2), "w"
+    yield "visual.merger.mlp.0.bias", (m2,), "bias"
+    yield "visual.merger.mlp.2.weight", (H, m2), "w"
+    yield "visual.merger.mlp.2.bias", (H,), "bias"
+
+
+def write_fp32_mllm(path: str, specs) -> None:
+    mf.write_mllm(path, ((n, mf.F32, tensor_f32(n, s, k)) for n, s, k in specs))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# synthetic prompt / image
+# ---------------------------------------------------------------------------------------------------------------
+
+def qwen2vl_inputs(c: Qwen2VLConfig, grid_hw: Tuple[int, int] = (32, 32), n_text: int = 24):
+    """pixel_values fp32 [N, 3*2*14*14] ~ N(0,1) seed 7; grid_thw [1,h,w]; ids = [vision_start] + N/4*[image_pad] +
+    [vision_end] + n_text ids uniform in [0, min(vocab, 151643)-1) seed 11 (never a special id)."""
+    gh, gw = grid_hw
+    n_patch = gh * gw
+    pix = np.random.default_rng(7).standard_normal((n_patch, c.patch_elems), dtype=np.float32)
+    n_img_tok = n_patch // (c.v_merge * c.v_merge)
+    hi = min(c.vocab, 151643)
+    specials = {c.image_token_id, c.vision_start_token_id, c.vision_end_token_id, c.video_token_id}
+    hi = min([hi] + [s for s in specials])
+    text = np.random.default_rng(11).integers(0, hi, size=n_text)
+    ids = np.concatenate([[c.vision_start_token_id], np.full(n_img_tok, c.image_token_id), [c.vision_end_token_id], text])
+    return pix, np.array([1, gh, gw], dtype=np.int32), ids.astype(np.int32)

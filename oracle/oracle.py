@@ -1,0 +1,225 @@
+"""ctypes face of oracle/restate.c -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
+mllm_amd/ does.  See the header of restate.c for what it restates and how it is pinned.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "liboracle.so")
+SRC = os.path.join(HERE, "restate.c")
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(SRC):
+        subprocess.check_call(["gcc", "-O2", "-mavx2", "-mf16c", "-mfma", "-ffp-contract=off", "-fopenmp", "-shared",
+                               "-fPIC", SRC, "-o", SO, "-lm"])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_vec_dot_q4_K_q8_K.restype = C.c_float
+        _lib.orc_vec_dot_q4_0_q8_0.restype = C.c_float
+        _lib.orc_vec_dot_f32.restype = C.c_float
+        _lib.orc_f16_to_f32.restype = C.c_float
+        _lib.orc_v_expf.restype = C.c_float
+        _lib.orc_v_expf.argtypes = [C.c_float]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+F32, Q4_0, Q4_K = 0, 2, 12
+
+
+def quantize_q8_K(x: np.ndarray) -> np.ndarray:
+    x = _f32(x)
+    k = x.shape[-1]
+    rows = x.reshape(-1, k)
+    out = np.zeros((rows.shape[0], k // 256 * 292), dtype=np.uint8)
+    for i in range(rows.shape[0]):
+        lib().orc_quantize_row_q8_K(_p(rows[i]), _p(out[i]), C.c_int(k))
+    return out
+
+
+def quantize_q8_0(x: np.ndarray) -> np.ndarray:
+    x = _f32(x)
+    k = x.shape[-1]
+    rows = x.reshape(-1, k)
+    out = np.zeros((rows.shape[0], k // 32 * 34), dtype=np.uint8)
+    for i in range(rows.shape[0]):
+        lib().orc_quantize_row_q8_0(_p(rows[i]), _p(out[i]), C.c_int(k))
+    return out
+
+
+def dequantize(raw: np.ndarray, dtype: int, n: int) -> np.ndarray:
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    out = np.empty(n, dtype=np.float32)
+    if dtype == Q4_0:
+        lib().orc_dequantize_row_q4_0(_p(raw), _p(out), C.c_int(n))
+    elif dtype == Q4_K:
+        lib().orc_dequantize_row_q4_K(_p(raw), _p(out), C.c_int(n))
+    else:
+        out[:] = raw.view(np.float32)[:n]
+    return out
+
+
+def linear(x, W_raw, wdtype, N, bias=None, out_f16=False):
+    x = _f32(x)
+    K = x.shape[-1]
+    M = x.size // K
+    W_raw = np.ascontiguousarray(W_raw)
+    b = _f32(bias) if bias is not None else None
+    y = np.empty((M, N), dtype=np.uint16 if out_f16 else np.float32)
+    lib().orc_linear(_p(x), C.c_int(M), C.c_int(K), _p(W_raw), C.c_int(wdtype), C.c_int(N), _p(b), _p(y), C.c_int(int(out_f16)))
+    return y
+
+
+def embedding(ids, W_raw, wdtype, hidden):
+    ids = _f32(ids).ravel()
+    out = np.empty((ids.size, hidden), dtype=np.float32)
+    lib().orc_embedding(_p(ids), C.c_int(ids.size), _p(np.ascontiguousarray(W_raw)), C.c_int(wdtype), C.c_int(hidden), _p(out))
+    return out
+
+
+def rmsnorm(x, w, eps, add_unit_offset=False):
+    x = _f32(x)
+    dim = x.shape[-1]
+    y = np.empty_like(x)
+    lib().orc_rmsnorm(_p(x), _p(_f32(w)), _p(y), C.c_int(x.size // dim), C.c_int(dim), C.c_float(eps), C.c_int(int(add_unit_offset)))
+    return y
+
+
+def layernorm(x, w, b, eps):
+    x = _f32(x)
+    dim = x.shape[-1]
+    y = np.empty_like(x)
+    lib().orc_layernorm(_p(x), _p(_f32(w)), _p(_f32(b)) if b is not None else None, _p(y), C.c_int(x.size // dim), C.c_int(dim), C.c_float(eps))
+    return y
+
+
+def _unary(name, x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    getattr(lib(), name)(_p(x), _p(y), C.c_int(x.size))
+    return y
+
+
+def silu(x):
+    return _unary("orc_silu", x)
+
+
+def gelu(x):
+    return _unary("orc_gelu", x)
+
+
+def quickgelu(x):
+    return _unary("orc_quickgelu", x)
+
+
+def gelu_tables():
+    g = np.empty(65536, dtype=np.uint16)
+    q = np.empty(65536, dtype=np.uint16)
+    lib().orc_gelu_tables(_p(g), _p(q))
+    return g, q
+
+
+def softmax(x, valid=None):
+    x = _f32(x)
+    n = x.shape[-1]
+    rows = x.reshape(-1, n)
+    y = np.empty_like(rows)
+    for i in range(rows.shape[0]):
+        v = n if valid is None else int(valid[i])
+        lib().orc_softmax_row(_p(rows[i]), _p(y[i]), C.c_int(n), C.c_int(v))
+    return y.reshape(x.shape)
+
+
+def rope_table_hf(base, dim, n_pos):
+    s = np.empty((n_pos, dim), dtype=np.float32)
+    c = np.empty((n_pos, dim), dtype=np.float32)
+    lib().orc_rope_table_hf(C.c_float(base), C.c_int(dim), C.c_int(n_pos), _p(s), _p(c))
+    return s, c
+
+
+def mrope_table(base, dim, pos, section=(16, 24, 24)):
+    pos = _f32(pos)  # [3, S]
+    S = pos.shape[1]
+    sec = np.asarray(section, dtype=np.int32)
+    s = np.zeros((S, dim // 2), dtype=np.float32)
+    c = np.zeros((S, dim // 2), dtype=np.float32)
+    lib().orc_mrope_table(C.c_float(base), C.c_int(dim), _p(pos), C.c_int(S), _p(sec), C.c_int(len(sec)), _p(s), _p(c))
+    return s, c
+
+
+def vision_rope_angles(t, h, w, merge, rot_dim):
+    a = np.empty((t * h * w, rot_dim), dtype=np.float32)
+    lib().orc_vision_rope_angles(C.c_int(t), C.c_int(h), C.c_int(w), C.c_int(merge), C.c_int(rot_dim), _p(a))
+    return a
+
+
+def rope_apply(x, S, H, D, sin_t, cos_t, out_f16=False):
+    x = _f32(x)
+    sin_t, cos_t = _f32(sin_t), _f32(cos_t)
+    out = np.empty(x.shape, dtype=np.uint16 if out_f16 else np.float32)
+    lib().orc_rope_apply(_p(x), C.c_int(S), C.c_int(H), C.c_int(D), _p(sin_t), _p(cos_t), C.c_int(sin_t.shape[-1]), _p(out), C.c_int(int(out_f16)))
+    return out
+
+
+def vision_rope_apply(x, S, H, D, angle):
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().orc_vision_rope_apply(_p(x), C.c_int(S), C.c_int(H), C.c_int(D), _p(_f32(angle)), _p(out))
+    return out
+
+
+def attention(q, k, v, Sq, Sk, Hq, Hkv, D, causal):
+    q = _f32(q)
+    kv_f16 = k.dtype == np.uint16
+    k = np.ascontiguousarray(k)
+    v = np.ascontiguousarray(v)
+    o = np.empty((Sq, Hq * D), dtype=np.float32)
+    lib().orc_attention(_p(q), _p(k), _p(v), C.c_int(int(kv_f16)), _p(o), C.c_int(Sq), C.c_int(Sk), C.c_int(Hq), C.c_int(Hkv), C.c_int(D), C.c_int(int(causal)))
+    return o
+
+
+def patch_gemm(patches, W, bias=None):
+    patches, W = _f32(patches), _f32(W)
+    N, KK = patches.shape
+    OC = W.size // KK
+    out = np.empty((N, OC), dtype=np.float32)
+    lib().orc_patch_gemm(_p(patches), C.c_int(N), C.c_int(KK), _p(W), C.c_int(OC), _p(_f32(bias)) if bias is not None else None, _p(out))
+    return out
+
+
+def conv2d_patch(img, H, Cc, Wd, Wt, OC, p, bias=None):
+    img, Wt = _f32(img), _f32(Wt)
+    out = np.empty((H // p, OC, Wd // p), dtype=np.float32)
+    lib().orc_conv2d_patch(_p(img), C.c_int(H), C.c_int(Cc), C.c_int(Wd), _p(Wt), C.c_int(OC), C.c_int(p), _p(_f32(bias)) if bias is not None else None, _p(out))
+    return out
+
+
+def f16_to_f32(a):
+    return np.asarray(a, dtype=np.uint16).view(np.float16).astype(np.float32)
+
+
+def f32_to_f16(a):
+    return _f32(a).astype(np.float16).view(np.uint16)

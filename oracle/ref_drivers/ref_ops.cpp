@@ -1,0 +1,194 @@
+// oracle/ref_drivers/ref_ops.cpp -- TEST INFRASTRUCTURE (oracle), not product.
+//
+// Runs single reference ops / blocks on the reference's x86 CPU backend through its own frontend (Layer / Module /
+// Tensor functional API) on raw fp32 inputs, and dumps the fp32 outputs.  This is how golden vectors for the A-rows
+// of SURVEY §8(a) are captured (the reference's own tests hold none): same call protocol as
+// test/cpu/CPUTest.hpp:18-53 but driven through Module::load + operator() so the trace/load/execute passes
+// (mllm/backends/cpu/CPUBackend.cpp:314-405) are the real ones.
+//
+// usage: ref_ops case=<name> weights=<file.mllm> out=<dir> [p=a,b,c,...] call=<file:b,h,s,d[+file:shape...]> [call=...]
+//   5-number shapes (n,c,t,h,w) build the BCTHW patch tensor the way processing_qwen2_vl.hpp:249-252 does.
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "models/qwen2_vl/configuration_qwen2_vl.hpp"
+#include "models/qwen2_vl/modeling_qwen2_vl.hpp"
+#include "backends/cpu/CPUBackend.hpp"
+
+using namespace mllm;
+
+static std::vector<float> read_f32(const std::string &p) {
+    std::ifstream f(p, std::ios::binary | std::ios::ate);
+    if (!f) { fprintf(stderr, "cannot open %s\n", p.c_str()); exit(2); }
+    size_t n = f.tellg();
+    f.seekg(0);
+    std::vector<float> v(n / 4);
+    f.read((char *)v.data(), n);
+    return v;
+}
+static std::vector<std::string> split(const std::string &s, char c) {
+    std::vector<std::string> o;
+    std::stringstream ss(s);
+    std::string t;
+    while (std::getline(ss, t, c)) o.push_back(t);
+    return o;
+}
+static std::vector<float> P;  // numeric params of the case
+static float p(int i, float dflt = 0) { return i < (int)P.size() ? P[i] : dflt; }
+
+class OpsModule final : public Module {
+public:
+    std::string kind;
+    Layer l0, l1;
+    Parameter param;
+    Softmax sm;
+    explicit OpsModule(const std::string &k) : kind(k) {
+        if (k == "linear") l0 = Linear((int)p(0), (int)p(1), p(2) != 0, "lin");
+        else if (k == "rmsnorm") l0 = RMSNorm((int)p(0), p(1), "norm");
+        else if (k == "layernorm") l0 = LayerNorm((int)p(0), true, p(1), "ln");
+        else if (k == "silu") l0 = SiLU("act");
+        else if (k == "gelu") l0 = GELU("act");
+        else if (k == "quickgelu") l0 = QuickGELU("act");
+        else if (k == "softmax") sm = Softmax(DIMENSION, p(0) != 0, "sm");
+        else if (k == "embedding") l0 = Embedding((int)p(0), (int)p(1), "emb");
+        else if (k == "mm_tied") param = Parameter(1, (int)p(0), 1, (int)p(1), "emb.weight");
+        else if (k == "conv3d") l0 = Convolution3D(3, (int)p(0), {2, 14, 14}, {2, 14, 14}, VALID, false, "proj");
+        else if (k == "conv2d") l0 = Convolution2D(3, (int)p(0), {(int)p(1), (int)p(1)}, {(int)p(1), (int)p(1)}, VALID, p(2) != 0, "proj");
+        else if (k == "vrope") l0 = VisionRoPE((int)p(0), (int)p(1), "rot");
+        else if (k == "mrope") l0 = MultimodalRoPE(p(0), (int)p(1), {16, 24, 24}, "rope");
+        else if (k == "rope") l0 = RoPE((int)p(0), p(1), (int)p(2), "rope");
+        else if (k == "fa2") {}
+        else { fprintf(stderr, "unknown case %s\n", k.c_str()); exit(2); }
+    }
+    vector<Tensor> Forward(vector<Tensor> in, vector<std::any> args) override {
+        if (kind == "softmax") return {sm(in[0])};
+        if (kind == "mm_tied") return {Tensor::mm(in[0], param().transpose(Chl::SEQUENCE, Chl::DIMENSION))};
+        if (kind == "conv3d") { auto e = l0(in[0]); return {e.view(1, 1, -1, (int)p(0))}; }
+        if (kind == "vrope") {
+            // in[0] = q [1,1,S,H*D], in[1] = grid_thw ; rotary table then F_APPLY_VISIOROPE (modeling_qwen2_vl.hpp:70-74,179)
+            auto rot = l0(in[1]);
+            auto q = in[0].view(-1, (int)p(2), -1, (int)p(3));
+            q = Tensor::apply_rotary_pos_emb_vision(q, rot);
+            return {q.view(-1, 1, -1, (int)(p(2) * p(3)))};
+        }
+        if (kind == "mrope") {
+            auto q = in[0].view(-1, (int)p(2), -1, (int)p(3));
+            MultimodalRoPE &r = (MultimodalRoPE &)l0;
+            q = r(q, in[1]);
+            return {q.view(-1, 1, -1, (int)(p(2) * p(3)))};
+        }
+        if (kind == "rope") {
+            auto q = in[0].view(-1, (int)p(3), -1, (int)p(4));
+            RoPE &r = (RoPE &)l0;
+            q = r(q);
+            return {q.view(-1, 1, -1, (int)(p(3) * p(4)))};
+        }
+        if (kind == "fa2") {
+            // in: q [1,1,Sq,Hq*D], k,v [1,1,Sk,Hkv*D] all fp32 (the vision / fp32-KV path, FlashAttention2.hpp:87)
+            auto q = in[0].view(-1, (int)p(0), -1, (int)p(2));
+            auto k = in[1].view(-1, (int)p(1), -1, (int)p(2));
+            auto v = in[2].view(-1, (int)p(1), -1, (int)p(2));
+            auto o = Tensor::flash_attention2_forward(q, k, v, p(3) != 0);
+            return {o.view(-1, 1, -1, (int)(p(0) * p(2)))};
+        }
+        return {l0(in[0])};
+    }
+};
+
+static Tensor make_input(const std::string &spec, int idx) {
+    auto parts = split(spec, ':');
+    auto data = read_f32(parts[0]);
+    auto shp = split(parts[1], ',');
+    Backend *bn = Backend::global_backends[MLLM_CPU].get();
+    Tensor::tensor_status = TENSOR_STATIC_INIT;
+    if (shp.size() == 5) {
+        int n = std::stoi(shp[0]), pe = std::stoi(shp[1]) * std::stoi(shp[2]) * std::stoi(shp[3]) * std::stoi(shp[4]);
+        Tensor t(1, n, 1, pe, bn, true);
+        t.setName("input" + std::to_string(idx));
+        t.setTtype(INPUT_TENSOR);
+        for (int i = 0; i < n; ++i)
+            for (int d = 0; d < pe; ++d) t.setDataAt<float>(0, i, 0, d, data[(size_t)i * pe + d]);
+        t.reshape(n, std::stoi(shp[1]), std::stoi(shp[2]), std::stoi(shp[3]), std::stoi(shp[4]));
+        return t;
+    }
+    int b = std::stoi(shp[0]), h = std::stoi(shp[1]), s = std::stoi(shp[2]), d = std::stoi(shp[3]);
+    Tensor t(b, h, s, d, bn, true);
+    t.setName("input" + std::to_string(idx));
+    t.setTtype(INPUT_TENSOR);
+    // file order is logical [b][h][s][d]; setDataAt honours the tensor's memory layout (BSHD)
+    size_t i = 0;
+    for (int bi = 0; bi < b; ++bi)
+        for (int hi = 0; hi < h; ++hi)
+            for (int si = 0; si < s; ++si)
+                for (int di = 0; di < d; ++di) t.setDataAt<float>(bi, hi, si, di, data[i++]);
+    return t;
+}
+
+static void dump(Tensor &o, const std::string &path) {
+    std::vector<float> v;
+    // logical [b][h][s][d] order
+    for (int b = 0; b < o.batch(); ++b)
+        for (int h = 0; h < o.head(); ++h)
+            for (int s = 0; s < o.sequence(); ++s)
+                for (int d = 0; d < o.dimension(); ++d) {
+                    if (o.dtype() == MLLM_TYPE_F16) v.push_back(MLLM_FP16_TO_FP32(o.dataAt<mllm_fp16_t>(b, h, s, d)));
+                    else v.push_back(o.dataAt<float>(b, h, s, d));
+                }
+    std::ofstream f(path, std::ios::binary);
+    f.write((const char *)v.data(), v.size() * 4);
+    printf("%s shape %d,%d,%d,%d dtype %d\n", path.c_str(), o.batch(), o.head(), o.sequence(), o.dimension(), (int)o.dtype());
+}
+
+int main(int argc, char **argv) {
+    std::string kind, weights, out = ".";
+    std::vector<std::string> calls;
+    int threads = 4;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto eq = a.find('=');
+        std::string k = a.substr(0, eq), v = a.substr(eq + 1);
+        if (k == "case") kind = v;
+        else if (k == "weights") weights = v;
+        else if (k == "out") out = v;
+        else if (k == "threads") threads = std::stoi(v);
+        else if (k == "p") for (auto &s : split(v, ',')) P.push_back(std::stof(s));
+        else if (k == "call") calls.push_back(v);
+    }
+    CPUBackend::cpu_threads = threads;
+    Module::initBackend(MLLM_CPU);
+
+    std::unique_ptr<Module> model;
+    if (kind == "vision") {
+        // p: hidden_dim(out), vision_embed_dim  (heads 16, mlp 4x, QuickGELU, patch 14, 32 blocks: modeling_qwen2_vl.hpp:371)
+        Qwen2VLConfig cfg(64, "1.5b");
+        model.reset(new Qwen2VisionModel((int)p(0), (int)p(1), 16, (int)p(1) * 4, "QuickGELU", 14, 336, 32, 2,
+                                         cfg.attn_implementation, cfg.vision_names_config, cfg.vision_names_config.vison_model_name));
+    } else if (kind == "attn" || kind == "decoder" || kind == "mlp") {
+        // p: hidden, inter, heads, kv_heads, cache_limit
+        Qwen2VLConfig cfg((int)p(4, 64), "1.5b");
+        cfg.hidden_size = (int)p(0);
+        cfg.intermediate_size = (int)p(1);
+        cfg.num_attention_heads = (int)p(2);
+        cfg.num_key_value_heads = (int)p(3);
+        std::string base = cfg.names_config.blk_name + "0.";
+        if (kind == "attn") model.reset(new QWen2Attention(cfg, cfg.names_config, base + cfg.names_config._attn_base_name));
+        else if (kind == "mlp") model.reset(new QWen2MLP(cfg.hidden_size, cfg.intermediate_size, cfg.names_config, base + cfg.names_config._ffn_base_name));
+        else model.reset(new QWen2Decoder(cfg, cfg.names_config, base));
+    } else {
+        model.reset(new OpsModule(kind));
+    }
+    model->load(weights);
+
+    for (size_t c = 0; c < calls.size(); ++c) {
+        std::vector<Tensor> in;
+        int idx = 0;
+        for (auto &spec : split(calls[c], '+')) in.push_back(make_input(spec, idx++));
+        auto res = (*model)(in);
+        dump(res[0], out + "/out" + std::to_string(c) + ".f32");
+    }
+    return 0;
+}
