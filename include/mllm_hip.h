@@ -139,7 +139,7 @@ size_t mllm_hip_fa2_workspace_bytes(int Sq, int Hq, int D, int max_sk);
 /* ---- A16/A17: patch-embedding convolution with kernel == stride as a GEMM over flattened receptive fields
  *      (compute/Convolution.cpp:35-82,179-235): out[n][oc] = vec_dot_fp32(W[oc], patch[n]) + bias ------------------- */
 int mllm_hip_patch_gemm_f32(const float *patches, const float *W, const float *bias, float *out, int N, int KK, int OC, void *stream);
-/* gather of conv2d receptive fields from the `[H][C][W]` image into `[oh*ow][kh*C*kw]` rows (Convolution.cpp:8-33 order) */
+/* gather of conv2d receptive fields from the (h, c, w)-ordered image into `[oh*ow][c][kh][kw]` rows (Convolution.cpp:8-33,45-60) */
 int mllm_hip_im2patch_hcw(const float *img, float *patches, int H, int C, int W, int p, void *stream);
 
 /* ================================================================================================================

@@ -324,14 +324,15 @@ __global__ __launch_bounds__(256) void store_f16_kernel(const float *__restrict_
         out[(int64_t)s * ldo + c] = f2h(x[(int64_t)s * ldx + c]);
     }
 }
-// conv2d receptive-field gather, [H][C][W] image -> [oh*ow][kh][C][kw] rows (Convolution.cpp:8-33 / :45-60 order)
+// conv2d receptive-field gather: image given in logical (h, c, w) order -> rows [oh*ow][c][kh][kw], the flattening the
+// reference uses for both kernel and receptive field (Convolution.cpp:8-33, :45-60), so weights stay [OC][C][kh][kw]
 __global__ __launch_bounds__(256) void im2patch_hcw_kernel(const float *__restrict__ img, float *__restrict__ patches, int H, int C, int W, int p) {
     const int ow = W / p, KK = p * C * p;
     const int64_t total = (int64_t)(H / p) * ow * KK;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int k = (int)(t % KK);
         const int pix = (int)(t / KK);
-        const int kw = k % p, c = (k / p) % C, kh = k / (p * C);
+        const int kw = k % p, kh = (k / p) % p, c = k / (p * p);
         const int oy = pix / ow, ox = pix % ow;
         patches[t] = img[((int64_t)(oy * p + kh) * C + c) * W + ox * p + kw];
     }

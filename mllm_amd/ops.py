@@ -1,0 +1,246 @@
+"""Python face of the C-ABI launchers over torch CUDA(HIP) tensors: one function per reference Op on the hot path
+(names follow the reference's OpType / Layer names).  torch is plumbing only (device memory + current stream);
+every computation runs in libmllm_hip.so.  There is no CPU fallback: calling these without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .lib import F16, F32, Q4_0, Q4_K, check, i64, vp
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(x, dtype=None):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        x = x.to(dtype)
+    return x.contiguous().cuda()
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise L.MllmHipError("mllm_amd.ops needs an MI355X: no HIP device is visible (no CPU fallback exists)")
+    check(L.load().mllm_hip_init(C.c_int(torch.cuda.current_device())), "mllm_hip_init")
+
+
+class Q8K:
+    """q8k planes of `[M][K]` activations."""
+
+    def __init__(self, M, K):
+        self.M, self.K = M, K
+        self.qs = torch.empty((M, K), dtype=torch.int8, device="cuda")
+        self.d = torch.empty((M, K // 256), dtype=torch.float32, device="cuda")
+        self.bsums = torch.empty((M, K // 16), dtype=torch.int16, device="cuda")
+
+
+def quantize_q8k(x) -> Q8K:
+    x = _dev(x, torch.float32)
+    M, K = x.shape
+    q = Q8K(M, K)
+    check(L.load().mllm_hip_quantize_q8k(vp(x), vp(q.qs), vp(q.d), vp(q.bsums), C.c_int(M), C.c_int(K), _stream()), "quantize_q8k")
+    return q
+
+
+def quantize_q80(x):
+    x = _dev(x, torch.float32)
+    M, K = x.shape
+    qs = torch.empty((M, K), dtype=torch.int8, device="cuda")
+    d = torch.empty((M, K // 32), dtype=torch.int16, device="cuda")
+    check(L.load().mllm_hip_quantize_q80(vp(x), vp(qs), vp(d), C.c_int(M), C.c_int(K), _stream()), "quantize_q80")
+    return qs, d
+
+
+def linear_q4k(W_raw, x, N, bias=None, residual=None, out_f16=False, xq: Q8K | None = None):
+    """CPULinear with Q4_K weights: W_raw uint8 `[N * K/256 * 144]`, x fp32 `[M][K]`."""
+    W = _dev(W_raw, torch.uint8)
+    if xq is None:
+        xq = quantize_q8k(x)
+    M, K = xq.M, xq.K
+    b = _dev(bias, torch.float32) if bias is not None else None
+    r = _dev(residual, torch.float32) if residual is not None else None
+    y = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device="cuda")
+    check(L.load().mllm_hip_linear_q4k_q8k(vp(W), vp(b), vp(xq.qs), vp(xq.d), vp(xq.bsums), vp(y), C.c_int(F16 if out_f16 else F32), i64(N), vp(r),
+                                           C.c_int(M), C.c_int(N), C.c_int(K), _stream()), "linear_q4k_q8k")
+    return y
+
+
+def repack_q40(raw, n_blocks):
+    raw = _dev(raw, torch.uint8)
+    qs = torch.empty(n_blocks * 16, dtype=torch.uint8, device="cuda")
+    d = torch.empty(n_blocks, dtype=torch.int16, device="cuda")
+    check(L.load().mllm_hip_repack_q40(vp(raw), vp(qs), vp(d), i64(n_blocks), _stream()), "repack_q40")
+    return qs, d
+
+
+def linear_q40(W_raw, x, N, bias=None):
+    x = _dev(x, torch.float32)
+    M, K = x.shape
+    Wqs, Wd = repack_q40(W_raw, N * K // 32)
+    xqs, xd = quantize_q80(x)
+    b = _dev(bias, torch.float32) if bias is not None else None
+    y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_linear_q40_q80(vp(Wqs), vp(Wd), vp(b), vp(xqs), vp(xd), vp(y), i64(N), C.c_int(M), C.c_int(N), C.c_int(K), _stream()), "linear_q40_q80")
+    return y
+
+
+def linear_f32(W, x, bias=None):
+    W, x = _dev(W, torch.float32), _dev(x, torch.float32)
+    M, K = x.shape
+    N = W.numel() // K
+    b = _dev(bias, torch.float32) if bias is not None else None
+    y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_linear_f32(vp(W), vp(b), vp(x), vp(y), i64(N), C.c_int(M), C.c_int(N), C.c_int(K), _stream()), "linear_f32")
+    return y
+
+
+def embedding_q40(ids, W_raw, vocab, hidden):
+    Wqs, Wd = repack_q40(W_raw, vocab * hidden // 32)
+    ids = _dev(np.asarray(ids, dtype=np.float32))
+    out = torch.empty((ids.numel(), hidden), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_embedding_q40(vp(ids), vp(Wqs), vp(Wd), vp(out), C.c_int(ids.numel()), C.c_int(hidden), C.c_int(vocab), _stream()), "embedding_q40")
+    return out
+
+
+def rmsnorm(x, w, eps, add_unit_offset=False, quant=False):
+    x, w = _dev(x, torch.float32), _dev(w, torch.float32)
+    M, dim = x.shape
+    y = torch.empty_like(x)
+    q = Q8K(M, dim) if quant else None
+    check(L.load().mllm_hip_rmsnorm(vp(x), vp(w), vp(y), vp(q.qs if q else None), vp(q.d if q else None), vp(q.bsums if q else None),
+                                    C.c_int(M), C.c_int(dim), C.c_float(eps), C.c_int(int(add_unit_offset)), _stream()), "rmsnorm")
+    return (y, q) if quant else y
+
+
+def layernorm(x, w, b, eps, quant=False):
+    x, w = _dev(x, torch.float32), _dev(w, torch.float32)
+    b = _dev(b, torch.float32) if b is not None else None
+    M, dim = x.shape
+    y = torch.empty_like(x)
+    q = Q8K(M, dim) if quant else None
+    check(L.load().mllm_hip_layernorm(vp(x), vp(w), vp(b), vp(y), vp(q.qs if q else None), vp(q.d if q else None), vp(q.bsums if q else None),
+                                      C.c_int(M), C.c_int(dim), C.c_float(eps), _stream()), "layernorm")
+    return (y, q) if quant else y
+
+
+def _unary(fn, x, *extra):
+    x = _dev(x, torch.float32)
+    y = torch.empty_like(x)
+    check(getattr(L.load(), fn)(vp(x), vp(y), i64(x.numel()), *extra, _stream()), fn)
+    return y
+
+
+def silu(x):
+    return _unary("mllm_hip_silu", x)
+
+
+_luts = None
+
+
+def _act_luts():
+    global _luts
+    if _luts is None:
+        g, q = L.build_act_luts()
+        _luts = (_dev(g.view(np.int16)), _dev(q.view(np.int16)))
+    return _luts
+
+
+def gelu(x):
+    return _unary("mllm_hip_act_lut", x, vp(_act_luts()[0]))
+
+
+def quickgelu(x):
+    return _unary("mllm_hip_act_lut", x, vp(_act_luts()[1]))
+
+
+def silu_mul(gu, I):
+    gu = _dev(gu, torch.float32)
+    M = gu.shape[0]
+    y = torch.empty((M, I), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_silu_mul(vp(gu), vp(y), C.c_int(M), C.c_int(I), _stream()), "silu_mul")
+    return y
+
+
+def add(a, b):
+    a, b = _dev(a, torch.float32), _dev(b, torch.float32)
+    y = torch.empty_like(a)
+    check(L.load().mllm_hip_add(vp(a), vp(b), vp(y), i64(a.numel()), _stream()), "add")
+    return y
+
+
+def mul(a, b):
+    a, b = _dev(a, torch.float32), _dev(b, torch.float32)
+    y = torch.empty_like(a)
+    check(L.load().mllm_hip_mul(vp(a), vp(b), vp(y), i64(a.numel()), _stream()), "mul")
+    return y
+
+
+def softmax(x, valid=None):
+    x = _dev(x, torch.float32)
+    n = x.shape[-1]
+    rows = x.numel() // n
+    y = torch.empty_like(x)
+    v = _dev(np.asarray(valid, dtype=np.int32)) if valid is not None else None
+    check(L.load().mllm_hip_softmax(vp(x), vp(y), C.c_int(rows), C.c_int(n), vp(v), _stream()), "softmax")
+    return y
+
+
+def argmax(x):
+    x = _dev(x, torch.float32)
+    out = torch.empty(1, dtype=torch.int32, device="cuda")
+    check(L.load().mllm_hip_argmax(vp(x), C.c_int(x.numel()), vp(out), _stream()), "argmax")
+    return int(out.item())
+
+
+def index_put_rows(dst, value, idx):
+    dst, value = _dev(dst, torch.float32).clone(), _dev(value, torch.float32)
+    idx = _dev(np.asarray(idx, dtype=np.int32))
+    check(L.load().mllm_hip_index_put_rows(vp(dst), vp(value), vp(idx), C.c_int(idx.numel()), C.c_int(dst.shape[-1]), _stream()), "index_put_rows")
+    return dst
+
+
+def rope_apply(x, S, H, D, sin_t, cos_t, out_f16=False):
+    x, sin_t, cos_t = _dev(x, torch.float32), _dev(sin_t, torch.float32), _dev(cos_t, torch.float32)
+    out = torch.empty((S, H * D), dtype=torch.float16 if out_f16 else torch.float32, device="cuda")
+    check(L.load().mllm_hip_rope_apply(vp(x), i64(H * D), vp(sin_t), vp(cos_t), C.c_int(sin_t.shape[-1]), vp(out), C.c_int(F16 if out_f16 else F32),
+                                       i64(H * D), C.c_int(S), C.c_int(H), C.c_int(D), _stream()), "rope_apply")
+    return out
+
+
+def flash_attention2(q, k, v, Sq, Sk, Hq, Hkv, D, causal, sk_dev=None):
+    """Tensor::flash_attention2_forward: q fp32 [Sq][Hq*D]; k, v fp16 or fp32 [Sk][Hkv*D]."""
+    q = _dev(q, torch.float32)
+    k, v = _dev(k), _dev(v)
+    kv_dt = F16 if k.dtype == torch.float16 else F32
+    o = torch.empty((Sq, Hq * D), dtype=torch.float32, device="cuda")
+    wsb = L.load().mllm_hip_fa2_workspace_bytes(C.c_int(Sq), C.c_int(Hq), C.c_int(D), C.c_int(Sk))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+    check(L.load().mllm_hip_fa2(vp(q), i64(Hq * D), vp(k), i64(Hkv * D), vp(v), i64(Hkv * D), C.c_int(kv_dt), vp(o), i64(Hq * D), C.c_int(Sq), C.c_int(Sk),
+                                C.c_int(Hq), C.c_int(Hkv), C.c_int(D), C.c_int(int(causal)), vp(sk_dev), vp(ws), _stream()), "fa2")
+    return o
+
+
+def patch_gemm(patches, W, bias=None):
+    patches, W = _dev(patches, torch.float32), _dev(W, torch.float32)
+    N, KK = patches.shape
+    OC = W.numel() // KK
+    b = _dev(bias, torch.float32) if bias is not None else None
+    out = torch.empty((N, OC), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_patch_gemm_f32(vp(patches), vp(W), vp(b), vp(out), C.c_int(N), C.c_int(KK), C.c_int(OC), _stream()), "patch_gemm")
+    return out
+
+
+def conv2d_patch(img_hcw, H, Cc, Wd, Wt, OC, p, bias=None):
+    img = _dev(img_hcw, torch.float32)
+    KK = p * Cc * p
+    patches = torch.empty(((H // p) * (Wd // p), KK), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_im2patch_hcw(vp(img), vp(patches), C.c_int(H), C.c_int(Cc), C.c_int(Wd), C.c_int(p), _stream()), "im2patch")
+    out = patch_gemm(patches, Wt, bias)  # [oh*ow][OC]
+    return out.reshape(H // p, Wd // p, OC).permute(0, 2, 1).contiguous()

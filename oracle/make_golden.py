@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""oracle/make_golden.py -- TEST INFRASTRUCTURE.  Generates the committed golden vectors under tests/golden/ by running
+the compiled REFERENCE itself (oracle/_ref/ref_ops, ref_qwen2vl, quantize -- built by oracle/Makefile.ref from
+/root/reference).  Runs only in the development container; the GPU box sees only the resulting small .npz files.
+
+    make -f oracle/Makefile.ref -j8 && python oracle/make_golden.py [--full]
+
+Every case stores its inputs (fp32), the raw weight bytes the reference consumed and the reference's outputs, so the
+tests need neither the reference nor a quantiser to replay it.
+"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mllm_amd import mllmfile as mf, synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def run_ops(case, weights, calls, p=(), threads=4):
+    """calls: list of list of (array, shape-tuple). Returns list of outputs (flat fp32)."""
+    with tempfile.TemporaryDirectory() as td:
+        args = [os.path.join(REF, "ref_ops"), f"case={case}", f"weights={weights}", f"out={td}", f"threads={threads}"]
+        if len(p):
+            args.append("p=" + ",".join(repr(float(v)) if isinstance(v, float) else str(v) for v in p))
+        for ci, call in enumerate(calls):
+            specs = []
+            for ii, (arr, shp) in enumerate(call):
+                fn = os.path.join(td, f"in{ci}_{ii}.f32")
+                np.ascontiguousarray(arr, dtype=np.float32).tofile(fn)
+                specs.append(fn + ":" + ",".join(str(int(s)) for s in shp))
+            args.append("call=" + "+".join(specs))
+        out = subprocess.run(args, check=True, capture_output=True, text=True)
+        res = [np.fromfile(os.path.join(td, f"out{ci}.f32"), dtype=np.float32) for ci in range(len(calls))]
+        return res, out.stdout
+
+
+def quantize_file(specs_arrays, target="Q4_K"):
+    """specs_arrays: list of (name, fp32 array). Writes fp32 .mllm, runs the reference `quantize`, returns MllmFile path."""
+    td = tempfile.mkdtemp()
+    src, dst = os.path.join(td, "w_f32.mllm"), os.path.join(td, "w_q.mllm")
+    mf.write_mllm(src, [(n, mf.F32, np.ascontiguousarray(a, dtype=np.float32)) for n, a in specs_arrays])
+    if target == "F32":
+        return src
+    subprocess.run([os.path.join(REF, "quantize"), src, dst, target], check=True, capture_output=True)
+    return dst
+
+
+def raw(path, name):
+    f = mf.MllmFile(path)
+    r = np.array(f.raw(name))
+    dt = f.dtype(name)
+    f.close()
+    return r, dt
+
+
+def ops_golden():
+    rng = np.random.default_rng(1234)
+    G = {}
+
+    def rn(*s, scale=1.0):
+        return (rng.standard_normal(s) * scale).astype(np.float32)
+
+    # ---- A1/A2/A5: Linear Q4_K (+bias), M = 5 and M = 1; K = 512, N = 96 ------------------------------------------------
+    W, b = rn(96, 512, scale=0.05), rn(96, scale=0.1)
+    path = quantize_file([("lin.weight", W), ("lin.bias", b)])
+    x5, x1 = rn(5, 512), rn(1, 512)
+    (y5, y1), _ = run_ops("linear", path, [[(x5, (1, 1, 5, 512))], [(x1, (1, 1, 1, 512))]], p=(512, 96, 1))
+    wq, dt = raw(path, "lin.weight")
+    assert dt == mf.Q4_K
+    G.update(lin_w=wq, lin_b=b, lin_x5=x5, lin_y5=y5.reshape(5, 96), lin_x1=x1, lin_y1=y1.reshape(1, 96), lin_w_f32=W)
+    # Linear with fp32 weights (TinyLlama config / patch-embed path), no bias, K = 64 (not a multiple of 32 lanes*4)
+    Wf = rn(24, 72, scale=0.1)
+    pathf = quantize_file([("lin.weight", Wf)], target="F32")
+    xf = rn(3, 72)
+    (yf,), _ = run_ops("linear", pathf, [[(xf, (1, 1, 3, 72))]], p=(72, 24, 0))
+    G.update(linf_w=Wf, linf_x=xf, linf_y=yf.reshape(3, 24))
+
+    # ---- A6/A7/A8: tied lm_head through Q4_0 x Q8_0 (Tensor::mm on the embedding Parameter) and the embedding gather ---
+    E = rn(160, 512, scale=0.05)
+    pathe = quantize_file([("model.embed_tokens.weight", E)])
+    eq, dt = raw(pathe, "model.embed_tokens.weight")
+    assert dt == mf.Q4_0
+    xh = rn(2, 512)
+    (lg,), _ = run_ops("mm_tied", pathe, [[(xh, (1, 1, 2, 512))]], p=(160, 512))
+    ids = np.array([3, 159, 0, 77, 3], dtype=np.float32)
+    (emb,), _ = run_ops("embedding", pathe, [[(ids, (1, 1, 5, 1))]], p=(160, 512))
+    G.update(emb_w=eq, mm_x=xh, mm_y=lg.reshape(2, 160), emb_ids=ids, emb_y=emb.reshape(5, 512))
+
+    # ---- A9 / A18 norms ----------------------------------------------------------------------------------------------------
+    nw, nb_ = (1.0 + rn(256, scale=0.1)), rn(256, scale=0.1)
+    pn = quantize_file([("norm.weight", nw), ("ln.weight", nw), ("ln.bias", nb_)], target="F32")
+    xn = rn(3, 256, scale=2.0)
+    (yr,), _ = run_ops("rmsnorm", pn, [[(xn, (1, 1, 3, 256))]], p=(256, 1e-6))
+    (yl,), _ = run_ops("layernorm", pn, [[(xn, (1, 1, 3, 256))]], p=(256, 1e-6))
+    G.update(norm_w=nw, norm_b=nb_, norm_x=xn, rms_y=yr.reshape(3, 256), ln_y=yl.reshape(3, 256))
+
+    # ---- A14 / A18 activations, A15 softmax --------------------------------------------------------------------------------
+    xa = np.concatenate([rn(3, 264, scale=3.0).ravel(), np.array([0.0, -0.0, 20.0, -20.0, 90.0, -90.0, 1e-8, 5.5], dtype=np.float32)]).reshape(1, -1)
+    n_act = xa.size
+    for k in ("silu", "gelu", "quickgelu"):
+        (ya,), _ = run_ops(k, pn, [[(xa, (1, 1, 1, n_act))]])
+        G[k + "_y"] = ya
+    G["act_x"] = xa.ravel()
+    xs = rn(2, 3, 24, scale=2.0)
+    (ys,), _ = run_ops("softmax", pn, [[(xs, (1, 2, 3, 24))]], p=(0,))
+    G.update(sm_x=xs, sm_y=ys.reshape(2, 3, 24))
+
+    # ---- A16 / A17 patch-embed convolutions ---------------------------------------------------------------------------------
+    Wc = rn(16, 1176, scale=0.05)
+    pc = quantize_file([("proj.weight", Wc)], target="F32")
+    px = rn(6, 1176)
+    (yc,), _ = run_ops("conv3d", pc, [[(px, (6, 3, 2, 14, 14))]], p=(16,))
+    G.update(conv3_w=Wc, conv3_x=px, conv3_y=yc.reshape(6, 16))
+    W2, b2 = rn(8, 3, 4, 4, scale=0.2), rn(8, scale=0.1)
+    pc2 = quantize_file([("proj.weight", W2), ("proj.bias", b2)], target="F32")
+    img = rn(8, 3, 12)  # [H][C][W]
+    (y2,), log = run_ops("conv2d", pc2, [[(img, (1, 8, 3, 12))]], p=(8, 4, 1))
+    G.update(conv2_w=W2, conv2_b=b2, conv2_x=img, conv2_y=y2, conv2_log=np.frombuffer(log.encode(), dtype=np.uint8))
+
+    # ---- A10 / A11 / A19 rotary ------------------------------------------------------------------------------------------
+    q = rn(5, 2 * 128)
+    pos = np.array([[0, 1, 1, 1, 2], [0, 1, 1, 2, 2], [0, 1, 2, 1, 2]], dtype=np.float32) * np.float32(3)
+    pos[:, 4] = 7
+    (ym,), _ = run_ops("mrope", pn, [[(q, (1, 1, 5, 256)), (pos, (3, 1, 1, 5))]], p=(1000000.0, 32768, 2, 128))
+    G.update(mrope_x=q, mrope_pos=pos, mrope_y=ym.reshape(5, 256))
+    q2 = rn(5, 2 * 64)
+    (yh,), _ = run_ops("rope", pn, [[(q2, (1, 1, 5, 128))]], p=(4, 10000.0, 64, 2, 64))  # HFHUBROPE = 4
+    G.update(rope_x=q2, rope_y=yh.reshape(5, 128))
+    qv = rn(16, 2 * 16)
+    grid = np.array([1, 4, 4], dtype=np.float32)
+    (yv,), _ = run_ops("vrope", pn, [[(qv, (1, 1, 16, 32)), (grid, (1, 1, 1, 3))]], p=(8, 2, 2, 16))
+    G.update(vrope_x=qv, vrope_y=yv.reshape(16, 32))
+
+    # ---- A13 attention, fp32 K/V (vision path): non-causal 40x40 D=16 H=2; causal with GQA (Hq=4, Hkv=2), Sq = Sk = 12 ----
+    qa, ka, va = rn(40, 2 * 16), rn(40, 2 * 16), rn(40, 2 * 16)
+    (oa,), _ = run_ops("fa2", pn, [[(qa, (1, 1, 40, 32)), (ka, (1, 1, 40, 32)), (va, (1, 1, 40, 32))]], p=(2, 2, 16, 0), threads=2)
+    G.update(fa_q=qa, fa_k=ka, fa_v=va, fa_o=oa.reshape(40, 32))
+    qb, kb, vb = rn(12, 4 * 16), rn(12, 2 * 16), rn(12, 2 * 16)
+    (ob,), _ = run_ops("fa2", pn, [[(qb, (1, 1, 12, 64)), (kb, (1, 1, 12, 32)), (vb, (1, 1, 12, 32))]], p=(4, 2, 16, 1), threads=2)
+    G.update(fac_q=qb, fac_k=kb, fac_v=vb, fac_o=ob.reshape(12, 64))
+
+    # ---- A21 blocks: QWen2Attention (A1+A11+A12+A13: prefill 8 tokens, then one decode token), QWen2MLP ---------------------
+    H, I, heads, kvh = 256, 512, 2, 1
+    names = {}
+    pfx = "model.layers.0."
+    for n, s, k in synth.qwen2vl_tensors(synth.Qwen2VLConfig(hidden=H, inter=I, layers=1, heads=heads, kv_heads=kvh, vocab=64), vision=False):
+        if n.startswith(pfx + "self_attn") or n.startswith(pfx + "mlp"):
+            names[n] = synth.tensor_f32(n, s, k) * (np.float32(2.5) if k == "w" else np.float32(1))
+    pa = quantize_file(list(names.items()))
+    xa8, xa1 = rn(8, H), rn(1, H)
+    pos8 = np.tile(np.arange(8, dtype=np.float32), (3, 1))
+    pos1 = np.full((3, 1), 8, dtype=np.float32)
+    (a8, a1), _ = run_ops("attn", pa, [[(xa8, (1, 1, 8, H)), (pos8, (3, 1, 1, 8))], [(xa1, (1, 1, 1, H)), (pos1, (3, 1, 1, 1))]], p=(H, I, heads, kvh, 32), threads=1)
+    (ml,), _ = run_ops("mlp", pa, [[(xa8, (1, 1, 8, H))]], p=(H, I, heads, kvh, 32))
+    f = mf.MllmFile(pa)
+    for n in f.names():
+        if n.startswith(pfx):
+            G["blk_" + n[len(pfx):].replace(".", "_")] = np.array(f.raw(n))
+    f.close()
+    G.update(blk_x8=xa8, blk_x1=xa1, blk_attn8=a8.reshape(8, H), blk_attn1=a1.reshape(1, H), blk_mlp8=ml.reshape(8, H))
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **G)
+    print("ops.npz:", len(G), "arrays,", os.path.getsize(os.path.join(GOLD, "ops.npz")) // 1024, "KiB")
+
+
+def e2e_tiny():
+    c = synth.qwen2vl_tiny()
+    td = tempfile.mkdtemp()
+    src, dst = os.path.join(td, "f32.mllm"), os.path.join(td, "q4k.mllm")
+    synth.write_fp32_mllm(src, synth.qwen2vl_tensors(c))
+    subprocess.run([os.path.join(REF, "quantize"), src, dst, "Q4_K"], check=True, capture_output=True)
+    pix, grid, ids = synth.qwen2vl_inputs(c, (8, 8), 6)
+    pix.tofile(os.path.join(td, "pix.f32"))
+    ids.tofile(os.path.join(td, "ids.i32"))
+    cfg = f"{c.hidden},{c.inter},{c.layers},{c.heads},{c.kv_heads},{c.vocab},{c.v_dim},{c.cache_limit},{c.image_token_id},{c.vision_start_token_id},{c.vision_end_token_id},{c.video_token_id}"
+    steps = 24
+    subprocess.run([os.path.join(REF, "ref_qwen2vl"), "--model", dst, "--ids", os.path.join(td, "ids.i32"), "--pix", os.path.join(td, "pix.f32"),
+                    "--grid", "1,8,8", "--steps", str(steps), "--threads", "4", "--out", td, "--cfg", cfg, "--dump-every", "1"], check=True, capture_output=True)
+    toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
+    logits = np.stack([np.fromfile(os.path.join(td, f"logits_{s}.f32"), dtype=np.float32) for s in range(steps)])
+    # vision tower alone (image_embeds) for stage-wise debugging
+    (emb,), _ = run_ops("vision", dst, [[(pix, (64, 3, 2, 14, 14)), (grid.astype(np.float32), (1, 1, 1, 3))]], p=(c.hidden, c.v_dim))
+    # text-only prompt (no image): exercises the has_img == false path
+    ids_t = np.random.default_rng(5).integers(0, 2000, size=9).astype(np.int32)
+    ids_t.tofile(os.path.join(td, "ids_t.i32"))
+    td2 = tempfile.mkdtemp()
+    subprocess.run([os.path.join(REF, "ref_qwen2vl"), "--model", dst, "--ids", os.path.join(td, "ids_t.i32"), "--steps", "6", "--threads", "4",
+                    "--out", td2, "--cfg", cfg, "--dump-every", "1"], check=True, capture_output=True)
+    toks_t = np.fromfile(os.path.join(td2, "tokens.i32"), dtype=np.int32)
+    logits_t = np.stack([np.fromfile(os.path.join(td2, f"logits_{s}.f32"), dtype=np.float32) for s in range(6)])
+    f = mf.MllmFile(dst)
+    import hashlib
+    dig = {n: hashlib.sha256(f.raw(n).tobytes()).hexdigest()[:16] for n in f.names() if n != "lm_head.weight"}
+    f.close()
+    np.savez_compressed(os.path.join(GOLD, "qwen2vl_tiny.npz"), ids=ids, grid=grid, tokens=toks, logits=logits, image_embeds=emb.reshape(-1, c.hidden),
+                        ids_text=ids_t, tokens_text=toks_t, logits_text=logits_t)
+    json.dump(dig, open(os.path.join(GOLD, "qwen2vl_tiny_q4k_digests.json"), "w"), indent=0, sort_keys=True)
+    print("qwen2vl_tiny.npz tokens", toks.tolist())
+
+
+def e2e_full(out_dir="/tmp/full/out", run_log="/tmp/full/run.log"):
+    """Packs the full-size (Qwen2-VL-2B shaped) reference run made with ref_qwen2vl on /tmp/full/q2vl_q4k.mllm
+    (reference-quantised synthetic weights): greedy ids, top-64 logits and a strided sample of the dumped logits rows."""
+    toks = np.fromfile(os.path.join(out_dir, "tokens.i32"), dtype=np.int32)
+    steps = sorted(int(f[7:-4]) for f in os.listdir(out_dir) if f.startswith("logits_"))
+    top_i, top_v, samp = [], [], []
+    for s in steps:
+        l = np.fromfile(os.path.join(out_dir, f"logits_{s}.f32"), dtype=np.float32)
+        idx = np.argsort(-l, kind="stable")[:64]
+        top_i.append(idx.astype(np.int32)); top_v.append(l[idx]); samp.append(l[::97].copy())
+    timing = open(run_log).read().splitlines()[0]
+    np.savez_compressed(os.path.join(GOLD, "qwen2vl_2b_ref.npz"), tokens=toks, steps=np.array(steps, dtype=np.int32), top_idx=np.stack(top_i),
+                        top_val=np.stack(top_v), strided=np.stack(samp), timing=np.frombuffer(timing.encode(), dtype=np.uint8))
+    print("qwen2vl_2b_ref.npz", toks[:8], timing)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    ops_golden()
+    e2e_tiny()
+    if "--full" in sys.argv:
+        e2e_full()

@@ -54,8 +54,8 @@ public:
         else if (k == "gelu") l0 = GELU("act");
         else if (k == "quickgelu") l0 = QuickGELU("act");
         else if (k == "softmax") sm = Softmax(DIMENSION, p(0) != 0, "sm");
-        else if (k == "embedding") l0 = Embedding((int)p(0), (int)p(1), "emb");
-        else if (k == "mm_tied") param = Parameter(1, (int)p(0), 1, (int)p(1), "emb.weight");
+        else if (k == "embedding") l0 = Embedding((int)p(0), (int)p(1), "model.embed_tokens");
+        else if (k == "mm_tied") param = Parameter(1, (int)p(0), 1, (int)p(1), "model.embed_tokens.weight");
         else if (k == "conv3d") l0 = Convolution3D(3, (int)p(0), {2, 14, 14}, {2, 14, 14}, VALID, false, "proj");
         else if (k == "conv2d") l0 = Convolution2D(3, (int)p(0), {(int)p(1), (int)p(1)}, {(int)p(1), (int)p(1)}, VALID, p(2) != 0, "proj");
         else if (k == "vrope") l0 = VisionRoPE((int)p(0), (int)p(1), "rot");

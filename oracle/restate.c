@@ -215,7 +215,7 @@ float orc_vec_dot_f32(int n, const float *x, const float *y) {
     float t[4] = {a[0] + a[4], a[1] + a[5], a[2] + a[6], a[3] + a[7]};
     float h0 = t[0] + t[1], h1 = t[2] + t[3];
     float sumf = h0 + h1;
-    for (int i = np; i < n; ++i) sumf += x[i] * y[i];
+    for (int i = np; i < n; ++i) sumf = fmaf(x[i], y[i], sumf);   /* contracted by the reference build (g++ -O2 -mfma) */
     return sumf;
 }
 
@@ -415,6 +415,19 @@ void orc_vision_rope_angles(int t, int h, int w, int merge, int rot_dim, float *
                     }
     free(inv);
 }
+#ifndef ROTV
+#define ROTV 1
+#endif
+#if ROTV == 0
+#define ROT1(a,b,s,c) ((a)*(c)-(b)*(s))
+#define ROT2(a,b,s,c) ((a)*(s)+(b)*(c))
+#elif ROTV == 1
+#define ROT1(a,b,s,c) fmaf((a),(c),-((b)*(s)))
+#define ROT2(a,b,s,c) fmaf((a),(s),(b)*(c))
+#else
+#define ROT1(a,b,s,c) fmaf(-(b),(s),(a)*(c))
+#define ROT2(a,b,s,c) fmaf((b),(c),(a)*(s))
+#endif
 /* rope_hf rotate (CPUMultimodalRoPE.cpp:153-221 / CPURoPE.cpp:261-...): x is [S][H][D] (BSHD); sin/cos [S][ld] use cols < D/2.
  * out fp32 or fp16 (K written straight into the fp16 cache). */
 void orc_rope_apply(const float *x, int S, int H, int D, const float *sin_t, const float *cos_t, int ld, void *out, int out_f16) {
@@ -425,7 +438,7 @@ void orc_rope_apply(const float *x, int S, int H, int D, const float *sin_t, con
                 size_t o = ((size_t)s * H + h) * D + d;
                 float a = x[o], b = x[o + half];
                 float sv = sin_t[(size_t)s * ld + d], cv = cos_t[(size_t)s * ld + d];
-                float v1 = a * cv - b * sv, v2 = a * sv + b * cv;
+                float v1 = ROT1(a, b, sv, cv), v2 = ROT2(a, b, sv, cv);
                 if (out_f16) { ((uint16_t *)out)[o] = orc_f32_to_f16(v1); ((uint16_t *)out)[o + half] = orc_f32_to_f16(v2); }
                 else { ((float *)out)[o] = v1; ((float *)out)[o + half] = v2; }
             }
@@ -439,8 +452,8 @@ void orc_vision_rope_apply(const float *x, int S, int H, int D, const float *ang
                 size_t o = ((size_t)s * H + h) * D + d;
                 float a = x[o], b = x[o + half];
                 float sv = sinf(angle[(size_t)s * half + d]), cv = cosf(angle[(size_t)s * half + d]);
-                out[o] = a * cv - b * sv;
-                out[o + half] = a * sv + b * cv;
+                out[o] = ROT1(a, b, sv, cv);
+                out[o + half] = ROT2(a, b, sv, cv);
             }
 }
 
@@ -498,32 +511,25 @@ void orc_patch_gemm(const float *patches, int N, int KK, const float *W, int OC,
             out[(size_t)n * OC + oc] = v;
         }
 }
-/* conv2d (ViT/CLIP): image [H][C][W] (mllm BSHD with head=H, seq=C: models/vit/processing_vit.hpp:18-26), weight file layout
- * [OC][C][kh][kw]; the reference relays the kernel to [kh][C][kw] (Convolution.cpp:8-33) and gathers the receptive
- * field in the same order; out [H/p][OC][W/p]. */
+/* conv2d (ViT/CLIP): image tensor [B, H, C, W] in mllm terms (head = H, sequence = C: models/vit/processing_vit.hpp:18-26),
+ * given here in logical (h, c, w) order; weight file layout [OC][C][kh][kw]. The reference flattens kernel and receptive
+ * field as [c][kh][kw] (Convolution.cpp:8-33 and :45-60), so the weight needs no relayout; out is logical [H/p][OC][W/p]. */
 void orc_conv2d_patch(const float *img, int H, int C, int Wd, const float *Wt, int OC, int p, const float *bias, float *out) {
     int oh = H / p, ow = Wd / p, KK = p * C * p;
-    float *kn = (float *)malloc((size_t)OC * KK * 4);
-    for (int oc = 0; oc < OC; ++oc)
-        for (int kh = 0; kh < p; ++kh)
-            for (int c = 0; c < C; ++c)
-                for (int kw = 0; kw < p; ++kw)
-                    kn[(size_t)oc * KK + (kh * C + c) * p + kw] = Wt[(((size_t)oc * C + c) * p + kh) * p + kw];
 #pragma omp parallel for collapse(2)
     for (int y = 0; y < oh; ++y)
         for (int x = 0; x < ow; ++x) {
             float *rf = (float *)malloc(KK * 4);
-            for (int kh = 0; kh < p; ++kh)
-                for (int c = 0; c < C; ++c)
-                    for (int kw = 0; kw < p; ++kw) rf[(kh * C + c) * p + kw] = img[((size_t)(y * p + kh) * C + c) * Wd + x * p + kw];
+            for (int c = 0; c < C; ++c)
+                for (int kh = 0; kh < p; ++kh)
+                    for (int kw = 0; kw < p; ++kw) rf[(c * p + kh) * p + kw] = img[((size_t)(y * p + kh) * C + c) * Wd + x * p + kw];
             for (int oc = 0; oc < OC; ++oc) {
-                float v = orc_vec_dot_f32(KK, kn + (size_t)oc * KK, rf);
+                float v = orc_vec_dot_f32(KK, Wt + (size_t)oc * KK, rf);
                 if (bias) v += bias[oc];
                 out[((size_t)y * OC + oc) * ow + x] = v;
             }
             free(rf);
         }
-    free(kn);
 }
 
 /* A20: elementwise (CPUBinaryFunc.hpp F_TTADD / F_TTMUL) */

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ops_gold():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLD, "ops.npz")))
+
+
+@pytest.fixture(scope="session")
+def tiny_gold():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLD, "qwen2vl_tiny.npz")))
