@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd)))

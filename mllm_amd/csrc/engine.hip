@@ -187,7 +187,7 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
     M *m = new M();
     m->c = *cfg;
     const auto &c = m->c;
-    if (c.hidden % c.heads || c.hidden % 512 || c.inter % 256 || c.heads % c.kv_heads) { delete m; return MLLM_HIP_ERR_SHAPE; }
+    if (c.hidden % c.heads || c.hidden % 256 || c.inter % 256 || c.heads % c.kv_heads) { delete m; return MLLM_HIP_ERR_SHAPE; }
     m->D = c.hidden / c.heads;
     m->HD = c.heads * m->D;
     m->KVD = c.kv_heads * m->D;

@@ -113,21 +113,22 @@ __global__ __launch_bounds__(256) void gemv_q4k_kernel(const uint8_t *__restrict
 
 // ------------------------------------------------------------------------------------------------------------------
 // Q4_0 (nibble/scale planes) x Q8_0 GEMV (M == 1): the tied lm_head (modeling_qwen2_vl.hpp:399 -> CPUmmFunction ->
-// vec_dot_q4_0_q8_0, VecDotQ4.cpp:514-545). 16 lanes per row, BPL blocks per lane, 4 rows per wave iteration.
+// vec_dot_q4_0_q8_0, VecDotQ4.cpp:514-545). LPR lanes per row, BPL blocks per lane (K = 32*LPR*BPL), 64/LPR rows per wave pass.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BPL>
+template <int BPL, int LPR>
 __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict__ Wqs, const uint16_t *__restrict__ Wd, const float *__restrict__ bias,
                                                        const int8_t *__restrict__ xqs, const uint16_t *__restrict__ xd, float *__restrict__ y, int N,
                                                        int rows_per_wave) {
-    const int lane = threadIdx.x & 63, sub = lane & 15, rsel = lane >> 4;
+    constexpr int RPW = 64 / LPR;  // rows per wave pass
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nblk = BPL * 16;
+    const int nblk = BPL * LPR;
     int4 xa[BPL], xb[BPL];
     float xdv[BPL];
     int xs8[BPL];
 #pragma unroll
     for (int b = 0; b < BPL; ++b) {
-        const int blk = sub + 16 * b;
+        const int blk = sub + LPR * b;
         xa[b] = *reinterpret_cast<const int4 *>(xqs + blk * 32);
         xb[b] = *reinterpret_cast<const int4 *>(xqs + blk * 32 + 16);
         xdv[b] = h2f(xd[blk]);
@@ -137,15 +138,15 @@ __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict
         xs8[b] = 8 * s;
     }
     const int row0 = wave * rows_per_wave, row1 = min(N, row0 + rows_per_wave);
-    for (int base = row0; base < row1; base += 8) {
+    for (int base = row0; base < row1; base += 2 * RPW) {
         uint4 q[2][BPL];
         uint16_t dw[2][BPL];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int rw = min(base + 4 * u + rsel, row1 - 1);
+            const int rw = min(base + RPW * u + rsel, row1 - 1);
 #pragma unroll
             for (int b = 0; b < BPL; ++b) {
-                const int64_t bi = (int64_t)rw * nblk + sub + 16 * b;
+                const int64_t bi = (int64_t)rw * nblk + sub + LPR * b;
                 q[u][b] = *reinterpret_cast<const uint4 *>(Wqs + bi * 16);
                 dw[u][b] = Wd[bi];
             }
@@ -166,11 +167,9 @@ __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict
                 i -= xs8[b];  // (nib - 8) * q8 summed
                 acc = __fmaf_rn(__fmul_rn(h2f(dw[u][b]), xdv[b]), (float)i, acc);
             }
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            acc += __shfl_xor(acc, 8, 64);
-            const int rw = base + 4 * u + rsel;
+#pragma unroll
+            for (int msk = 1; msk < LPR; msk <<= 1) acc += __shfl_xor(acc, msk, 64);
+            const int rw = base + RPW * u + rsel;
             if (sub == 0 && rw < row1) y[rw] = bias ? __fadd_rn(acc, bias[rw]) : acc;
         }
     }
@@ -360,20 +359,23 @@ extern "C" int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const i
 
 extern "C" int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, const float *bias, const int8_t *xqs, const uint16_t *xd,
                                        float *y, int64_t ldy, int M, int N, int K, void *stream) {
-    if (K % 512 != 0 || K / 512 > 8 || N <= 0) return MLLM_HIP_ERR_SHAPE;
+    if (K % 256 != 0 || K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
+    // 16 lanes per row when K is a multiple of 512 (<= 8 blocks per lane), else 8 lanes per row (K multiple of 256)
+    const int lpr = (K % 512 == 0 && K / 512 <= 8) ? 16 : 8;
+    const int bpl = K / 32 / lpr;
+    if (bpl > 8) return MLLM_HIP_ERR_SHAPE;
     hipStream_t st = as_stream(stream);
-    const int target_waves = 256 * 8;
+    const int target_waves = 256 * 8, rpp = 2 * (64 / lpr);
     int rows_per_wave = (N + target_waves - 1) / target_waves;
-    rows_per_wave = ((rows_per_wave + 7) / 8) * 8;
+    rows_per_wave = ((rows_per_wave + rpp - 1) / rpp) * rpp;
     const int waves = (N + rows_per_wave - 1) / rows_per_wave;
     for (int m = 0; m < M; ++m) {
         const int8_t *xq = xqs + (int64_t)m * K;
         const uint16_t *xdd = xd + (int64_t)m * (K / 32);
         float *ym = y + (int64_t)m * ldy;
-#define Q40_CASE(B) case B: hipLaunchKernelGGL((gemv_q40_kernel<B>), dim3((waves + 3) / 4), dim3(256), 0, st, Wqs, Wd, bias, xq, xdd, ym, N, rows_per_wave); break;
-        switch (K / 512) {
-            Q40_CASE(1) Q40_CASE(2) Q40_CASE(3) Q40_CASE(4) Q40_CASE(5) Q40_CASE(6) Q40_CASE(7) Q40_CASE(8)
-        }
+#define Q40_CASE(B, L) if (bpl == B && lpr == L) hipLaunchKernelGGL((gemv_q40_kernel<B, L>), dim3((waves + 3) / 4), dim3(256), 0, st, Wqs, Wd, bias, xq, xdd, ym, N, rows_per_wave);
+        Q40_CASE(1, 16) Q40_CASE(2, 16) Q40_CASE(3, 16) Q40_CASE(4, 16) Q40_CASE(5, 16) Q40_CASE(6, 16) Q40_CASE(7, 16) Q40_CASE(8, 16)
+        Q40_CASE(1, 8) Q40_CASE(3, 8) Q40_CASE(5, 8) Q40_CASE(7, 8)
 #undef Q40_CASE
         int rc = MH_LAUNCH_OK("gemv_q40");
         if (rc) return rc;

@@ -99,6 +99,53 @@ public:
     }
 };
 
+// one VisionBlock (modeling_qwen2_vl.hpp:112-137) driven with its rotary table: inputs x [1,1,N,V], grid_thw
+class VBlockModule final : public Module {
+public:
+    Layer rot;
+    VisionBlock blk;
+    VBlockModule(int V, const std::string &base) {
+        Qwen2VLConfig cfg(64, "1.5b");
+        rot = VisionRoPE((V / 16) / 2, 2, "visual.rot_pos_emb");
+        blk = VisionBlock(V, 16, V * 4, "QuickGELU", cfg.attn_implementation, cfg.vision_names_config, base);
+    }
+    vector<Tensor> Forward(vector<Tensor> in, vector<std::any> args) override {
+        auto r = rot(in[1]);
+        vector<float> cu = {0.0F, 1.0F};
+        auto cu_t = Tensor(cu);
+        return blk({in[0], cu_t, r});
+    }
+};
+
+// the vision tower re-assembled from the reference's public sub-modules, truncated after `nblk` blocks, merger optional:
+// used to localise divergences (p: hidden, V, nblk, merger)
+class VisionPartModule final : public Module {
+public:
+    Qwen2PatchEmbed pe;
+    Layer rot;
+    vector<VisionBlock> blocks;
+    PatchMerger merger;
+    bool do_merger;
+    VisionPartModule(int hidden, int V, int nblk, bool mg) : do_merger(mg) {
+        Qwen2VLConfig cfg(64, "1.5b");
+        auto &n = cfg.vision_names_config;
+        std::string base = n.vison_model_name;
+        pe = Qwen2PatchEmbed(V, 14, 336, n, base + n.patch_embed_name);
+        rot = VisionRoPE((V / 16) / 2, 2, base + ".rot_pos_emb");
+        blocks = List<VisionBlock>(nblk, V, 16, V * 4, "QuickGELU", cfg.attn_implementation, n, base + n._layer_name);
+        merger = PatchMerger(hidden, V, 2, n, base + n._merger_name);
+    }
+    vector<Tensor> Forward(vector<Tensor> in, vector<std::any> args) override {
+        auto h = pe({in[0]})[0];
+        auto r = rot(in[1]);
+        vector<float> cu = {0.0F, 1.0F};
+        auto cu_t = Tensor(cu);
+        for (auto &b : blocks) h = b({h, cu_t, r})[0];
+        if (do_merger) h = merger({h})[0];
+        return {h};
+    }
+};
+
 static Tensor make_input(const std::string &spec, int idx) {
     auto parts = split(spec, ':');
     auto data = read_f32(parts[0]);
@@ -167,6 +214,10 @@ int main(int argc, char **argv) {
         Qwen2VLConfig cfg(64, "1.5b");
         model.reset(new Qwen2VisionModel((int)p(0), (int)p(1), 16, (int)p(1) * 4, "QuickGELU", 14, 336, 32, 2,
                                          cfg.attn_implementation, cfg.vision_names_config, cfg.vision_names_config.vison_model_name));
+    } else if (kind == "visionpart") {
+        model.reset(new VisionPartModule((int)p(0), (int)p(1), (int)p(2), p(3) != 0));
+    } else if (kind == "vblock") {
+        model.reset(new VBlockModule((int)p(0), "visual.blocks." + std::to_string((int)p(1)) + "."));
     } else if (kind == "attn" || kind == "decoder" || kind == "mlp") {
         // p: hidden, inter, heads, kv_heads, cache_limit
         Qwen2VLConfig cfg((int)p(4, 64), "1.5b");
