@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 SO = os.path.join(HERE, "libmllm_hip.so")
-HIP_SOURCES = ["runtime.hip", "kernels_elem.hip", "kernels_linear.hip", "kernels_attn.hip", "engine.hip"]
+HIP_SOURCES = ["runtime.hip", "kernels_elem.hip", "kernels_linear.hip", "kernels_attn.hip", "kernels_decode.hip", "engine.hip"]
 HOST_SOURCES = ["host_quantize.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -27,7 +27,7 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "mllm_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "decode_launch.h"), os.path.join(HERE, "..", "include", "mllm_hip.h")]
     objs = []
     procs = []
     for s in HIP_SOURCES:

@@ -1,0 +1,36 @@
+// mllm_amd/csrc/decode_launch.h -- host-side description of one fused decode step (kernels_decode.hip), used by engine.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mllm_hip {
+
+// per-step scalars in device memory, advanced by dec_next_kernel so one captured graph replays every step
+struct DecodeState {
+    int T;      // tokens already in the KV slab before this step
+    int step;   // decode step since the prefill (row of the rotary tables)
+    int token;  // token id to embed at this step
+    int pad;
+};
+
+struct DecodeLayer {
+    const float *in_norm, *post_norm;
+    const uint8_t *Wqkv; const float *bqkv; int qkv_N;
+    const uint8_t *Wo, *Wgu, *Wdown;
+};
+
+struct DecodeCtx {
+    DecodeState *state;
+    int H, I, heads, kv_heads, D, vocab, cache_limit, nsplit, max_parts;
+    float eps;
+    const uint8_t *emb_qs; const uint16_t *emb_d; const float *final_norm;
+    float *x0, *x1, *qkv, *act, *logits, *fa_ws, *part_val, *normed;
+    int8_t *x80_qs; uint16_t *x80_d;
+    int *part_idx, *tok_dev, *history;
+    const float *rope_sin, *rope_cos;   // [max_steps][D/2], row = DecodeState::step
+    uint16_t *kslab, *vslab;
+};
+
+int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st);
+
+}  // namespace mllm_hip

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "common.h"
+#include "decode_launch.h"
 
 using namespace mllm_hip;
 
@@ -112,6 +113,16 @@ struct mllm_hip_qwen2vl {
     int max_patch = 0;
     float *vx = nullptr, *vr = nullptr, *vqkv = nullptr, *vattn = nullptr, *vfc = nullptr, *vact = nullptr, *vpix = nullptr, *vsin = nullptr, *vcos = nullptr,
           *vemb = nullptr, *vm0 = nullptr;
+    // fused decode path (kernels_decode.hip): device-side step state, per-step rotary rows, captured graph
+    DecodeState *d_state = nullptr;
+    float *dec_sin = nullptr, *dec_cos = nullptr, *part_val = nullptr;
+    int *part_idx = nullptr, *history = nullptr;
+    int nsplit = 0, max_parts = 4096, dec_rows = 0;
+    DecodeCtx dctx;
+    std::vector<DecodeLayer> dlayers;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool use_graph = true;
     // state
     int cache_len = 0;
     float last_pos = -1.0f;
@@ -266,7 +277,30 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
     CK(m->dalloc(&m->x80_qs, (size_t)H)); CK(m->dalloc(&m->x80_d, (size_t)(H / 32) * 2));
     CK(m->dalloc(&m->rope_sin, (size_t)T * (m->D / 2) * 4)); CK(m->dalloc(&m->rope_cos, (size_t)T * (m->D / 2) * 4));
     CK(m->dalloc(&m->kslab, (size_t)c.layers * T * m->KVD * 2)); CK(m->dalloc(&m->vslab, (size_t)c.layers * T * m->KVD * 2));
-    CK(m->dalloc((uint8_t **)&m->fa_ws, mllm_hip_fa2_workspace_bytes(1, c.heads, m->D, T)));
+    m->nsplit = (T + 63) / 64;
+    {
+        size_t wsb = mllm_hip_fa2_workspace_bytes(1, c.heads, m->D, T), wsd = (size_t)c.heads * m->nsplit * 136 * 4;
+        CK(m->dalloc((uint8_t **)&m->fa_ws, wsb > wsd ? wsb : wsd));
+    }
+    CK(m->dalloc(&m->d_state, sizeof(DecodeState)));
+    CK(m->dalloc(&m->dec_sin, (size_t)T * (m->D / 2) * 4)); CK(m->dalloc(&m->dec_cos, (size_t)T * (m->D / 2) * 4));
+    CK(m->dalloc(&m->part_val, (size_t)m->max_parts * 4)); CK(m->dalloc(&m->part_idx, (size_t)m->max_parts * 4));
+    CK(m->dalloc(&m->history, (size_t)T * 4));
+    {
+        DecodeCtx &d = m->dctx;
+        d.state = m->d_state; d.H = H; d.I = I; d.heads = c.heads; d.kv_heads = c.kv_heads; d.D = m->D; d.vocab = c.vocab; d.cache_limit = T;
+        d.nsplit = m->nsplit; d.max_parts = m->max_parts; d.eps = c.rms_eps; d.emb_qs = m->emb_qs; d.emb_d = m->emb_d; d.final_norm = m->final_norm;
+        d.x0 = m->h0; d.x1 = m->h1; d.qkv = m->qkv; d.act = m->act; d.logits = m->logits; d.fa_ws = (float *)m->fa_ws; d.part_val = m->part_val;
+        d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos;
+        d.kslab = m->kslab; d.vslab = m->vslab; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
+        for (auto &L : m->layers) {
+            DecodeLayer dl;
+            dl.in_norm = L.in_norm; dl.post_norm = L.post_norm; dl.Wqkv = (const uint8_t *)L.qkv.w; dl.bqkv = L.qkv.bias; dl.qkv_N = L.qkv.N;
+            dl.Wo = (const uint8_t *)L.o.w; dl.Wgu = (const uint8_t *)L.gu.w; dl.Wdown = (const uint8_t *)L.down.w;
+            m->dlayers.push_back(dl);
+        }
+        m->use_graph = getenv("MLLM_HIP_NO_GRAPH") == nullptr;
+    }
     *out = m;
     return MLLM_HIP_OK;
 #undef CK
@@ -274,6 +308,8 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
 
 extern "C" void mllm_hip_qwen2vl_destroy(mllm_hip_qwen2vl *m) {
     if (!m) return;
+    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) hipGraphDestroy(m->graph);
     for (void *p : m->allocs) hipFree(p);
     if (m->ev0) hipEventDestroy(m->ev0);
     if (m->ev1) hipEventDestroy(m->ev1);
@@ -433,6 +469,8 @@ static int forward_llm(M *m, int S, const float *pos3) {
     return 0;
 }
 
+static int arm_decode(M *m);
+
 static int finish(M *m, float *logits_host, int32_t *next_token, float *elapsed_ms) {
     HH(hipEventRecord(m->ev1, m->st));
     HH(hipEventSynchronize(m->ev1));
@@ -471,49 +509,72 @@ extern "C" int mllm_hip_qwen2vl_prefill(mllm_hip_qwen2vl *m, const int32_t *ids,
     }
     EH(forward_llm(m, n_ids, pos.data()));
     m->last_pos = pos[(size_t)n_ids - 1];  // row 0 (t axis), last column: get_position_ids' decode branch
-    return finish(m, logits_host, next_token, elapsed_ms);
+    EH(finish(m, logits_host, next_token, elapsed_ms));
+    return arm_decode(m);
 }
 
-static int decode_one(M *m, int32_t token, bool from_device) {
+// After a prefill: device step state {T, step = 0, token}, and the M-RoPE rows of every position the decode loop can still
+// reach (get_position_ids' decode branch: all three axes = last_pos + 1 + step, modeling_qwen2_vl.hpp:423-432).
+static int arm_decode(M *m) {
     const auto &c = m->c;
-    if (!from_device) {
-        const float tf = (float)token;
-        HH(hipMemcpyAsync(m->ids_f, &tf, 4, hipMemcpyHostToDevice, m->st));
-        HH(hipStreamSynchronize(m->st));
+    const int rows = c.cache_limit - m->cache_len;
+    m->dec_rows = rows;
+    if (rows > 0) {
+        std::vector<float> pos((size_t)3 * rows), s((size_t)rows * (m->D / 2)), co((size_t)rows * (m->D / 2));
+        for (int a = 0; a < 3; ++a) for (int r = 0; r < rows; ++r) pos[(size_t)a * rows + r] = m->last_pos + 1.0f + (float)r;
+        EH(mllm_hip_mrope_table(c.rope_theta, m->D, pos.data(), rows, c.mrope_section, 3, s.data(), co.data()));
+        HH(hipMemcpy(m->dec_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+        HH(hipMemcpy(m->dec_cos, co.data(), co.size() * 4, hipMemcpyHostToDevice));
     }
-    const float p = m->last_pos + 1.0f;
-    const float pos3[3] = {p, p, p};
-    EH(mllm_hip_embedding_q40(m->ids_f, m->emb_qs, m->emb_d, m->h0, 1, c.hidden, c.vocab, m->st));
-    EH(forward_llm(m, 1, pos3));
-    m->last_pos = p;
+    int tok = 0;
+    HH(hipMemcpy(&tok, m->tok_dev, 4, hipMemcpyDeviceToHost));
+    DecodeState st0 = {m->cache_len, 0, tok, 0};
+    HH(hipMemcpy(m->d_state, &st0, sizeof(st0), hipMemcpyHostToDevice));
     return 0;
+}
+
+static int launch_step(M *m) {
+    if (m->use_graph) {
+        if (!m->graph_exec) {
+            HH(hipStreamBeginCapture(m->st, hipStreamCaptureModeThreadLocal));
+            int rc = decode_step_launch(m->dctx, m->dlayers.data(), (int)m->dlayers.size(), m->st);
+            hipError_t e = hipStreamEndCapture(m->st, &m->graph);
+            if (rc) return rc;
+            HH(e);
+            HH(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+        }
+        HH(hipGraphLaunch(m->graph_exec, m->st));
+        return 0;
+    }
+    return decode_step_launch(m->dctx, m->dlayers.data(), (int)m->dlayers.size(), m->st);
 }
 
 extern "C" int mllm_hip_qwen2vl_decode(mllm_hip_qwen2vl *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms) {
     if (!m || m->cache_len <= 0) return MLLM_HIP_ERR_ARG;
+    if (m->cache_len + 1 > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + 1 > %d)\n", m->cache_len, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
+    HH(hipMemcpyAsync(&m->d_state->token, &token, 4, hipMemcpyHostToDevice, m->st));
+    HH(hipStreamSynchronize(m->st));
     HH(hipEventRecord(m->ev0, m->st));
-    EH(decode_one(m, token, false));
+    EH(launch_step(m));
+    m->cache_len += 1;
+    m->last_pos += 1.0f;
     return finish(m, logits_host, next_token, elapsed_ms);
 }
 
-__global__ void tok_to_float_kernel(const int *tok, float *idf, int32_t *hist, int step) { idf[0] = (float)tok[0]; hist[step] = tok[0]; }
-
 extern "C" int mllm_hip_qwen2vl_generate(mllm_hip_qwen2vl *m, int32_t first_token, int steps, int32_t *tokens_host, float *elapsed_ms) {
     if (!m || m->cache_len <= 0 || steps <= 0) return MLLM_HIP_ERR_ARG;
-    int32_t *hist;
-    HH(hipMalloc(&hist, (size_t)steps * 4));
-    const float tf = (float)first_token;
-    HH(hipMemcpy(m->ids_f, &tf, 4, hipMemcpyHostToDevice));
+    if (m->cache_len + steps > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + %d > %d)\n", m->cache_len, steps, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
+    DecodeState st0;
+    HH(hipMemcpy(&st0, m->d_state, sizeof(st0), hipMemcpyDeviceToHost));
+    const int step0 = st0.step;
+    HH(hipMemcpy(&m->d_state->token, &first_token, 4, hipMemcpyHostToDevice));
     HH(hipEventRecord(m->ev0, m->st));
-    int rc = 0;
-    for (int s = 0; s < steps && !rc; ++s) {
-        rc = decode_one(m, 0, true);
-        if (!rc) hipLaunchKernelGGL(tok_to_float_kernel, dim3(1), dim3(1), 0, m->st, m->tok_dev, m->ids_f, hist, s);
-    }
-    if (!rc) rc = finish(m, nullptr, nullptr, elapsed_ms);
-    if (!rc && tokens_host) rc = hipMemcpy(tokens_host, hist, (size_t)steps * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : MLLM_HIP_ERR_HIP;
-    hipFree(hist);
-    return rc;
+    for (int s = 0; s < steps; ++s) EH(launch_step(m));
+    m->cache_len += steps;
+    m->last_pos += (float)steps;
+    EH(finish(m, nullptr, nullptr, elapsed_ms));
+    if (tokens_host) HH(hipMemcpy(tokens_host, m->history + step0, (size_t)steps * 4, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 extern "C" int mllm_hip_qwen2vl_vision(mllm_hip_qwen2vl *m, const float *pixel_values_host, const int32_t *grid_thw, int n_img, float *embeds_dev,

@@ -1,0 +1,769 @@
+// mllm_amd/csrc/kernels_decode.hip -- the fused single-token (decode) layer of the Qwen2 / LLaMA style decoder for gfx950.
+//
+// One decode step of one layer of QWen2Decoder (models/qwen2_vl/modeling_qwen2_vl.hpp:316-325) is 5 launches instead
+// of the 14 ops the reference dispatches; every launch is a weight-streaming GEMV whose prologue recomputes, per
+// workgroup and redundantly, the small activation-side work the reference does as separate ops:
+//
+//   dec_qkv     [RMSNorm(x) -> Q8_K]            . Wqkv^T + b               -> qkv fp32            (A9+A4+A1, layer 0: +A8)
+//   dec_attn    M-RoPE(q), M-RoPE(k)->fp16 slab, v->fp16 slab, flash-decode over the slab, GQA group per workgroup (A11+A12+A13)
+//   dec_oproj   [merge key splits -> attn -> Q8_K] . Wo^T + x             -> tmp                  (A13 tail+A4+A1+A20)
+//   dec_gateup  [RMSNorm(tmp) -> Q8_K]          . (Wgate|Wup)^T, silu(g)*u -> act                 (A9+A4+A1+A14+A20)
+//   dec_down    [act -> Q8_K]                   . Wdown^T + tmp           -> x                    (A4+A1+A20)
+//   dec_head    [RMSNorm(x) -> Q8_0]            . Wemb^T (tied lm_head, Q4_0 planes) -> logits + per-workgroup argmax
+//   dec_next    final argmax (first maximum), token history, advance the device-side step state
+//
+// The arithmetic of every fused piece is the same sequence of fp32/int operations as the stand-alone launchers in
+// kernels_elem/linear/attn.hip (which the prefill path uses), so decode and prefill agree with each other and with the
+// oracle to the same bars.  Per-step scalars (KV length, rotary row, token id) live in device memory, so one captured
+// hipGraph replays every step.  Weight loads are issued BEFORE the prologue so the HBM latency of the first rows overlaps
+// the prologue's arithmetic (vmcnt counts in issue order: the prologue's own small loads are issued first).
+#include <cmath>
+
+#include "common.h"
+#include "decode_launch.h"
+
+namespace mllm_hip {
+
+__device__ __forceinline__ float v_expf_dec(float x) {  // same polynomial as kernels_elem.hip v_expf (mllm_v_expf)
+    const float r = 0x1.8p23f;
+    const float z = __fmaf_rn(x, 0x1.715476p+0f, r);
+    const float n = z - r;
+    const float b = __fmaf_rn(-n, 0x1.7f7d1cp-20f, __fmaf_rn(-n, 0x1.62e4p-1f, x));
+    const uint32_t e = __float_as_uint(z) << 23;
+    const float k = __uint_as_float(e + __float_as_uint(1.0f));
+    const bool c = fabsf(n) > 126.0f;
+    const float u = b * b;
+    const float j = __fmaf_rn(__fmaf_rn(__fmaf_rn(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, __fmaf_rn(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u,
+                              0x1.ffffecp-1f * b);
+    if (!c) return __fmaf_rn(j, k, k);
+    const uint32_t g = (n <= 0.0f) ? 0x82000000u : 0u;
+    const float s1 = __uint_as_float(g + 0x7f000000u);
+    const float s2 = __uint_as_float(e - g);
+    if (fabsf(n) > 192.0f) return s1 * s1;
+    return __fmaf_rn(s2, j, s2) * s1;
+}
+
+// ---- shared-memory image of one Q8_K quantised activation row ---------------------------------------------------------
+// layout in dynamic LDS (16-B aligned pieces): qs[K] | d[K/256] | q8s[K/32] (int32 sums of 32) ; xf[K] scratch (fp32)
+struct ActLds {
+    int8_t *qs;
+    float *d;
+    int *q8s;
+    float *xf;
+};
+__device__ __forceinline__ ActLds carve_act(char *smem, int K) {
+    ActLds a;
+    a.qs = reinterpret_cast<int8_t *>(smem);
+    a.d = reinterpret_cast<float *>(smem + K);
+    a.q8s = reinterpret_cast<int *>(smem + K + ((K / 256 * 4 + 15) & ~15));
+    a.xf = reinterpret_cast<float *>(smem + K + ((K / 256 * 4 + 15) & ~15) + ((K / 32 * 4 + 15) & ~15));
+    return a;
+}
+static inline size_t act_lds_bytes(int K, bool with_xf) {
+    return (size_t)K + ((K / 256 * 4 + 15) & ~15) + ((K / 32 * 4 + 15) & ~15) + (with_xf ? (size_t)K * 4 : 0) + 64;
+}
+
+// one wave quantises one 256-block given as 4 consecutive values per lane (quantize_row_q8_K_reference) into LDS
+__device__ __forceinline__ void wave_quant_to_lds(float4 v, int lane, int blk, const ActLds &a) {
+    const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+    const float amax = wave_max(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    const float mine = a0 == amax ? v.x : (a1 == amax ? v.y : (a2 == amax ? v.z : v.w));
+    const float mx = first_flagged(a0 == amax || a1 == amax || a2 == amax || a3 == amax, mine);
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    float dd = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -128.0f / mx;
+        q0 = min(127, nearest_int(iscale * v.x));
+        q1 = min(127, nearest_int(iscale * v.y));
+        q2 = min(127, nearest_int(iscale * v.z));
+        q3 = min(127, nearest_int(iscale * v.w));
+        dd = 1.0f / iscale;
+    }
+    reinterpret_cast<uint32_t *>(a.qs + blk * 256)[lane] =
+        (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+    const int s = group8_sum(q0 + q1 + q2 + q3);   // sum over 8 lanes = 32 values (bsums[2k] + bsums[2k+1])
+    if ((lane & 7) == 0) a.q8s[blk * 8 + (lane >> 3)] = s;
+    if (lane == 0) a.d[blk] = dd;
+}
+
+// RMSNorm of one row (CPURMSNorm.cpp:31-136) by a 256-thread workgroup, then Q8_K into LDS. dim % 256 == 0, dim <= 1024*NV.
+// The row is loaded into registers by load_row() BEFORE the caller issues its weight loads (vmcnt retires in issue order).
+template <int NV>
+__device__ __forceinline__ void load_row(float4 (&xv)[NV], const float *__restrict__ x, int dim) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int d = threadIdx.x * 4 + i * 1024;
+        xv[i] = d < dim ? *reinterpret_cast<const float4 *>(x + d) : make_float4(0, 0, 0, 0);
+    }
+}
+// thread (wid, lane) holds values [(wid + 4i)*256 + 4*lane, +4): exactly the 4 values of lane `lane` of quant block wid + 4i
+template <int NV>
+__device__ __forceinline__ void wg_rmsnorm_quant(const float4 (&xv)[NV], const float4 (&wv)[NV], int dim, float eps, const ActLds &a, double *red) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 v = xv[i];   // zero beyond dim
+        ss += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    }
+    ss = wave_sum_d(ss);
+    if (lane == 0) red[wid] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float m = (float)(ss / (double)dim);
+    const float inv = 1.0f / __fsqrt_rn(m + eps);
+    const int nblk = dim >> 8;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int blk = wid + 4 * i;
+        if (blk < nblk) {
+            float4 o;
+            o.x = (xv[i].x * inv) * wv[i].x; o.y = (xv[i].y * inv) * wv[i].y; o.z = (xv[i].z * inv) * wv[i].z; o.w = (xv[i].w * inv) * wv[i].w;
+            wave_quant_to_lds(o, lane, blk, a);
+        }
+    }
+    __syncthreads();
+}
+
+// ---- GEMV core: this wave computes ROWS consecutive rows of a Q4_K matrix against the LDS activation row ----------------
+template <int NSTEPS, int ROWS>
+struct RowLoads { uint4 hdr[ROWS][NSTEPS], q[ROWS][NSTEPS]; };
+
+template <int NSTEPS, int ROWS>
+__device__ __forceinline__ void issue_rows(RowLoads<NSTEPS, ROWS> &L, const uint8_t *__restrict__ W, int nb, const int *rows, int lane) {
+    const int g = lane >> 3, r = lane & 7;
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+        for (int st = 0; st < NSTEPS; ++st) {
+            const int blk = st * 8 + g < nb ? st * 8 + g : 0;
+            const uint8_t *wb = W + ((int64_t)rows[rr] * nb + blk) * 144;
+            L.hdr[rr][st] = *reinterpret_cast<const uint4 *>(wb);
+            L.q[rr][st] = *reinterpret_cast<const uint4 *>(wb + 16 + 16 * r);
+        }
+}
+
+template <int NSTEPS, int ROWS>
+__device__ __forceinline__ void dot_rows(const RowLoads<NSTEPS, ROWS> &L, const ActLds &a, int nb, int lane, float out[ROWS]) {
+    const int g = lane >> 3, r = lane & 7, j = r >> 1, tp = r & 1;
+    int4 xa[NSTEPS], xb[NSTEPS];
+    float xdv[NSTEPS];
+    int q8s[NSTEPS];
+    bool valid[NSTEPS];
+#pragma unroll
+    for (int st = 0; st < NSTEPS; ++st) {
+        const int blk = st * 8 + g;
+        valid[st] = blk < nb;
+        const int b = valid[st] ? blk : 0;
+        xa[st] = *reinterpret_cast<const int4 *>(a.qs + b * 256 + 64 * j + 16 * tp);
+        xb[st] = *reinterpret_cast<const int4 *>(a.qs + b * 256 + 64 * j + 32 + 16 * tp);
+        xdv[st] = a.d[b];
+        q8s[st] = a.q8s[b * 8 + r];
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int st = 0; st < NSTEPS; ++st) {
+            const uint4 hdr = L.hdr[rr][st], q = L.q[rr][st];
+            const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
+            uint32_t sc8[2], mn8[2];
+            unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
+            const int sc_lo = byte_of(sc8, 2 * j), sc_hi = byte_of(sc8, 2 * j + 1), mr = byte_of(mn8, r);
+            int dl = dot4((int)(q.x & 0x0f0f0f0fu), xa[st].x, 0);
+            dl = dot4((int)(q.y & 0x0f0f0f0fu), xa[st].y, dl);
+            dl = dot4((int)(q.z & 0x0f0f0f0fu), xa[st].z, dl);
+            dl = dot4((int)(q.w & 0x0f0f0f0fu), xa[st].w, dl);
+            int dh = dot4((int)((q.x >> 4) & 0x0f0f0f0fu), xb[st].x, 0);
+            dh = dot4((int)((q.y >> 4) & 0x0f0f0f0fu), xb[st].y, dh);
+            dh = dot4((int)((q.z >> 4) & 0x0f0f0f0fu), xb[st].z, dh);
+            dh = dot4((int)((q.w >> 4) & 0x0f0f0f0fu), xb[st].w, dh);
+            int i1 = sc_lo * dl + sc_hi * dh, i2 = mr * q8s[st];
+            i1 = group8_sum(i1);
+            i2 = group8_sum(i2);
+            const float p = __fmaf_rn(xdv[st] * d, (float)i1, -((xdv[st] * dmin) * (float)i2));
+            acc += valid[st] ? p : 0.0f;
+        }
+        out[rr] = groups_total_lane63(acc);   // valid in lane 63
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dec_qkv: x (or the embedding row of state->token for layer 0) -> RMSNorm -> Q8_K -> Wqkv rows (+bias) -> qkv fp32
+// ------------------------------------------------------------------------------------------------------------------------
+template <int NSTEPS, int ROWS, bool EMBED, int NV>
+__global__ __launch_bounds__(256) void dec_qkv_kernel(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
+                                                      const uint8_t *__restrict__ emb_qs, const uint16_t *__restrict__ emb_d, int vocab,
+                                                      const float *__restrict__ norm_w, float eps, const uint8_t *__restrict__ W,
+                                                      const float *__restrict__ bias, float *__restrict__ y, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[4];
+    const ActLds a = carve_act(smem, K);
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nb = K >> 8;
+    int rows[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) rows[rr] = min(wave * ROWS + rr, N - 1);
+    RowLoads<NSTEPS, ROWS> L;
+    float4 xv[NV];
+    if (EMBED) {
+        // CPUEmbedding (Q4_0 row dequant) of the current token: thread t owns values 4t..4t+3 (+1024 i) like load_row();
+        // workgroup 0 also stores the row to x_out (it is the residual the o-projection adds back)
+        int id = state->token;
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const uint8_t *q = emb_qs + (int64_t)id * (K / 2);
+        const uint16_t *dd = emb_d + (int64_t)id * (K / 32);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int d0 = threadIdx.x * 4 + i * 1024;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (d0 < K) {
+                const int blk = d0 >> 5, jj = d0 & 31;           // 4 consecutive values of one 32-block: all low or all high nibbles
+                const float d = h2f(dd[blk]);
+                const uint32_t b4 = *reinterpret_cast<const uint32_t *>(q + blk * 16 + (jj & 15));
+                const int sh = jj >= 16 ? 4 : 0;
+                v.x = (float)((int)((b4 >> sh) & 0xF) - 8) * d;
+                v.y = (float)((int)((b4 >> (8 + sh)) & 0xF) - 8) * d;
+                v.z = (float)((int)((b4 >> (16 + sh)) & 0xF) - 8) * d;
+                v.w = (float)((int)((b4 >> (24 + sh)) & 0xF) - 8) * d;
+                if (blockIdx.x == 0) *reinterpret_cast<float4 *>(x_out + d0) = v;
+            }
+            xv[i] = v;
+        }
+    } else {
+        load_row<NV>(xv, x, K);
+    }
+    float4 wv[NV];
+    load_row<NV>(wv, norm_w, K);
+    issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+    wg_rmsnorm_quant<NV>(xv, wv, K, eps, a, red);
+    float out[ROWS];
+    dot_rows<NSTEPS, ROWS>(L, a, nb, lane, out);
+    if (lane == 63) {
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int rw = wave * ROWS + rr;
+            if (rw < N) y[rw] = bias ? out[rr] + bias[rw] : out[rr];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dec_gateup: tmp -> RMSNorm -> Q8_K -> rows (gate n, up n) -> act[n] = silu(gate) * up   (gate rows [0,I), up rows [I,2I))
+// ------------------------------------------------------------------------------------------------------------------------
+template <int NSTEPS, int PAIRS, int NV>
+__global__ __launch_bounds__(256) void dec_gateup_kernel(const float *__restrict__ x, const float *__restrict__ norm_w, float eps,
+                                                         const uint8_t *__restrict__ W, float *__restrict__ act, int I, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[4];
+    const ActLds a = carve_act(smem, K);
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nb = K >> 8;
+    int rows[2 * PAIRS];
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+        const int n = min(wave * PAIRS + p, I - 1);
+        rows[2 * p] = n;
+        rows[2 * p + 1] = I + n;
+    }
+    RowLoads<NSTEPS, 2 * PAIRS> L;
+    float4 xv[NV], wv[NV];
+    load_row<NV>(xv, x, K);
+    load_row<NV>(wv, norm_w, K);
+    issue_rows<NSTEPS, 2 * PAIRS>(L, W, nb, rows, lane);
+    wg_rmsnorm_quant<NV>(xv, wv, K, eps, a, red);
+    float out[2 * PAIRS];
+    dot_rows<NSTEPS, 2 * PAIRS>(L, a, nb, lane, out);
+    if (lane == 63) {
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) {
+            const int n = wave * PAIRS + p;
+            if (n < I) {
+                const float g = out[2 * p], u = out[2 * p + 1];
+                act[n] = (g / (1.0f + v_expf_dec(0.0f - g))) * u;   // mllm_v_silu then F_TTMUL
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dec_down / dec_oproj: fp32 activation row (act, or the merged attention output) -> Q8_K -> W rows + residual -> y
+// MERGE: the activation row is first assembled from the flash-decode partials (max, sum, out[D]) of every key split.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int WSD = 136;  // floats per (head, split) partial: [0] max, [1] sum, [2..2+D) out
+constexpr int KPWG = 64;  // keys per attention workgroup (one split)
+
+template <int NSTEPS, int ROWS, bool MERGE>
+__global__ __launch_bounds__(256) void dec_proj_kernel(const DecodeState *__restrict__ state, const float *__restrict__ xin, const float *__restrict__ ws, int heads, int D, int nsplit,
+                                                       const uint8_t *__restrict__ W, const float *__restrict__ residual, float *__restrict__ y, int N,
+                                                       int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ActLds a = carve_act(smem, K);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wave = blockIdx.x * 4 + wid, nb = K >> 8;
+    int rows[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) rows[rr] = min(wave * ROWS + rr, N - 1);
+    RowLoads<NSTEPS, ROWS> L;
+    if (MERGE) {
+        // merge of the key splits (same arithmetic as fa2_decode_merge_kernel). Phase A: one thread per head turns the split
+        // maxima into factors f_s = exp((m_s - m)*scale) and the denominator l; phase B: one thread per (head, dim) sums f_s*o_s.
+        const float scale = 1.0f / __fsqrt_rn((float)D);
+        float *fac = a.xf + K;            // [heads][nsplit]
+        float *lsum = fac + heads * nsplit;  // [heads]
+        const int nact = min(nsplit, state->T / KPWG + 1);   // splits holding keys at this length
+        if (tid < heads) {
+            const float *base = ws + (int64_t)tid * nsplit * WSD;
+            float m_tot = -INFINITY;
+            for (int sp = 0; sp < nact; ++sp) m_tot = fmaxf(m_tot, base[sp * WSD]);
+            const float mt = m_tot == -INFINITY ? 0.0f : m_tot;
+            float l = 0.0f;
+            for (int sp = 0; sp < nact; ++sp) {
+                const float ms = base[sp * WSD];
+                const float f = ms == -INFINITY ? 0.0f : expf((ms - mt) * scale);
+                l = __fmaf_rn(f, base[sp * WSD + 1], l);
+                fac[tid * nsplit + sp] = f;
+            }
+            lsum[tid] = l;
+        }
+        __syncthreads();
+        for (int e = tid; e < K; e += 256) {
+            const int head = e / D, dd = e - head * D;
+            const float *base = ws + (int64_t)head * nsplit * WSD + 2 + dd;
+            float acc = 0.0f;
+#pragma unroll 4
+            for (int sp = 0; sp < nact; ++sp) acc = __fmaf_rn(fac[head * nsplit + sp], base[sp * WSD], acc);
+            a.xf[e] = acc / lsum[head];
+        }
+        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+        __syncthreads();
+        for (int blk = wid; blk < nb; blk += 4) wave_quant_to_lds(*reinterpret_cast<const float4 *>(a.xf + blk * 256 + lane * 4), lane, blk, a);
+    } else {
+        float4 v[(NSTEPS * 8 + 3) / 4];
+#pragma unroll
+        for (int i = 0; i < (NSTEPS * 8 + 3) / 4; ++i) {
+            const int blk = wid + 4 * i;
+            v[i] = blk < nb ? *reinterpret_cast<const float4 *>(xin + blk * 256 + lane * 4) : make_float4(0, 0, 0, 0);
+        }
+        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+#pragma unroll
+        for (int i = 0; i < (NSTEPS * 8 + 3) / 4; ++i) {
+            const int blk = wid + 4 * i;
+            if (blk < nb) wave_quant_to_lds(v[i], lane, blk, a);
+        }
+    }
+    __syncthreads();
+    float out[ROWS];
+    dot_rows<NSTEPS, ROWS>(L, a, nb, lane, out);
+    if (lane == 63) {
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int rw = wave * ROWS + rr;
+            if (rw < N) y[rw] = residual ? out[rr] + residual[rw] : out[rr];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dec_attn: one workgroup per (kv head, key split of 64 keys). Rotates q (all GROUP heads of the GQA group) and the new k
+// with the step's sin/cos row, appends k,v (fp16) to the slab, then flash-decode partials for the group's heads:
+// scores with 4 lanes per key (32 dims each, 16 keys per wave), P V with 2 output dims per lane over the wave's 16 keys.
+// qkv: [Hq*D | Hkv*D | Hkv*D] fp32 of this token.  Slabs: [cache_limit][Hkv*D] fp16.  D == 128.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int D, int GROUP>
+__global__ __launch_bounds__(256) void dec_attn_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
+                                                       const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
+                                                       float *__restrict__ ws, int Hq, int Hkv, int nsplit) {
+    constexpr int HALF = D / 2;
+    __shared__ float qs[GROUP][D];
+    __shared__ __attribute__((aligned(16))) uint16_t knew[D];
+    __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
+    __shared__ float ps[4][GROUP][16];
+    __shared__ float red[4][GROUP][D + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int kvh = blockIdx.x, split = blockIdx.y;
+    const int T = state->T, Sk = T + 1;
+    const int HD = Hq * D, KVD = Hkv * D;
+    float *outbase = ws + ((int64_t)(kvh * GROUP) * nsplit + split) * WSD;
+    if (split * KPWG >= Sk) {   // nothing to do for this split at the current length: neutral partial
+        for (int e = tid; e < GROUP * (D + 2); e += 256) {
+            const int hh = e / (D + 2), c = e - hh * (D + 2);
+            outbase[(int64_t)hh * nsplit * WSD + c] = c == 0 ? -INFINITY : 0.0f;
+        }
+        return;
+    }
+    const float *sn = sin_t + (int64_t)state->step * HALF, *cs = cos_t + (int64_t)state->step * HALF;
+    // rotate the group's q heads (rope_hf: fma(a,c,-(b*s)), fma(a,s,b*c))
+    for (int e = tid; e < GROUP * HALF; e += 256) {
+        const int hh = e / HALF, d = e - hh * HALF;
+        const float *qp = qkv + (kvh * GROUP + hh) * D;
+        const float av = qp[d], bv = qp[d + HALF], sv = sn[d], cv = cs[d];
+        qs[hh][d] = __fmaf_rn(av, cv, -(bv * sv));
+        qs[hh][d + HALF] = __fmaf_rn(av, sv, bv * cv);
+    }
+    // the new key/value of this kv head: rotate k, round both to fp16 (what the reference's cache holds)
+    if (tid < HALF) {
+        const float *kp = qkv + HD + kvh * D;
+        const float av = kp[tid], bv = kp[tid + HALF], sv = sn[tid], cv = cs[tid];
+        knew[tid] = f2h(__fmaf_rn(av, cv, -(bv * sv)));
+        knew[tid + HALF] = f2h(__fmaf_rn(av, sv, bv * cv));
+    } else if (tid >= 64 && tid < 64 + D) {
+        vnew[tid - 64] = f2h(qkv[HD + KVD + kvh * D + (tid - 64)]);
+    }
+    __syncthreads();
+    if (split == T / KPWG && tid < D) {     // the split that owns position T appends to the slabs
+        kslab[(int64_t)T * KVD + kvh * D + tid] = knew[tid];
+        vslab[(int64_t)T * KVD + kvh * D + tid] = vnew[tid];
+    }
+    const float scale = 1.0f / __fsqrt_rn((float)D);
+    const int kidx = lane >> 2, part = lane & 3;                 // 16 keys per wave, 4 lanes (32 dims each) per key
+    const int kbase = split * KPWG + wid * 16;
+    const int key = kbase + kidx;
+    float s[GROUP];
+#pragma unroll
+    for (int hh = 0; hh < GROUP; ++hh) s[hh] = 0.0f;
+    if (key < Sk) {
+        const uint4 *kp = key == T ? reinterpret_cast<const uint4 *>(knew) + part * 4
+                                   : reinterpret_cast<const uint4 *>(kslab + (int64_t)key * KVD + kvh * D) + part * 4;
+        uint4 kk[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kk[c] = kp[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t w[4] = {kk[c].x, kk[c].y, kk[c].z, kk[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float k0 = h2f((uint16_t)(w[e] & 0xffff)), k1 = h2f((uint16_t)(w[e] >> 16));
+                const int dd = part * 32 + c * 8 + 2 * e;
+#pragma unroll
+                for (int hh = 0; hh < GROUP; ++hh) {
+                    s[hh] = __fmaf_rn(qs[hh][dd], k0, s[hh]);
+                    s[hh] = __fmaf_rn(qs[hh][dd + 1], k1, s[hh]);
+                }
+            }
+        }
+    }
+    float m_w[GROUP], l_w[GROUP];
+#pragma unroll
+    for (int hh = 0; hh < GROUP; ++hh) {
+        float sc = group4_sum(s[hh]);
+        sc = key < Sk ? sc : -INFINITY;
+        m_w[hh] = wave_max(sc);
+        const float mu = m_w[hh] == -INFINITY ? 0.0f : m_w[hh];
+        const float p = key < Sk ? expf((sc - mu) * scale) : 0.0f;
+        l_w[hh] = wave_sum(part == 0 ? p : 0.0f);
+        if (part == 0) ps[wid][hh][kidx] = p;
+    }
+    __syncthreads();
+    // P V: lane owns dims 2*lane, 2*lane+1 (D == 128 -> all 64 lanes), over this wave's (up to) 16 keys
+    float o0[GROUP], o1[GROUP];
+#pragma unroll
+    for (int hh = 0; hh < GROUP; ++hh) { o0[hh] = 0.0f; o1[hh] = 0.0f; }
+    const int nk = min(16, Sk - kbase);
+    uint32_t vv[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int kk2 = kbase + jj;
+        vv[jj] = jj < nk ? (kk2 == T ? reinterpret_cast<const uint32_t *>(vnew)[lane]
+                                      : *reinterpret_cast<const uint32_t *>(vslab + (int64_t)kk2 * KVD + kvh * D + 2 * lane))
+                         : 0u;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        if (jj < nk) {
+            const float v0 = h2f((uint16_t)(vv[jj] & 0xffff)), v1 = h2f((uint16_t)(vv[jj] >> 16));
+#pragma unroll
+            for (int hh = 0; hh < GROUP; ++hh) {
+                const float pj = ps[wid][hh][jj];
+                o0[hh] = __fmaf_rn(pj, v0, o0[hh]);
+                o1[hh] = __fmaf_rn(pj, v1, o1[hh]);
+            }
+        }
+    }
+#pragma unroll
+    for (int hh = 0; hh < GROUP; ++hh) {
+        if (lane == 0) { red[wid][hh][0] = m_w[hh]; red[wid][hh][1] = l_w[hh]; }
+        red[wid][hh][2 + 2 * lane] = o0[hh];
+        red[wid][hh][3 + 2 * lane] = o1[hh];
+    }
+    __syncthreads();
+    for (int e = tid; e < GROUP * (D + 2); e += 256) {
+        const int hh = e / (D + 2), c = e - hh * (D + 2);
+        const float m_tot = fmaxf(fmaxf(red[0][hh][0], red[1][hh][0]), fmaxf(red[2][hh][0], red[3][hh][0]));
+        const float mt = m_tot == -INFINITY ? 0.0f : m_tot;
+        float f[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) f[w] = red[w][hh][0] == -INFINITY ? 0.0f : expf((red[w][hh][0] - mt) * scale);
+        float *outp = outbase + (int64_t)hh * nsplit * WSD;
+        if (c == 0) outp[0] = m_tot;
+        else outp[c] = f[0] * red[0][hh][c] + f[1] * red[1][hh][c] + f[2] * red[2][hh][c] + f[3] * red[3][hh][c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dec_head: x -> RMSNorm -> Q8_0 -> tied lm_head rows (Q4_0 planes) -> logits, plus this workgroup's (max, first index)
+// ------------------------------------------------------------------------------------------------------------------------
+template <int BPL>
+__global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__ x, const float *__restrict__ norm_w, float eps,
+                                                       const uint8_t *__restrict__ Wqs, const uint16_t *__restrict__ Wd, float *__restrict__ logits,
+                                                       float *__restrict__ part_val, int *__restrict__ part_idx, int N, int K, int rows_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[4];
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    float *xf = reinterpret_cast<float *>(smem);                 // [K] normalised row
+    int8_t *xq = reinterpret_cast<int8_t *>(smem + (size_t)K * 4);  // [K] q8_0
+    float *xdd = reinterpret_cast<float *>(smem + (size_t)K * 5);   // [K/32] fp16-rounded scales as fp32
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, sub = lane & 15, rsel = lane >> 4;
+    const int wave = blockIdx.x * 4 + wid, nblk = BPL * 16;
+    const int row0 = wave * rows_per_wave, row1 = min(N, row0 + rows_per_wave);
+    // first batch of weight rows in flight before the prologue
+    uint4 q0[2][BPL];
+    uint16_t d0[2][BPL];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int rw = min(row0 + 4 * u + rsel, max(row1 - 1, 0));
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) {
+            const int64_t bidx = (int64_t)rw * nblk + sub + 16 * b;
+            q0[u][b] = *reinterpret_cast<const uint4 *>(Wqs + bidx * 16);
+            d0[u][b] = Wd[bidx];
+        }
+    }
+    // RMSNorm (final norm, eps 1e-6) of the single row
+    double ss = 0.0;
+    for (int d = tid * 4; d < K; d += 1024) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + d);
+        *reinterpret_cast<float4 *>(xf + d) = v;
+        ss += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    }
+    ss = wave_sum_d(ss);
+    if (lane == 0) red[wid] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / __fsqrt_rn((float)(ss / (double)K) + eps);
+    // Q8_0 (quantize_row_q8_0_reference): 8 lanes per 32-block
+    for (int blk = tid >> 3; blk < K / 32; blk += 32) {
+        const int d4 = blk * 32 + (tid & 7) * 4;
+        float4 v = *reinterpret_cast<const float4 *>(xf + d4);
+        const float4 ww = *reinterpret_cast<const float4 *>(norm_w + d4);
+        v.x = (v.x * inv) * ww.x; v.y = (v.y * inv) * ww.y; v.z = (v.z * inv) * ww.z; v.w = (v.w * inv) * ww.w;
+        float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        amax = group8_max(amax);
+        const float dd = amax / 127.0f;
+        const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+        const int a0 = (int)roundf(v.x * id), a1 = (int)roundf(v.y * id), a2 = (int)roundf(v.z * id), a3 = (int)roundf(v.w * id);
+        *reinterpret_cast<uint32_t *>(xq + d4) = (uint32_t)(a0 & 0xff) | ((uint32_t)(a1 & 0xff) << 8) | ((uint32_t)(a2 & 0xff) << 16) | ((uint32_t)(a3 & 0xff) << 24);
+        if ((tid & 7) == 0) xdd[blk] = h2f(f2h(dd));
+    }
+    __syncthreads();
+    int4 xa[BPL], xb[BPL];
+    float xdv[BPL];
+    int xs8[BPL];
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) {
+        const int blk = sub + 16 * b;
+        xa[b] = *reinterpret_cast<const int4 *>(xq + blk * 32);
+        xb[b] = *reinterpret_cast<const int4 *>(xq + blk * 32 + 16);
+        xdv[b] = xdd[blk];
+        const int one = 0x01010101;
+        int s = dot4(xa[b].x, one, 0); s = dot4(xa[b].y, one, s); s = dot4(xa[b].z, one, s); s = dot4(xa[b].w, one, s);
+        s = dot4(xb[b].x, one, s); s = dot4(xb[b].y, one, s); s = dot4(xb[b].z, one, s); s = dot4(xb[b].w, one, s);
+        xs8[b] = 8 * s;
+    }
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int base = row0; base < row1; base += 8) {
+        uint4 q[2][BPL];
+        uint16_t dw[2][BPL];
+        if (base == row0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int b = 0; b < BPL; ++b) { q[u][b] = q0[u][b]; dw[u][b] = d0[u][b]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int rw = min(base + 4 * u + rsel, row1 - 1);
+#pragma unroll
+                for (int b = 0; b < BPL; ++b) {
+                    const int64_t bidx = (int64_t)rw * nblk + sub + 16 * b;
+                    q[u][b] = *reinterpret_cast<const uint4 *>(Wqs + bidx * 16);
+                    dw[u][b] = Wd[bidx];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) {
+                int i = dot4((int)(q[u][b].x & 0x0f0f0f0fu), xa[b].x, 0);
+                i = dot4((int)(q[u][b].y & 0x0f0f0f0fu), xa[b].y, i);
+                i = dot4((int)(q[u][b].z & 0x0f0f0f0fu), xa[b].z, i);
+                i = dot4((int)(q[u][b].w & 0x0f0f0f0fu), xa[b].w, i);
+                i = dot4((int)((q[u][b].x >> 4) & 0x0f0f0f0fu), xb[b].x, i);
+                i = dot4((int)((q[u][b].y >> 4) & 0x0f0f0f0fu), xb[b].y, i);
+                i = dot4((int)((q[u][b].z >> 4) & 0x0f0f0f0fu), xb[b].z, i);
+                i = dot4((int)((q[u][b].w >> 4) & 0x0f0f0f0fu), xb[b].w, i);
+                i -= xs8[b];
+                acc = __fmaf_rn(h2f(dw[u][b]) * xdv[b], (float)i, acc);
+            }
+            acc = group16_sum(acc);
+            const int rw = base + 4 * u + rsel;
+            if (rw < row1) {
+                if (sub == 0) logits[rw] = acc;
+                if (acc > best) { best = acc; besti = rw; }   // rows visited in increasing order per lane group
+            }
+        }
+    }
+    // workgroup argmax with first-index tie break
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(besti, m, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { bv[wid] = best; bi[wid] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        part_val[blockIdx.x] = best;
+        part_idx[blockIdx.x] = besti;
+    }
+}
+
+// final argmax over the workgroup partials (std::max_element: first maximum), record the token, advance the step state
+__global__ __launch_bounds__(256) void dec_next_kernel(DecodeState *__restrict__ state, const float *__restrict__ part_val, const int *__restrict__ part_idx,
+                                                       int nparts, int *__restrict__ tok_out, int *__restrict__ history) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        const float v = part_val[i];
+        const int ix = part_idx[i];
+        if (v > best || (v == best && ix < besti)) { best = v; besti = ix; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(besti, m, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        *tok_out = besti;
+        if (history) history[state->step] = besti;
+        state->token = besti;
+        state->T += 1;
+        state->step += 1;
+    }
+}
+__global__ void dec_advance_kernel(DecodeState *state, const int *tok, int *history) {
+    const int t = *tok;
+    if (history) history[state->step] = t;
+    state->token = t;
+    state->T += 1;
+    state->step += 1;
+}
+}  // namespace mllm_hip
+
+using namespace mllm_hip;
+
+// ---- launch helpers used by engine.hip (decode_launch.h) ---------------------------------------------------------------
+
+namespace mllm_hip {
+
+template <int NS>
+static int launch_qkv(const DecodeLayer &L, const DecodeCtx &c, bool embed, const float *x, float *x_out, hipStream_t st) {
+    constexpr int ROWS = NS == 1 ? 2 : 1;
+    const int waves = (L.qkv_N + ROWS - 1) / ROWS;
+    const size_t lds = act_lds_bytes(c.H, false);
+    constexpr int NV = NS * 2;   // K <= 2048*NS values = 1024*NV
+    if (embed)
+        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, true, NV>), dim3((waves + 3) / 4), dim3(256), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, L.in_norm,
+                           c.eps, L.Wqkv, L.bqkv, c.qkv, L.qkv_N, c.H);
+    else
+        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, false, NV>), dim3((waves + 3) / 4), dim3(256), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, L.in_norm,
+                           c.eps, L.Wqkv, L.bqkv, c.qkv, L.qkv_N, c.H);
+    return MH_LAUNCH_OK("dec_qkv");
+}
+template <int NS>
+static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *x, hipStream_t st) {
+    constexpr int PAIRS = NS == 1 ? 2 : 1;
+    const int waves = (c.I + PAIRS - 1) / PAIRS;
+    hipLaunchKernelGGL((dec_gateup_kernel<NS, PAIRS, NS * 2>), dim3((waves + 3) / 4), dim3(256), act_lds_bytes(c.H, false), st, x, L.post_norm, c.eps, L.Wgu, c.act, c.I, c.H);
+    return MH_LAUNCH_OK("dec_gateup");
+}
+template <int NS, bool MERGE>
+static int launch_proj(const uint8_t *W, const float *xin, const DecodeCtx &c, const float *residual, float *y, int N, int K, hipStream_t st) {
+    constexpr int ROWS = NS == 1 ? 2 : 1;
+    const int waves = (N + ROWS - 1) / ROWS;
+    const size_t lds = act_lds_bytes(K, MERGE) + (MERGE ? (size_t)(c.heads * c.nsplit + c.heads) * 4 : 0);
+    hipLaunchKernelGGL((dec_proj_kernel<NS, ROWS, MERGE>), dim3((waves + 3) / 4), dim3(256), lds, st, c.state, xin, c.fa_ws, c.heads, c.D, c.nsplit, W,
+                       residual, y, N, K);
+    return MH_LAUNCH_OK("dec_proj");
+}
+
+#define NS_DISPATCH(K, CALL)                           \
+    switch (((K) / 256 + 7) / 8) {                     \
+    case 1: { constexpr int NS = 1; CALL; } break;     \
+    case 2: { constexpr int NS = 2; CALL; } break;     \
+    case 3: { constexpr int NS = 3; CALL; } break;     \
+    case 4: { constexpr int NS = 4; CALL; } break;     \
+    case 5: { constexpr int NS = 5; CALL; } break;     \
+    case 6: { constexpr int NS = 6; CALL; } break;     \
+    default: return MLLM_HIP_ERR_SHAPE;                \
+    }
+
+int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st) {
+    if (c.D != 128 || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
+    const int group = c.heads / c.kv_heads;
+    float *x = c.x0, *t = c.x1;
+    int rc = 0;
+    for (int li = 0; li < n_layers; ++li) {
+        const DecodeLayer &L = layers[li];
+        NS_DISPATCH(c.H, rc = launch_qkv<NS>(L, c, li == 0, x, x, st));
+        if (rc) return rc;
+        uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.cache_limit * c.kv_heads * c.D;
+#define ATTN_CASE(G) case G: hipLaunchKernelGGL((dec_attn_kernel<128, G>), dim3(c.kv_heads, c.nsplit), dim3(256), 0, st, c.state, c.qkv, c.rope_sin, c.rope_cos, kl, vl, c.fa_ws, c.heads, c.kv_heads, c.nsplit); break;
+        switch (group) {
+            ATTN_CASE(1) ATTN_CASE(2) ATTN_CASE(4) ATTN_CASE(6) ATTN_CASE(7) ATTN_CASE(8)
+        default: return MLLM_HIP_ERR_SHAPE;
+        }
+#undef ATTN_CASE
+        rc = MH_LAUNCH_OK("dec_attn");
+        if (rc) return rc;
+        NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS, true>(L.Wo, nullptr, c, x, t, c.H, c.heads * c.D, st)));
+        if (rc) return rc;
+        NS_DISPATCH(c.H, rc = launch_gateup<NS>(L, c, t, st));
+        if (rc) return rc;
+        NS_DISPATCH(c.I, rc = (launch_proj<NS, false>(L.Wdown, c.act, c, t, x, c.H, c.I, st)));
+        if (rc) return rc;
+    }
+    // tied lm_head + argmax
+    if (c.H % 512 != 0 || c.H / 512 > 8) {
+        // shapes the fused head kernel does not cover: the stand-alone launchers (same arithmetic), then advance the state
+        rc = mllm_hip_rmsnorm(x, c.final_norm, c.normed, nullptr, nullptr, nullptr, 1, c.H, 1e-6f, 0, st);
+        if (!rc) rc = mllm_hip_quantize_q80(c.normed, c.x80_qs, c.x80_d, 1, c.H, st);
+        if (!rc) rc = mllm_hip_linear_q40_q80(c.emb_qs, c.emb_d, nullptr, c.x80_qs, c.x80_d, c.logits, c.vocab, 1, c.vocab, c.H, st);
+        if (!rc) rc = mllm_hip_argmax(c.logits, c.vocab, c.tok_dev, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, st, c.state, c.tok_dev, c.history);
+        return MH_LAUNCH_OK("dec_advance");
+    }
+    const int target_waves = 256 * 12;
+    int rpw = (c.vocab + target_waves - 1) / target_waves;
+    rpw = ((rpw + 7) / 8) * 8;
+    const int waves = (c.vocab + rpw - 1) / rpw, blocks = (waves + 3) / 4;
+    if (blocks > c.max_parts) return MLLM_HIP_ERR_SHAPE;
+    const size_t lds = (size_t)c.H * 5 + (size_t)c.H / 32 * 4 + 64;
+#define HEAD_CASE(B) case B: hipLaunchKernelGGL((dec_head_kernel<B>), dim3(blocks), dim3(256), lds, st, x, c.final_norm, 1e-6f, c.emb_qs, c.emb_d, c.logits, c.part_val, c.part_idx, c.vocab, c.H, rpw); break;
+    switch (c.H / 512) { HEAD_CASE(1) HEAD_CASE(2) HEAD_CASE(3) HEAD_CASE(4) HEAD_CASE(5) HEAD_CASE(6) HEAD_CASE(7) HEAD_CASE(8) }
+#undef HEAD_CASE
+    rc = MH_LAUNCH_OK("dec_head");
+    if (rc) return rc;
+    hipLaunchKernelGGL(dec_next_kernel, dim3(1), dim3(256), 0, st, c.state, c.part_val, c.part_idx, blocks, c.tok_dev, c.history);
+    return MH_LAUNCH_OK("dec_next");
+}
+}  // namespace mllm_hip

@@ -20,17 +20,9 @@ __device__ __forceinline__ void wave_quant_q8k(float4 v, int lane, int8_t *qs_bl
     float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
     float amax = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
     amax = wave_max(amax);
-    // first index (in element order) that attains amax -- the reference's strict `>` scan keeps the first
-    int idx = 1 << 20;
-    if (a3 == amax) idx = lane * 4 + 3;
-    if (a2 == amax) idx = lane * 4 + 2;
-    if (a1 == amax) idx = lane * 4 + 1;
-    if (a0 == amax) idx = lane * 4 + 0;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) idx = min(idx, __shfl_xor(idx, m, 64));
-    const int sub = idx & 3;
-    float mine = sub == 0 ? v.x : (sub == 1 ? v.y : (sub == 2 ? v.z : v.w));
-    const float mx = __shfl(mine, idx >> 2, 64);
+    // the first element (in element order) that attains amax -- the reference's strict `>` scan keeps the first
+    const float mine = a0 == amax ? v.x : (a1 == amax ? v.y : (a2 == amax ? v.z : v.w));
+    const float mx = first_flagged(a0 == amax || a1 == amax || a2 == amax || a3 == amax, mine);
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     float dd = 0.0f;
     if (amax != 0.0f) {
@@ -43,9 +35,7 @@ __device__ __forceinline__ void wave_quant_q8k(float4 v, int lane, int8_t *qs_bl
     }
     const uint32_t packed = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
     reinterpret_cast<uint32_t *>(qs_blk)[lane] = packed;
-    int s = q0 + q1 + q2 + q3;
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
+    const int s = group4_sum(q0 + q1 + q2 + q3);
     if ((lane & 3) == 0) bsums_blk[lane >> 2] = (int16_t)s;
     if (lane == 0) *d_out = dd;
 }
@@ -69,9 +59,7 @@ __global__ __launch_bounds__(256) void quantize_q80_kernel(const float *__restri
     float4 v = make_float4(0, 0, 0, 0);
     if (ok) v = reinterpret_cast<const float4 *>(x + blk * 32)[lane & 7];
     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    amax = group8_max(amax);
     const float dd = __fdiv_rn(amax, 127.0f);
     const float id = dd != 0.0f ? __fdiv_rn(1.0f, dd) : 0.0f;
     if (!ok) return;

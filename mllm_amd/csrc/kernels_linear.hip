@@ -87,18 +87,15 @@ __global__ __launch_bounds__(256) void gemv_q4k_kernel(const uint8_t *__restrict
                 int i1, i2;
                 float d, dmin;
                 q4k_lane_dot(hdr[rr][st], q[rr][st], xa[st], xb[st], q8s[st], r, i1, i2, d, dmin);
-                i1 += __shfl_xor(i1, 1, 64); i2 += __shfl_xor(i2, 1, 64);
-                i1 += __shfl_xor(i1, 2, 64); i2 += __shfl_xor(i2, 2, 64);
-                i1 += __shfl_xor(i1, 4, 64); i2 += __shfl_xor(i2, 4, 64);
+                i1 = group8_sum(i1);
+                i2 = group8_sum(i2);
                 // d = y.d * fp16(x.d) ; dmin = y.d * fp16(x.dmin)  (VecDotQ4.cpp:228-229)
                 const float p = __fmaf_rn(__fmul_rn(xdv[st], d), (float)i1, -__fmul_rn(__fmul_rn(xdv[st], dmin), (float)i2));
                 acc += valid[st] ? p : 0.0f;
             }
-            acc += __shfl_xor(acc, 8, 64);
-            acc += __shfl_xor(acc, 16, 64);
-            acc += __shfl_xor(acc, 32, 64);
+            acc = groups_total_lane63(acc);
             const int rw = row + rr;
-            if (lane == 0 && rw < row1) {
+            if (lane == 63 && rw < row1) {
                 float v = acc;
                 if (bias) v = __fadd_rn(v, bias[rw]);
                 if (y_f16) reinterpret_cast<uint16_t *>(y)[rw] = f2h(v);
@@ -167,8 +164,7 @@ __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict
                 i -= xs8[b];  // (nib - 8) * q8 summed
                 acc = __fmaf_rn(__fmul_rn(h2f(dw[u][b]), xdv[b]), (float)i, acc);
             }
-#pragma unroll
-            for (int msk = 1; msk < LPR; msk <<= 1) acc += __shfl_xor(acc, msk, 64);
+            acc = LPR == 16 ? group16_sum(acc) : group8_sum(acc);
             const int rw = base + RPW * u + rsel;
             if (sub == 0 && rw < row1) y[rw] = bias ? __fadd_rn(acc, bias[rw]) : acc;
         }
@@ -310,7 +306,10 @@ static int launch_gemv_q4k(const void *W, const float *bias, const int8_t *xqs, 
                            const float *residual, int N, int K, hipStream_t st) {
     const int nb = K / 256;
     const int nsteps = (nb + 7) / 8;
-    const int target_waves = 256 * 8;  // 8 waves per CU
+    // Little's law: ~6.3 TB/s x ~2 us of HBM latency = ~50 KB in flight per CU.  Every wave issues all the loads of its
+    // rows up front (ROWS x NSTEPS KiB), so give each wave one batch of rows and put as many waves as the register budget
+    // admits on the chip (<= 28 per CU at <= 72 VGPRs) before letting a wave loop over a second batch.
+    const int target_waves = 256 * 24;
     int rows_per_wave = (N + target_waves - 1) / target_waves;
 #define GEMV_CASE(NS, RW)                                                                                                       \
     case NS: {                                                                                                                  \

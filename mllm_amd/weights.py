@@ -15,26 +15,23 @@ from . import lib, mllmfile as mf, synth
 
 def _make_tensor(args):
     name, shape, kind, target = args
-    os.environ.setdefault("OMP_NUM_THREADS", "4")
     x = synth.tensor_f32(name, shape, kind)
     dt = synth.storage_dtype(name, target)
     return name, dt, (x if dt == mf.F32 else lib.quantize_host(dt, x))
 
 
 def build_q4k_file(path: str, specs, target: int = mf.Q4_K, workers: int | None = None) -> str:
-    """Synthesise + quantise every tensor (tensors in parallel worker processes: numpy's RNG is single-threaded) and write
-    the .mllm.  The output bytes do not depend on `workers`."""
+    """Synthesise + quantise every tensor and write the .mllm.  Tensors are made by a thread pool (numpy's Generator and the
+    ctypes call into the C quantiser both release the GIL); the output bytes do not depend on `workers`."""
     jobs = [(n, s, k, target) for n, s, k in specs]
     total = sum(int(np.prod(s)) for _, s, _, _ in jobs)
     if workers is None:
         workers = min(16, os.cpu_count() or 1)
     tmp = path + f".tmp{os.getpid()}"
     if workers > 1 and total > 50_000_000:
-        import multiprocessing as mp
-        os.environ["OMP_NUM_THREADS"] = "4"
-        with mp.get_context("spawn").Pool(workers) as pool:
-            items = pool.map(_make_tensor, jobs, chunksize=1)
-        os.environ.pop("OMP_NUM_THREADS", None)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            items = list(pool.map(_make_tensor, jobs))
     else:
         items = [_make_tensor(j) for j in jobs]
     mf.write_mllm(tmp, items)
