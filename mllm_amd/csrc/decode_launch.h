@@ -31,6 +31,7 @@ struct DecodeCtx {
     uint16_t *kslab, *vslab;
 };
 
+int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st);
 int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st);
 
 }  // namespace mllm_hip

@@ -599,19 +599,30 @@ extern "C" int mllm_hip_qwen2vl_vision(mllm_hip_qwen2vl *m, const float *pixel_v
 }
 
 extern "C" int mllm_hip_qwen2vl_time_gemv(mllm_hip_qwen2vl *m, int which, int iters, float *ms_per_launch, int64_t *bytes_per_launch) {
+    // which 0..3: stand-alone Q4_K GEMV launcher on gate|up, down, qkv, o; which 10..14: fused decode kernels qkv, attn, o-proj,
+    // gate|up, down.  Launch i uses layer i % layers, so consecutive launches stream different weights (28 x 15.5 MB does not
+    // fit the 256 MiB Infinity Cache): the time is that of a cold HBM stream, like inside the decode step.
     if (!m || iters <= 0) return MLLM_HIP_ERR_ARG;
-    auto &L = m->layers[0];
-    const LinearW &w = which == 0 ? L.gu : (which == 1 ? L.down : (which == 2 ? L.qkv : L.o));
-    const Q8Planes &x = which == 1 ? m->xq2 : m->xq;
-    float *y = which == 0 ? m->gu : m->h1;
-    EH(lin(m, w, x, y, MLLM_HIP_F32, w.N, nullptr, 1));  // warm
+    const int nl = (int)m->layers.size();
+    auto launch = [&](int i) -> int {
+        auto &L = m->layers[i % nl];
+        if (which >= 10) return decode_kernel_launch(m->dctx, m->dlayers.data(), i % nl == 0 && which == 10 ? 1 % nl : i % nl, which - 10, m->st);
+        const LinearW &w = which == 0 ? L.gu : (which == 1 ? L.down : (which == 2 ? L.qkv : L.o));
+        const Q8Planes &x = which == 1 ? m->xq2 : m->xq;
+        float *y = which == 0 ? m->gu : m->h1;
+        return lin(m, w, x, y, MLLM_HIP_F32, w.N, nullptr, 1);
+    };
+    for (int i = 0; i < nl; ++i) EH(launch(i));
     HH(hipEventRecord(m->ev0, m->st));
-    for (int i = 0; i < iters; ++i) EH(lin(m, w, x, y, MLLM_HIP_F32, w.N, nullptr, 1));
+    for (int i = 0; i < iters; ++i) EH(launch(i));
     HH(hipEventRecord(m->ev1, m->st));
     HH(hipEventSynchronize(m->ev1));
     float ms;
     HH(hipEventElapsedTime(&ms, m->ev0, m->ev1));
     if (ms_per_launch) *ms_per_launch = ms / iters;
-    if (bytes_per_launch) *bytes_per_launch = (int64_t)w.N * (w.K / 256) * 144;
+    auto &L0 = m->layers[0];
+    const int k = which >= 10 ? which - 10 : -1;
+    const LinearW *w = which == 0 || k == 3 ? &L0.gu : (which == 1 || k == 4 ? &L0.down : (which == 2 || k == 0 ? &L0.qkv : &L0.o));
+    if (bytes_per_launch) *bytes_per_launch = k == 1 ? (int64_t)2 * m->cache_len * m->KVD * 2 : (int64_t)w->N * (w->K / 256) * 144;
     return 0;
 }

@@ -18,11 +18,32 @@
 // hipGraph replays every step.  Weight loads are issued BEFORE the prologue so the HBM latency of the first rows overlaps
 // the prologue's arithmetic (vmcnt counts in issue order: the prologue's own small loads are issued first).
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 #include "decode_launch.h"
 
 namespace mllm_hip {
+
+// diagnostic build only (-DMLLM_HIP_STAMPS): wave 0 of every workgroup records s_memrealtime (100 MHz) at named points
+#ifndef MLLM_HIP_NT
+#define MLLM_HIP_NT 0
+#endif
+constexpr bool g_nt = MLLM_HIP_NT != 0;
+
+#ifdef MLLM_HIP_STAMPS
+__device__ unsigned long long g_stamps[8192 * 8];
+#define STAMP(i)                                                                                         \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+        }                                                                                                \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
 
 __device__ __forceinline__ float v_expf_dec(float x) {  // same polynomial as kernels_elem.hip v_expf (mllm_v_expf)
     const float r = 0x1.8p23f;
@@ -63,41 +84,63 @@ static inline size_t act_lds_bytes(int K, bool with_xf) {
     return (size_t)K + ((K / 256 * 4 + 15) & ~15) + ((K / 32 * 4 + 15) & ~15) + (with_xf ? (size_t)K * 4 : 0) + 64;
 }
 
-// one wave quantises one 256-block given as 4 consecutive values per lane (quantize_row_q8_K_reference) into LDS
-__device__ __forceinline__ void wave_quant_to_lds(float4 v, int lane, int blk, const ActLds &a) {
-    const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
-    const float amax = wave_max(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
-    const float mine = a0 == amax ? v.x : (a1 == amax ? v.y : (a2 == amax ? v.z : v.w));
-    const float mx = first_flagged(a0 == amax || a1 == amax || a2 == amax || a3 == amax, mine);
-    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    float dd = 0.0f;
-    if (amax != 0.0f) {
-        const float iscale = -128.0f / mx;
-        q0 = min(127, nearest_int(iscale * v.x));
-        q1 = min(127, nearest_int(iscale * v.y));
-        q2 = min(127, nearest_int(iscale * v.z));
-        q3 = min(127, nearest_int(iscale * v.w));
-        dd = 1.0f / iscale;
+// one wave quantises NB 256-blocks (block wid + 4i, 4 consecutive values per lane) into LDS: quantize_row_q8_K_reference.
+// Branch-free and written block-parallel (arrays over i) so the NB reduction chains interleave instead of serialising.
+template <int NB, int WPB>
+__device__ __forceinline__ void wave_quant_blocks(const float4 (&v)[NB], int lane, int wid, int nblk, const ActLds &a) {
+    float amax[NB], mx[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) amax[i] = fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) amax[i] = wave_max(amax[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const float a0 = fabsf(v[i].x), a1 = fabsf(v[i].y), a2 = fabsf(v[i].z), a3 = fabsf(v[i].w);
+        const float mine = a0 == amax[i] ? v[i].x : (a1 == amax[i] ? v[i].y : (a2 == amax[i] ? v[i].z : v[i].w));
+        mx[i] = first_flagged(a0 == amax[i] || a1 == amax[i] || a2 == amax[i] || a3 == amax[i], mine);
     }
-    reinterpret_cast<uint32_t *>(a.qs + blk * 256)[lane] =
-        (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
-    const int s = group8_sum(q0 + q1 + q2 + q3);   // sum over 8 lanes = 32 values (bsums[2k] + bsums[2k+1])
-    if ((lane & 7) == 0) a.q8s[blk * 8 + (lane >> 3)] = s;
-    if (lane == 0) a.d[blk] = dd;
+    int qsum[NB];
+    uint32_t packed[NB];
+    float dd[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const bool nz = amax[i] != 0.0f;
+        const float iscale = nz ? -128.0f / mx[i] : 0.0f;
+        const int q0 = min(127, nearest_int(iscale * v[i].x)), q1 = min(127, nearest_int(iscale * v[i].y));
+        const int q2 = min(127, nearest_int(iscale * v[i].z)), q3 = min(127, nearest_int(iscale * v[i].w));
+        dd[i] = nz ? 1.0f / iscale : 0.0f;
+        packed[i] = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+        qsum[i] = q0 + q1 + q2 + q3;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) qsum[i] = group8_sum(qsum[i]);   // 8 lanes = 32 values (bsums[2k] + bsums[2k+1])
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int blk = wid + WPB * i;
+        if (blk < nblk) {
+            reinterpret_cast<uint32_t *>(a.qs + blk * 256)[lane] = packed[i];
+            if ((lane & 7) == 0) a.q8s[blk * 8 + (lane >> 3)] = qsum[i];
+            if (lane == 0) a.d[blk] = dd[i];
+        }
+    }
+}
+__device__ __forceinline__ void wave_quant_to_lds(float4 v, int lane, int blk, const ActLds &a) {
+    const float4 vv[1] = {v};
+    wave_quant_blocks<1, 4>(vv, lane, blk, blk + 1, a);
 }
 
 // RMSNorm of one row (CPURMSNorm.cpp:31-136) by a 256-thread workgroup, then Q8_K into LDS. dim % 256 == 0, dim <= 1024*NV.
 // The row is loaded into registers by load_row() BEFORE the caller issues its weight loads (vmcnt retires in issue order).
-template <int NV>
+template <int NV, int WPB>
 __device__ __forceinline__ void load_row(float4 (&xv)[NV], const float *__restrict__ x, int dim) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int d = threadIdx.x * 4 + i * 1024;
+        const int d = threadIdx.x * 4 + i * WPB * 256;
         xv[i] = d < dim ? *reinterpret_cast<const float4 *>(x + d) : make_float4(0, 0, 0, 0);
     }
 }
-// thread (wid, lane) holds values [(wid + 4i)*256 + 4*lane, +4): exactly the 4 values of lane `lane` of quant block wid + 4i
-template <int NV>
+// thread (wid, lane) holds values [(wid + WPB*i)*256 + 4*lane, +4): exactly the 4 values of lane `lane` of quant block wid + WPB*i
+template <int NV, int WPB>
 __device__ __forceinline__ void wg_rmsnorm_quant(const float4 (&xv)[NV], const float4 (&wv)[NV], int dim, float eps, const ActLds &a, double *red) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     double ss = 0.0;
@@ -109,20 +152,25 @@ __device__ __forceinline__ void wg_rmsnorm_quant(const float4 (&xv)[NV], const f
     ss = wave_sum_d(ss);
     if (lane == 0) red[wid] = ss;
     __syncthreads();
-    ss = red[0] + red[1] + red[2] + red[3];
+    ss = red[0];
+#pragma unroll
+    for (int w = 1; w < WPB; ++w) ss += red[w];
     const float m = (float)(ss / (double)dim);
     const float inv = 1.0f / __fsqrt_rn(m + eps);
     const int nblk = dim >> 8;
+    float4 o[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int blk = wid + 4 * i;
-        if (blk < nblk) {
-            float4 o;
-            o.x = (xv[i].x * inv) * wv[i].x; o.y = (xv[i].y * inv) * wv[i].y; o.z = (xv[i].z * inv) * wv[i].z; o.w = (xv[i].w * inv) * wv[i].w;
-            wave_quant_to_lds(o, lane, blk, a);
-        }
+        o[i].x = (xv[i].x * inv) * wv[i].x; o[i].y = (xv[i].y * inv) * wv[i].y; o[i].z = (xv[i].z * inv) * wv[i].z; o[i].w = (xv[i].w * inv) * wv[i].w;
     }
+    wave_quant_blocks<NV, WPB>(o, lane, wid, nblk, a);
     __syncthreads();
+}
+
+__device__ __forceinline__ uint4 ld_nt(const uint4 *p) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 v = g_nt ? __builtin_nontemporal_load(reinterpret_cast<const u4 *>(p)) : *reinterpret_cast<const u4 *>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // ---- GEMV core: this wave computes ROWS consecutive rows of a Q4_K matrix against the LDS activation row ----------------
@@ -138,8 +186,9 @@ __device__ __forceinline__ void issue_rows(RowLoads<NSTEPS, ROWS> &L, const uint
         for (int st = 0; st < NSTEPS; ++st) {
             const int blk = st * 8 + g < nb ? st * 8 + g : 0;
             const uint8_t *wb = W + ((int64_t)rows[rr] * nb + blk) * 144;
-            L.hdr[rr][st] = *reinterpret_cast<const uint4 *>(wb);
-            L.q[rr][st] = *reinterpret_cast<const uint4 *>(wb + 16 + 16 * r);
+            // streamed once per token: non-temporal (keeps L2/MALL for the activations and partials that are re-read)
+            L.hdr[rr][st] = ld_nt(reinterpret_cast<const uint4 *>(wb));
+            L.q[rr][st] = ld_nt(reinterpret_cast<const uint4 *>(wb + 16 + 16 * r));
         }
 }
 
@@ -191,15 +240,15 @@ __device__ __forceinline__ void dot_rows(const RowLoads<NSTEPS, ROWS> &L, const 
 // ------------------------------------------------------------------------------------------------------------------------
 // dec_qkv: x (or the embedding row of state->token for layer 0) -> RMSNorm -> Q8_K -> Wqkv rows (+bias) -> qkv fp32
 // ------------------------------------------------------------------------------------------------------------------------
-template <int NSTEPS, int ROWS, bool EMBED, int NV>
-__global__ __launch_bounds__(256) void dec_qkv_kernel(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
+template <int NSTEPS, int ROWS, bool EMBED, int NV, int WPB>
+__global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
                                                       const uint8_t *__restrict__ emb_qs, const uint16_t *__restrict__ emb_d, int vocab,
                                                       const float *__restrict__ norm_w, float eps, const uint8_t *__restrict__ W,
                                                       const float *__restrict__ bias, float *__restrict__ y, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double red[4];
+    __shared__ double red[WPB];
     const ActLds a = carve_act(smem, K);
-    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nb = K >> 8;
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * WPB + (threadIdx.x >> 6), nb = K >> 8;
     int rows[ROWS];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) rows[rr] = min(wave * ROWS + rr, N - 1);
@@ -214,7 +263,7 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecodeState *__restr
         const uint16_t *dd = emb_d + (int64_t)id * (K / 32);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int d0 = threadIdx.x * 4 + i * 1024;
+            const int d0 = threadIdx.x * 4 + i * WPB * 256;
             float4 v = make_float4(0, 0, 0, 0);
             if (d0 < K) {
                 const int blk = d0 >> 5, jj = d0 & 31;           // 4 consecutive values of one 32-block: all low or all high nibbles
@@ -230,12 +279,13 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecodeState *__restr
             xv[i] = v;
         }
     } else {
-        load_row<NV>(xv, x, K);
+        load_row<NV, WPB>(xv, x, K);
     }
     float4 wv[NV];
-    load_row<NV>(wv, norm_w, K);
+    load_row<NV, WPB>(wv, norm_w, K);
     issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
-    wg_rmsnorm_quant<NV>(xv, wv, K, eps, a, red);
+    __builtin_amdgcn_sched_barrier(0);
+    wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
     float out[ROWS];
     dot_rows<NSTEPS, ROWS>(L, a, nb, lane, out);
     if (lane == 63) {
@@ -250,13 +300,13 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecodeState *__restr
 // ------------------------------------------------------------------------------------------------------------------------
 // dec_gateup: tmp -> RMSNorm -> Q8_K -> rows (gate n, up n) -> act[n] = silu(gate) * up   (gate rows [0,I), up rows [I,2I))
 // ------------------------------------------------------------------------------------------------------------------------
-template <int NSTEPS, int PAIRS, int NV>
-__global__ __launch_bounds__(256) void dec_gateup_kernel(const float *__restrict__ x, const float *__restrict__ norm_w, float eps,
+template <int NSTEPS, int PAIRS, int NV, int WPB>
+__global__ __launch_bounds__(64 * WPB) void dec_gateup_kernel(const float *__restrict__ x, const float *__restrict__ norm_w, float eps,
                                                          const uint8_t *__restrict__ W, float *__restrict__ act, int I, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double red[4];
+    __shared__ double red[WPB];
     const ActLds a = carve_act(smem, K);
-    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nb = K >> 8;
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * WPB + (threadIdx.x >> 6), nb = K >> 8;
     int rows[2 * PAIRS];
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
@@ -266,12 +316,21 @@ __global__ __launch_bounds__(256) void dec_gateup_kernel(const float *__restrict
     }
     RowLoads<NSTEPS, 2 * PAIRS> L;
     float4 xv[NV], wv[NV];
-    load_row<NV>(xv, x, K);
-    load_row<NV>(wv, norm_w, K);
+    STAMP(0);
+    load_row<NV, WPB>(xv, x, K);
+    load_row<NV, WPB>(wv, norm_w, K);
     issue_rows<NSTEPS, 2 * PAIRS>(L, W, nb, rows, lane);
-    wg_rmsnorm_quant<NV>(xv, wv, K, eps, a, red);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PAIRS * NSTEPS * 2));   // x / norm-weight rows landed (older than the weight rows)
+    STAMP(2);
+    wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
+    STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)");
+    STAMP(4);
     float out[2 * PAIRS];
     dot_rows<NSTEPS, 2 * PAIRS>(L, a, nb, lane, out);
+    STAMP(5);
     if (lane == 63) {
 #pragma unroll
         for (int p = 0; p < PAIRS; ++p) {
@@ -291,13 +350,14 @@ __global__ __launch_bounds__(256) void dec_gateup_kernel(const float *__restrict
 constexpr int WSD = 136;  // floats per (head, split) partial: [0] max, [1] sum, [2..2+D) out
 constexpr int KPWG = 64;  // keys per attention workgroup (one split)
 
-template <int NSTEPS, int ROWS, bool MERGE>
-__global__ __launch_bounds__(256) void dec_proj_kernel(const DecodeState *__restrict__ state, const float *__restrict__ xin, const float *__restrict__ ws, int heads, int D, int nsplit,
+template <int NSTEPS, int ROWS, bool MERGE, int WPB>
+__global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *__restrict__ state, const float *__restrict__ xin, const float *__restrict__ ws, int heads, int D, int nsplit,
                                                        const uint8_t *__restrict__ W, const float *__restrict__ residual, float *__restrict__ y, int N,
-                                                       int K) {
+                                                       int K, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ActLds a = carve_act(smem, K);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wave = blockIdx.x * 4 + wid, nb = K >> 8;
+    constexpr int NT = 64 * WPB, NQ = (NSTEPS * 8 + WPB - 1) / WPB;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wave = blockIdx.x * WPB + wid, nb = K >> 8;
     int rows[ROWS];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) rows[rr] = min(wave * ROWS + rr, N - 1);
@@ -324,7 +384,7 @@ __global__ __launch_bounds__(256) void dec_proj_kernel(const DecodeState *__rest
             lsum[tid] = l;
         }
         __syncthreads();
-        for (int e = tid; e < K; e += 256) {
+        for (int e = tid; e < K; e += NT) {
             const int head = e / D, dd = e - head * D;
             const float *base = ws + (int64_t)head * nsplit * WSD + 2 + dd;
             float acc = 0.0f;
@@ -334,23 +394,34 @@ __global__ __launch_bounds__(256) void dec_proj_kernel(const DecodeState *__rest
         }
         issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
         __syncthreads();
-        for (int blk = wid; blk < nb; blk += 4) wave_quant_to_lds(*reinterpret_cast<const float4 *>(a.xf + blk * 256 + lane * 4), lane, blk, a);
-    } else {
-        float4 v[(NSTEPS * 8 + 3) / 4];
+        {
+            float4 vq[NQ];
 #pragma unroll
-        for (int i = 0; i < (NSTEPS * 8 + 3) / 4; ++i) {
-            const int blk = wid + 4 * i;
-            v[i] = blk < nb ? *reinterpret_cast<const float4 *>(xin + blk * 256 + lane * 4) : make_float4(0, 0, 0, 0);
+            for (int i = 0; i < NQ; ++i) {
+                const int blk = wid + WPB * i;
+                vq[i] = blk < nb ? *reinterpret_cast<const float4 *>(a.xf + blk * 256 + lane * 4) : make_float4(0, 0, 0, 0);
+            }
+            wave_quant_blocks<NQ, WPB>(vq, lane, wid, nb, a);
+        }
+    } else {
+        float4 v[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int blk = wid + WPB * i;
+            v[i] = (blk < nb && !(dbg & 4)) ? *reinterpret_cast<const float4 *>(xin + blk * 256 + lane * 4) : make_float4(lane * 0.5f, blk, -1.0f * lane, 0.25f);
         }
         issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
-#pragma unroll
-        for (int i = 0; i < (NSTEPS * 8 + 3) / 4; ++i) {
-            const int blk = wid + 4 * i;
-            if (blk < nb) wave_quant_to_lds(v[i], lane, blk, a);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 1)) wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
     }
     __syncthreads();
     float out[ROWS];
+    if (dbg & 2) {
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) { out[rr] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < NSTEPS; ++st) out[rr] += __uint_as_float(L.hdr[rr][st].x ^ L.q[rr][st].y); }
+    } else
     dot_rows<NSTEPS, ROWS>(L, a, nb, lane, out);
     if (lane == 63) {
 #pragma unroll
@@ -666,6 +737,13 @@ __global__ void dec_advance_kernel(DecodeState *state, const int *tok, int *hist
     state->T += 1;
     state->step += 1;
 }
+#ifdef MLLM_HIP_STAMPS
+}  // namespace mllm_hip
+extern "C" int mllm_hip_debug_read_stamps(unsigned long long *host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mllm_hip::g_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+namespace mllm_hip {
+#endif
 }  // namespace mllm_hip
 
 using namespace mllm_hip;
@@ -674,34 +752,36 @@ using namespace mllm_hip;
 
 namespace mllm_hip {
 
+static int g_dbg = getenv("MLLM_HIP_DBG") ? atoi(getenv("MLLM_HIP_DBG")) : 0;
+
 template <int NS>
 static int launch_qkv(const DecodeLayer &L, const DecodeCtx &c, bool embed, const float *x, float *x_out, hipStream_t st) {
-    constexpr int ROWS = NS == 1 ? 2 : 1;
+    constexpr int ROWS = NS == 1 ? 2 : 1, WPB = 4;
     const int waves = (L.qkv_N + ROWS - 1) / ROWS;
     const size_t lds = act_lds_bytes(c.H, false);
-    constexpr int NV = NS * 2;   // K <= 2048*NS values = 1024*NV
+    constexpr int NV = (NS * 8 + WPB - 1) / WPB;   // quant blocks per wave
     if (embed)
-        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, true, NV>), dim3((waves + 3) / 4), dim3(256), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, L.in_norm,
+        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, true, NV, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, L.in_norm,
                            c.eps, L.Wqkv, L.bqkv, c.qkv, L.qkv_N, c.H);
     else
-        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, false, NV>), dim3((waves + 3) / 4), dim3(256), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, L.in_norm,
+        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, false, NV, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, L.in_norm,
                            c.eps, L.Wqkv, L.bqkv, c.qkv, L.qkv_N, c.H);
     return MH_LAUNCH_OK("dec_qkv");
 }
 template <int NS>
 static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *x, hipStream_t st) {
-    constexpr int PAIRS = NS == 1 ? 2 : 1;
+    constexpr int PAIRS = NS == 1 ? 2 : 1, WPB = 8;
     const int waves = (c.I + PAIRS - 1) / PAIRS;
-    hipLaunchKernelGGL((dec_gateup_kernel<NS, PAIRS, NS * 2>), dim3((waves + 3) / 4), dim3(256), act_lds_bytes(c.H, false), st, x, L.post_norm, c.eps, L.Wgu, c.act, c.I, c.H);
+    hipLaunchKernelGGL((dec_gateup_kernel<NS, PAIRS, (NS * 8 + WPB - 1) / WPB, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), act_lds_bytes(c.H, false), st, x, L.post_norm, c.eps, L.Wgu, c.act, c.I, c.H);
     return MH_LAUNCH_OK("dec_gateup");
 }
 template <int NS, bool MERGE>
 static int launch_proj(const uint8_t *W, const float *xin, const DecodeCtx &c, const float *residual, float *y, int N, int K, hipStream_t st) {
-    constexpr int ROWS = NS == 1 ? 2 : 1;
+    constexpr int ROWS = NS == 1 ? 2 : 1, WPB = NS >= 3 ? 16 : 4;   // long rows: 1024-thread workgroups share the row quantisation
     const int waves = (N + ROWS - 1) / ROWS;
     const size_t lds = act_lds_bytes(K, MERGE) + (MERGE ? (size_t)(c.heads * c.nsplit + c.heads) * 4 : 0);
-    hipLaunchKernelGGL((dec_proj_kernel<NS, ROWS, MERGE>), dim3((waves + 3) / 4), dim3(256), lds, st, c.state, xin, c.fa_ws, c.heads, c.D, c.nsplit, W,
-                       residual, y, N, K);
+    hipLaunchKernelGGL((dec_proj_kernel<NS, ROWS, MERGE, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, xin, c.fa_ws, c.heads, c.D, c.nsplit, W,
+                       residual, y, N, K, g_dbg);
     return MH_LAUNCH_OK("dec_proj");
 }
 
@@ -716,15 +796,18 @@ static int launch_proj(const uint8_t *W, const float *xin, const DecodeCtx &c, c
     default: return MLLM_HIP_ERR_SHAPE;                \
     }
 
-int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st) {
+// one fused kernel of layer `li`: 0 qkv, 1 attn, 2 o-proj, 3 gate|up, 4 down. x = layer input / output, t = post-attention residual
+int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st) {
     if (c.D != 128 || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
     const int group = c.heads / c.kv_heads;
     float *x = c.x0, *t = c.x1;
+    const DecodeLayer &L = layers[li];
     int rc = 0;
-    for (int li = 0; li < n_layers; ++li) {
-        const DecodeLayer &L = layers[li];
+    switch (which) {
+    case 0:
         NS_DISPATCH(c.H, rc = launch_qkv<NS>(L, c, li == 0, x, x, st));
-        if (rc) return rc;
+        return rc;
+    case 1: {
         uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.cache_limit * c.kv_heads * c.D;
 #define ATTN_CASE(G) case G: hipLaunchKernelGGL((dec_attn_kernel<128, G>), dim3(c.kv_heads, c.nsplit), dim3(256), 0, st, c.state, c.qkv, c.rope_sin, c.rope_cos, kl, vl, c.fa_ws, c.heads, c.kv_heads, c.nsplit); break;
         switch (group) {
@@ -732,15 +815,29 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
         default: return MLLM_HIP_ERR_SHAPE;
         }
 #undef ATTN_CASE
-        rc = MH_LAUNCH_OK("dec_attn");
-        if (rc) return rc;
-        NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS, true>(L.Wo, nullptr, c, x, t, c.H, c.heads * c.D, st)));
-        if (rc) return rc;
-        NS_DISPATCH(c.H, rc = launch_gateup<NS>(L, c, t, st));
-        if (rc) return rc;
-        NS_DISPATCH(c.I, rc = (launch_proj<NS, false>(L.Wdown, c.act, c, t, x, c.H, c.I, st)));
-        if (rc) return rc;
+        return MH_LAUNCH_OK("dec_attn");
     }
+    case 2:
+        NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS, true>(L.Wo, nullptr, c, x, t, c.H, c.heads * c.D, st)));
+        return rc;
+    case 3:
+        NS_DISPATCH(c.H, rc = launch_gateup<NS>(L, c, t, st));
+        return rc;
+    case 4:
+        NS_DISPATCH(c.I, rc = (launch_proj<NS, false>(L.Wdown, c.act, c, t, x, c.H, c.I, st)));
+        return rc;
+    }
+    return MLLM_HIP_ERR_ARG;
+}
+
+int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st) {
+    float *x = c.x0;
+    int rc = 0;
+    for (int li = 0; li < n_layers; ++li)
+        for (int k = 0; k < 5; ++k) {
+            rc = decode_kernel_launch(c, layers, li, k, st);
+            if (rc) return rc;
+        }
     // tied lm_head + argmax
     if (c.H % 512 != 0 || c.H / 512 > 8) {
         // shapes the fused head kernel does not cover: the stand-alone launchers (same arithmetic), then advance the state
