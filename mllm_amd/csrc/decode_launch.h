@@ -27,7 +27,8 @@ struct DecodeCtx {
     float *x0, *x1, *qkv, *act, *logits, *fa_ws, *part_val, *normed;
     int8_t *x80_qs; uint16_t *x80_d;
     int *part_idx, *tok_dev, *history;
-    const float *rope_sin, *rope_cos;   // [max_steps][D/2], row = DecodeState::step
+    const float *rope_sin, *rope_cos;   // [cache_limit][D/2], row = DecodeState::step
+    float *cur_sin, *cur_cos;           // [D/2]: the row of the step about to run (refreshed by dec_next)
     uint16_t *kslab, *vslab;
 };
 

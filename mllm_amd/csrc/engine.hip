@@ -115,7 +115,7 @@ struct mllm_hip_qwen2vl {
           *vemb = nullptr, *vm0 = nullptr;
     // fused decode path (kernels_decode.hip): device-side step state, per-step rotary rows, captured graph
     DecodeState *d_state = nullptr;
-    float *dec_sin = nullptr, *dec_cos = nullptr, *part_val = nullptr;
+    float *dec_sin = nullptr, *dec_cos = nullptr, *part_val = nullptr, *cur_sin = nullptr, *cur_cos = nullptr;
     int *part_idx = nullptr, *history = nullptr;
     int nsplit = 0, max_parts = 4096, dec_rows = 0;
     DecodeCtx dctx;
@@ -276,7 +276,9 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
     CK(alloc_q8(m, &m->xq, T, H > m->HD ? H : m->HD)); CK(alloc_q8(m, &m->xq2, T, I));
     CK(m->dalloc(&m->x80_qs, (size_t)H)); CK(m->dalloc(&m->x80_d, (size_t)(H / 32) * 2));
     CK(m->dalloc(&m->rope_sin, (size_t)T * (m->D / 2) * 4)); CK(m->dalloc(&m->rope_cos, (size_t)T * (m->D / 2) * 4));
-    CK(m->dalloc(&m->kslab, (size_t)c.layers * T * m->KVD * 2)); CK(m->dalloc(&m->vslab, (size_t)c.layers * T * m->KVD * 2));
+    // + 64 rows: the decode attention reads whole 64-key splits speculatively
+    CK(m->dalloc(&m->kslab, ((size_t)c.layers * T + 64) * m->KVD * 2)); CK(m->dalloc(&m->vslab, ((size_t)c.layers * T + 64) * m->KVD * 2));
+    hipMemset(m->kslab, 0, ((size_t)c.layers * T + 64) * m->KVD * 2); hipMemset(m->vslab, 0, ((size_t)c.layers * T + 64) * m->KVD * 2);
     m->nsplit = (T + 63) / 64;
     {
         size_t wsb = mllm_hip_fa2_workspace_bytes(1, c.heads, m->D, T), wsd = (size_t)c.heads * m->nsplit * 136 * 4;
@@ -284,6 +286,7 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
     }
     CK(m->dalloc(&m->d_state, sizeof(DecodeState)));
     CK(m->dalloc(&m->dec_sin, (size_t)T * (m->D / 2) * 4)); CK(m->dalloc(&m->dec_cos, (size_t)T * (m->D / 2) * 4));
+    CK(m->dalloc(&m->cur_sin, (size_t)m->D * 4)); CK(m->dalloc(&m->cur_cos, (size_t)m->D * 4));
     CK(m->dalloc(&m->part_val, (size_t)m->max_parts * 4)); CK(m->dalloc(&m->part_idx, (size_t)m->max_parts * 4));
     CK(m->dalloc(&m->history, (size_t)T * 4));
     {
@@ -291,7 +294,7 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
         d.state = m->d_state; d.H = H; d.I = I; d.heads = c.heads; d.kv_heads = c.kv_heads; d.D = m->D; d.vocab = c.vocab; d.cache_limit = T;
         d.nsplit = m->nsplit; d.max_parts = m->max_parts; d.eps = c.rms_eps; d.emb_qs = m->emb_qs; d.emb_d = m->emb_d; d.final_norm = m->final_norm;
         d.x0 = m->h0; d.x1 = m->h1; d.qkv = m->qkv; d.act = m->act; d.logits = m->logits; d.fa_ws = (float *)m->fa_ws; d.part_val = m->part_val;
-        d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos;
+        d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos; d.cur_sin = m->cur_sin; d.cur_cos = m->cur_cos;
         d.kslab = m->kslab; d.vslab = m->vslab; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
         for (auto &L : m->layers) {
             DecodeLayer dl;
@@ -525,6 +528,8 @@ static int arm_decode(M *m) {
         EH(mllm_hip_mrope_table(c.rope_theta, m->D, pos.data(), rows, c.mrope_section, 3, s.data(), co.data()));
         HH(hipMemcpy(m->dec_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
         HH(hipMemcpy(m->dec_cos, co.data(), co.size() * 4, hipMemcpyHostToDevice));
+        HH(hipMemcpy(m->cur_sin, s.data(), (size_t)(m->D / 2) * 4, hipMemcpyHostToDevice));
+        HH(hipMemcpy(m->cur_cos, co.data(), (size_t)(m->D / 2) * 4, hipMemcpyHostToDevice));
     }
     int tok = 0;
     HH(hipMemcpy(&tok, m->tok_dev, 4, hipMemcpyDeviceToHost));

@@ -29,6 +29,9 @@ namespace mllm_hip {
 #ifndef MLLM_HIP_NT
 #define MLLM_HIP_NT 0
 #endif
+#ifndef MLLM_HIP_PRE_ROWS
+#define MLLM_HIP_PRE_ROWS 0
+#endif
 constexpr bool g_nt = MLLM_HIP_NT != 0;
 
 #ifdef MLLM_HIP_STAMPS
@@ -177,11 +180,11 @@ __device__ __forceinline__ uint4 ld_nt(const uint4 *p) {
 template <int NSTEPS, int ROWS>
 struct RowLoads { uint4 hdr[ROWS][NSTEPS], q[ROWS][NSTEPS]; };
 
-template <int NSTEPS, int ROWS>
+template <int NSTEPS, int ROWS, int R0 = 0, int R1 = ROWS>
 __device__ __forceinline__ void issue_rows(RowLoads<NSTEPS, ROWS> &L, const uint8_t *__restrict__ W, int nb, const int *rows, int lane) {
     const int g = lane >> 3, r = lane & 7;
 #pragma unroll
-    for (int rr = 0; rr < ROWS; ++rr)
+    for (int rr = R0; rr < R1; ++rr)
 #pragma unroll
         for (int st = 0; st < NSTEPS; ++st) {
             const int blk = st * 8 + g < nb ? st * 8 + g : 0;
@@ -283,9 +286,10 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
     }
     float4 wv[NV];
     load_row<NV, WPB>(wv, norm_w, K);
-    issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
     __builtin_amdgcn_sched_barrier(0);
     wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
+    issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);   // after the prologue: see dec_gateup_kernel
+    __builtin_amdgcn_sched_barrier(0);
     float out[ROWS];
     dot_rows<NSTEPS, ROWS>(L, a, nb, lane, out);
     if (lane == 63) {
@@ -319,14 +323,18 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_kernel(const float *__res
     STAMP(0);
     load_row<NV, WPB>(xv, x, K);
     load_row<NV, WPB>(wv, norm_w, K);
-    issue_rows<NSTEPS, 2 * PAIRS>(L, W, nb, rows, lane);
+    // The activation row is tiny and L2-resident; the weight rows saturate the CU's memory queue for ~2 us.  Issuing them
+    // first makes every wave of the workgroup sit in load issue while the prologue's barriers wait for it, so only PRE rows
+    // go out before the prologue and the rest right after it (measured with the stamp build: 5.3 -> see DESIGN.md).
+    constexpr int PRE = MLLM_HIP_PRE_ROWS < 2 * PAIRS ? MLLM_HIP_PRE_ROWS : 2 * PAIRS;
+    issue_rows<NSTEPS, 2 * PAIRS, 0, PRE>(L, W, nb, rows, lane);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PAIRS * NSTEPS * 2));   // x / norm-weight rows landed (older than the weight rows)
     STAMP(2);
     wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
     STAMP(3);
-    asm volatile("s_waitcnt vmcnt(0)");
+    issue_rows<NSTEPS, 2 * PAIRS, PRE, 2 * PAIRS>(L, W, nb, rows, lane);
+    __builtin_amdgcn_sched_barrier(0);
     STAMP(4);
     float out[2 * PAIRS];
     dot_rows<NSTEPS, 2 * PAIRS>(L, a, nb, lane, out);
@@ -392,7 +400,6 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *_
             for (int sp = 0; sp < nact; ++sp) acc = __fmaf_rn(fac[head * nsplit + sp], base[sp * WSD], acc);
             a.xf[e] = acc / lsum[head];
         }
-        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
         __syncthreads();
         {
             float4 vq[NQ];
@@ -403,6 +410,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *_
             }
             wave_quant_blocks<NQ, WPB>(vq, lane, wid, nb, a);
         }
+        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
     } else {
         float4 v[NQ];
 #pragma unroll
@@ -410,9 +418,9 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *_
             const int blk = wid + WPB * i;
             v[i] = (blk < nb && !(dbg & 4)) ? *reinterpret_cast<const float4 *>(xin + blk * 256 + lane * 4) : make_float4(lane * 0.5f, blk, -1.0f * lane, 0.25f);
         }
-        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 1)) wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
+        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
     }
     __syncthreads();
     float out[ROWS];
@@ -438,133 +446,113 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *_
 // scores with 4 lanes per key (32 dims each, 16 keys per wave), P V with 2 output dims per lane over the wave's 16 keys.
 // qkv: [Hq*D | Hkv*D | Hkv*D] fp32 of this token.  Slabs: [cache_limit][Hkv*D] fp16.  D == 128.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int D, int GROUP>
+template <int D>
 __global__ __launch_bounds__(256) void dec_attn_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
                                                        const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
                                                        float *__restrict__ ws, int Hq, int Hkv, int nsplit) {
+    // one workgroup per (query head, key split): the per-wave instruction chain stays short (the kernel is latency-bound,
+    // K/V rows are re-read by the heads of a GQA group from L2)
     constexpr int HALF = D / 2;
-    __shared__ float qs[GROUP][D];
+    __shared__ float qs[D];
     __shared__ __attribute__((aligned(16))) uint16_t knew[D];
     __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
-    __shared__ float ps[4][GROUP][16];
-    __shared__ float red[4][GROUP][D + 8];
+    __shared__ float ps[4][16];
+    __shared__ float red[4][D + 8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int kvh = blockIdx.x, split = blockIdx.y;
-    const int T = state->T, Sk = T + 1;
+    const int head = blockIdx.x, split = blockIdx.y, gsize = Hq / Hkv, kvh = head / gsize;
     const int HD = Hq * D, KVD = Hkv * D;
-    float *outbase = ws + ((int64_t)(kvh * GROUP) * nsplit + split) * WSD;
+    const int kidx = lane >> 2, part = lane & 3;                 // scores: 16 keys per wave, 4 lanes (32 dims each) per key
+    const int kbase = split * KPWG + wid * 16;
+    const int key = kbase + kidx;
+    // ---- every global load of the kernel is issued here, before anything is waited for: the slab rows of this split are
+    // read speculatively (the slabs are padded to a multiple of KPWG rows), T only masks them afterwards.
+    uint4 kk[4];
+    {
+        const uint4 *kp = reinterpret_cast<const uint4 *>(kslab + (int64_t)key * KVD + kvh * D) + part * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kk[c] = kp[c];
+    }
+    uint32_t vv[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) vv[jj] = *reinterpret_cast<const uint32_t *>(vslab + (int64_t)(kbase + jj) * KVD + kvh * D + 2 * lane);
+    const int T = state->T, Sk = T + 1;
+    float qa = 0.0f, qb = 0.0f, sn = 0.0f, cs = 0.0f, vn = 0.0f;
+    if (tid < HALF) { const float *qp = qkv + head * D; qa = qp[tid]; qb = qp[tid + HALF]; sn = sin_t[tid]; cs = cos_t[tid]; }
+    else if (tid < D) { const float *kp = qkv + HD + kvh * D; qa = kp[tid - HALF]; qb = kp[tid]; sn = sin_t[tid - HALF]; cs = cos_t[tid - HALF]; }
+    else if (tid < 2 * D) vn = qkv[HD + KVD + kvh * D + (tid - D)];
+    __builtin_amdgcn_sched_barrier(0);
+    float *outp = ws + ((int64_t)head * nsplit + split) * WSD;
     if (split * KPWG >= Sk) {   // nothing to do for this split at the current length: neutral partial
-        for (int e = tid; e < GROUP * (D + 2); e += 256) {
-            const int hh = e / (D + 2), c = e - hh * (D + 2);
-            outbase[(int64_t)hh * nsplit * WSD + c] = c == 0 ? -INFINITY : 0.0f;
-        }
+        if (tid < D + 2) outp[tid] = tid == 0 ? -INFINITY : 0.0f;
         return;
     }
-    const float *sn = sin_t + (int64_t)state->step * HALF, *cs = cos_t + (int64_t)state->step * HALF;
-    // rotate the group's q heads (rope_hf: fma(a,c,-(b*s)), fma(a,s,b*c))
-    for (int e = tid; e < GROUP * HALF; e += 256) {
-        const int hh = e / HALF, d = e - hh * HALF;
-        const float *qp = qkv + (kvh * GROUP + hh) * D;
-        const float av = qp[d], bv = qp[d + HALF], sv = sn[d], cv = cs[d];
-        qs[hh][d] = __fmaf_rn(av, cv, -(bv * sv));
-        qs[hh][d + HALF] = __fmaf_rn(av, sv, bv * cv);
-    }
-    // the new key/value of this kv head: rotate k, round both to fp16 (what the reference's cache holds)
+    // rope_hf: fma(a,c,-(b*s)), fma(a,s,b*c); the new key/value are rounded to fp16 (what the reference's cache holds)
     if (tid < HALF) {
-        const float *kp = qkv + HD + kvh * D;
-        const float av = kp[tid], bv = kp[tid + HALF], sv = sn[tid], cv = cs[tid];
-        knew[tid] = f2h(__fmaf_rn(av, cv, -(bv * sv)));
-        knew[tid + HALF] = f2h(__fmaf_rn(av, sv, bv * cv));
-    } else if (tid >= 64 && tid < 64 + D) {
-        vnew[tid - 64] = f2h(qkv[HD + KVD + kvh * D + (tid - 64)]);
+        qs[tid] = __fmaf_rn(qa, cs, -(qb * sn));
+        qs[tid + HALF] = __fmaf_rn(qa, sn, qb * cs);
+    } else if (tid < D) {
+        knew[tid - HALF] = f2h(__fmaf_rn(qa, cs, -(qb * sn)));
+        knew[tid] = f2h(__fmaf_rn(qa, sn, qb * cs));
+    } else if (tid < 2 * D) {
+        vnew[tid - D] = f2h(vn);
     }
     __syncthreads();
-    if (split == T / KPWG && tid < D) {     // the split that owns position T appends to the slabs
+    if (split == T / KPWG && head % gsize == 0 && tid < D) {     // the (first head of the group, split owning position T) appends
         kslab[(int64_t)T * KVD + kvh * D + tid] = knew[tid];
         vslab[(int64_t)T * KVD + kvh * D + tid] = vnew[tid];
     }
     const float scale = 1.0f / __fsqrt_rn((float)D);
-    const int kidx = lane >> 2, part = lane & 3;                 // 16 keys per wave, 4 lanes (32 dims each) per key
-    const int kbase = split * KPWG + wid * 16;
-    const int key = kbase + kidx;
-    float s[GROUP];
+    if (key == T) {
 #pragma unroll
-    for (int hh = 0; hh < GROUP; ++hh) s[hh] = 0.0f;
-    if (key < Sk) {
-        const uint4 *kp = key == T ? reinterpret_cast<const uint4 *>(knew) + part * 4
-                                   : reinterpret_cast<const uint4 *>(kslab + (int64_t)key * KVD + kvh * D) + part * 4;
-        uint4 kk[4];
+        for (int c = 0; c < 4; ++c) kk[c] = reinterpret_cast<const uint4 *>(knew)[part * 4 + c];
+    }
+    float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) kk[c] = kp[c];
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t w[4] = {kk[c].x, kk[c].y, kk[c].z, kk[c].w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t w[4] = {kk[c].x, kk[c].y, kk[c].z, kk[c].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float k0 = h2f((uint16_t)(w[e] & 0xffff)), k1 = h2f((uint16_t)(w[e] >> 16));
-                const int dd = part * 32 + c * 8 + 2 * e;
-#pragma unroll
-                for (int hh = 0; hh < GROUP; ++hh) {
-                    s[hh] = __fmaf_rn(qs[hh][dd], k0, s[hh]);
-                    s[hh] = __fmaf_rn(qs[hh][dd + 1], k1, s[hh]);
-                }
-            }
+        for (int e = 0; e < 4; ++e) {
+            const int dd = part * 32 + c * 8 + 2 * e;
+            s = __fmaf_rn(qs[dd], h2f((uint16_t)(w[e] & 0xffff)), s);
+            s = __fmaf_rn(qs[dd + 1], h2f((uint16_t)(w[e] >> 16)), s);
         }
     }
-    float m_w[GROUP], l_w[GROUP];
-#pragma unroll
-    for (int hh = 0; hh < GROUP; ++hh) {
-        float sc = group4_sum(s[hh]);
-        sc = key < Sk ? sc : -INFINITY;
-        m_w[hh] = wave_max(sc);
-        const float mu = m_w[hh] == -INFINITY ? 0.0f : m_w[hh];
-        const float p = key < Sk ? expf((sc - mu) * scale) : 0.0f;
-        l_w[hh] = wave_sum(part == 0 ? p : 0.0f);
-        if (part == 0) ps[wid][hh][kidx] = p;
-    }
+    float sc = group4_sum(s);
+    sc = key < Sk ? sc : -INFINITY;
+    const float m_w = wave_max(sc);
+    const float mu = m_w == -INFINITY ? 0.0f : m_w;
+    const float p = key < Sk ? expf((sc - mu) * scale) : 0.0f;
+    const float l_w = wave_sum(part == 0 ? p : 0.0f);
+    if (part == 0) ps[wid][kidx] = p;
     __syncthreads();
     // P V: lane owns dims 2*lane, 2*lane+1 (D == 128 -> all 64 lanes), over this wave's (up to) 16 keys
-    float o0[GROUP], o1[GROUP];
-#pragma unroll
-    for (int hh = 0; hh < GROUP; ++hh) { o0[hh] = 0.0f; o1[hh] = 0.0f; }
+    float o0 = 0.0f, o1 = 0.0f;
     const int nk = min(16, Sk - kbase);
-    uint32_t vv[16];
+    if (T >= kbase && T < kbase + 16) {
+        const uint32_t vt = reinterpret_cast<const uint32_t *>(vnew)[lane];
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const int kk2 = kbase + jj;
-        vv[jj] = jj < nk ? (kk2 == T ? reinterpret_cast<const uint32_t *>(vnew)[lane]
-                                      : *reinterpret_cast<const uint32_t *>(vslab + (int64_t)kk2 * KVD + kvh * D + 2 * lane))
-                         : 0u;
+        for (int jj = 0; jj < 16; ++jj) if (kbase + jj == T) vv[jj] = vt;
     }
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         if (jj < nk) {
-            const float v0 = h2f((uint16_t)(vv[jj] & 0xffff)), v1 = h2f((uint16_t)(vv[jj] >> 16));
-#pragma unroll
-            for (int hh = 0; hh < GROUP; ++hh) {
-                const float pj = ps[wid][hh][jj];
-                o0[hh] = __fmaf_rn(pj, v0, o0[hh]);
-                o1[hh] = __fmaf_rn(pj, v1, o1[hh]);
-            }
+            const float pj = ps[wid][jj];
+            o0 = __fmaf_rn(pj, h2f((uint16_t)(vv[jj] & 0xffff)), o0);
+            o1 = __fmaf_rn(pj, h2f((uint16_t)(vv[jj] >> 16)), o1);
         }
     }
-#pragma unroll
-    for (int hh = 0; hh < GROUP; ++hh) {
-        if (lane == 0) { red[wid][hh][0] = m_w[hh]; red[wid][hh][1] = l_w[hh]; }
-        red[wid][hh][2 + 2 * lane] = o0[hh];
-        red[wid][hh][3 + 2 * lane] = o1[hh];
-    }
+    if (lane == 0) { red[wid][0] = m_w; red[wid][1] = l_w; }
+    red[wid][2 + 2 * lane] = o0;
+    red[wid][3 + 2 * lane] = o1;
     __syncthreads();
-    for (int e = tid; e < GROUP * (D + 2); e += 256) {
-        const int hh = e / (D + 2), c = e - hh * (D + 2);
-        const float m_tot = fmaxf(fmaxf(red[0][hh][0], red[1][hh][0]), fmaxf(red[2][hh][0], red[3][hh][0]));
+    if (tid < D + 2) {
+        const float m_tot = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
         const float mt = m_tot == -INFINITY ? 0.0f : m_tot;
         float f[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) f[w] = red[w][hh][0] == -INFINITY ? 0.0f : expf((red[w][hh][0] - mt) * scale);
-        float *outp = outbase + (int64_t)hh * nsplit * WSD;
-        if (c == 0) outp[0] = m_tot;
-        else outp[c] = f[0] * red[0][hh][c] + f[1] * red[1][hh][c] + f[2] * red[2][hh][c] + f[3] * red[3][hh][c];
+        for (int w = 0; w < 4; ++w) f[w] = red[w][0] == -INFINITY ? 0.0f : expf((red[w][0] - mt) * scale);
+        if (tid == 0) outp[0] = m_tot;
+        else outp[tid] = f[0] * red[0][tid] + f[1] * red[1][tid] + f[2] * red[2][tid] + f[3] * red[3][tid];
     }
 }
 
@@ -703,7 +691,14 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__
 
 // final argmax over the workgroup partials (std::max_element: first maximum), record the token, advance the step state
 __global__ __launch_bounds__(256) void dec_next_kernel(DecodeState *__restrict__ state, const float *__restrict__ part_val, const int *__restrict__ part_idx,
-                                                       int nparts, int *__restrict__ tok_out, int *__restrict__ history) {
+                                                       int nparts, int *__restrict__ tok_out, int *__restrict__ history, const float *__restrict__ tab_sin,
+                                                       const float *__restrict__ tab_cos, float *__restrict__ cur_sin, float *__restrict__ cur_cos, int half,
+                                                       int max_rows) {
+    // the next step's rotary row moves to a fixed address, so the attention kernel's loads do not depend on the step index
+    {
+        const int nxt = min(state->step + 1, max_rows - 1);
+        if ((int)threadIdx.x < half) { cur_sin[threadIdx.x] = tab_sin[(int64_t)nxt * half + threadIdx.x]; cur_cos[threadIdx.x] = tab_cos[(int64_t)nxt * half + threadIdx.x]; }
+    }
     __shared__ float bv[4];
     __shared__ int bi[4];
     float best = -INFINITY;
@@ -730,7 +725,10 @@ __global__ __launch_bounds__(256) void dec_next_kernel(DecodeState *__restrict__
         state->step += 1;
     }
 }
-__global__ void dec_advance_kernel(DecodeState *state, const int *tok, int *history) {
+__global__ void dec_advance_kernel(DecodeState *state, const int *tok, int *history, const float *tab_sin, const float *tab_cos, float *cur_sin,
+                                   float *cur_cos, int half, int max_rows) {
+    const int nxt = min(state->step + 1, max_rows - 1);
+    for (int i = 0; i < half; ++i) { cur_sin[i] = tab_sin[(int64_t)nxt * half + i]; cur_cos[i] = tab_cos[(int64_t)nxt * half + i]; }
     const int t = *tok;
     if (history) history[state->step] = t;
     state->token = t;
@@ -809,12 +807,9 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         return rc;
     case 1: {
         uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.cache_limit * c.kv_heads * c.D;
-#define ATTN_CASE(G) case G: hipLaunchKernelGGL((dec_attn_kernel<128, G>), dim3(c.kv_heads, c.nsplit), dim3(256), 0, st, c.state, c.qkv, c.rope_sin, c.rope_cos, kl, vl, c.fa_ws, c.heads, c.kv_heads, c.nsplit); break;
-        switch (group) {
-            ATTN_CASE(1) ATTN_CASE(2) ATTN_CASE(4) ATTN_CASE(6) ATTN_CASE(7) ATTN_CASE(8)
-        default: return MLLM_HIP_ERR_SHAPE;
-        }
-#undef ATTN_CASE
+        hipLaunchKernelGGL((dec_attn_kernel<128>), dim3(c.heads, c.nsplit), dim3(256), 0, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads,
+                           c.kv_heads, c.nsplit);
+        (void)group;
         return MH_LAUNCH_OK("dec_attn");
     }
     case 2:
@@ -846,7 +841,7 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
         if (!rc) rc = mllm_hip_linear_q40_q80(c.emb_qs, c.emb_d, nullptr, c.x80_qs, c.x80_d, c.logits, c.vocab, 1, c.vocab, c.H, st);
         if (!rc) rc = mllm_hip_argmax(c.logits, c.vocab, c.tok_dev, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, st, c.state, c.tok_dev, c.history);
+        hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, st, c.state, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos, c.D / 2, c.cache_limit);
         return MH_LAUNCH_OK("dec_advance");
     }
     const int target_waves = 256 * 12;
@@ -860,7 +855,8 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
 #undef HEAD_CASE
     rc = MH_LAUNCH_OK("dec_head");
     if (rc) return rc;
-    hipLaunchKernelGGL(dec_next_kernel, dim3(1), dim3(256), 0, st, c.state, c.part_val, c.part_idx, blocks, c.tok_dev, c.history);
+    hipLaunchKernelGGL(dec_next_kernel, dim3(1), dim3(256), 0, st, c.state, c.part_val, c.part_idx, blocks, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos,
+                       c.D / 2, c.cache_limit);
     return MH_LAUNCH_OK("dec_next");
 }
 }  // namespace mllm_hip
