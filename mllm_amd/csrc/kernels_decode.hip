@@ -370,35 +370,58 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *_
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) rows[rr] = min(wave * ROWS + rr, N - 1);
     RowLoads<NSTEPS, ROWS> L;
+    STAMP(0);
     if (MERGE) {
-        // merge of the key splits (same arithmetic as fa2_decode_merge_kernel). Phase A: one thread per head turns the split
-        // maxima into factors f_s = exp((m_s - m)*scale) and the denominator l; phase B: one thread per (head, dim) sums f_s*o_s.
+        // merge of the key splits (same arithmetic as fa2_decode_merge_kernel): out[h][d] = sum_s f_s o_s[d] / sum_s f_s l_s with
+        // f_s = exp((m_s - max_s m_s) * scale).  Thread (h, s) fetches (m_s, l_s) of every split speculatively together with
+        // T; the o_s values of the live splits are then fetched straight into registers while the factors are formed in LDS.
+        constexpr int NE = (NSTEPS * 2048 + NT - 1) / NT;   // output elements per thread
+        constexpr int SMAX = 16;                            // live splits held in registers (cache_limit <= 1024)
         const float scale = 1.0f / __fsqrt_rn((float)D);
-        float *fac = a.xf + K;            // [heads][nsplit]
-        float *lsum = fac + heads * nsplit;  // [heads]
-        const int nact = min(nsplit, state->T / KPWG + 1);   // splits holding keys at this length
-        if (tid < heads) {
-            const float *base = ws + (int64_t)tid * nsplit * WSD;
+        float *fac = a.xf + K;                 // [heads][nsplit]  f_s
+        float *lsp = fac + heads * nsplit;     // [heads][nsplit]  l_s
+        float *mbuf = lsp + heads * nsplit;    // [heads][nsplit]  m_s
+        float *lsum = mbuf + heads * nsplit;   // [heads]
+        float m_mine = -INFINITY, l_mine = 0.0f;
+        if (tid < heads * nsplit) { m_mine = ws[(int64_t)tid * WSD]; l_mine = ws[(int64_t)tid * WSD + 1]; }
+        const int nact = min(min(nsplit, SMAX), state->T / KPWG + 1);   // splits holding keys at this length
+        float ov[NE][SMAX];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * NT;
+            const int head = e / D, dd = e - head * D;
+            const float *base = ws + (int64_t)(e < K ? head : 0) * nsplit * WSD + 2 + dd;
+#pragma unroll
+            for (int sp = 0; sp < SMAX; ++sp) ov[i][sp] = sp < nact ? base[sp * WSD] : 0.0f;
+        }
+        STAMP(1);
+        if (tid < heads * nsplit) { mbuf[tid] = m_mine; lsp[tid] = l_mine; }
+        __syncthreads();
+        if (tid < heads * nsplit) {
+            const int h = tid / nsplit, sp = tid - h * nsplit;
             float m_tot = -INFINITY;
-            for (int sp = 0; sp < nact; ++sp) m_tot = fmaxf(m_tot, base[sp * WSD]);
+            for (int q = 0; q < nact; ++q) m_tot = fmaxf(m_tot, mbuf[h * nsplit + q]);
             const float mt = m_tot == -INFINITY ? 0.0f : m_tot;
+            fac[tid] = (sp < nact && m_mine != -INFINITY) ? expf((m_mine - mt) * scale) : 0.0f;
+        }
+        __syncthreads();
+        if (tid < heads) {
             float l = 0.0f;
-            for (int sp = 0; sp < nact; ++sp) {
-                const float ms = base[sp * WSD];
-                const float f = ms == -INFINITY ? 0.0f : expf((ms - mt) * scale);
-                l = __fmaf_rn(f, base[sp * WSD + 1], l);
-                fac[tid * nsplit + sp] = f;
-            }
+            for (int q = 0; q < nact; ++q) l = __fmaf_rn(fac[tid * nsplit + q], lsp[tid * nsplit + q], l);
             lsum[tid] = l;
         }
         __syncthreads();
-        for (int e = tid; e < K; e += NT) {
-            const int head = e / D, dd = e - head * D;
-            const float *base = ws + (int64_t)head * nsplit * WSD + 2 + dd;
-            float acc = 0.0f;
-#pragma unroll 4
-            for (int sp = 0; sp < nact; ++sp) acc = __fmaf_rn(fac[head * nsplit + sp], base[sp * WSD], acc);
-            a.xf[e] = acc / lsum[head];
+        STAMP(2);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * NT;
+            if (e < K) {
+                const int head = e / D;
+                float acc = 0.0f;
+#pragma unroll
+                for (int sp = 0; sp < SMAX; ++sp) if (sp < nact) acc = __fmaf_rn(fac[head * nsplit + sp], ov[i][sp], acc);
+                a.xf[e] = acc / lsum[head];
+            }
         }
         __syncthreads();
         {
@@ -408,8 +431,10 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *_
                 const int blk = wid + WPB * i;
                 vq[i] = blk < nb ? *reinterpret_cast<const float4 *>(a.xf + blk * 256 + lane * 4) : make_float4(0, 0, 0, 0);
             }
+            STAMP(3);
             wave_quant_blocks<NQ, WPB>(vq, lane, wid, nb, a);
         }
+        STAMP(4);
         issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
     } else {
         float4 v[NQ];
@@ -423,6 +448,9 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *_
         issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
     }
     __syncthreads();
+    STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)");
+    STAMP(6);
     float out[ROWS];
     if (dbg & 2) {
 #pragma unroll
@@ -431,6 +459,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *_
             for (int st = 0; st < NSTEPS; ++st) out[rr] += __uint_as_float(L.hdr[rr][st].x ^ L.q[rr][st].y); }
     } else
     dot_rows<NSTEPS, ROWS>(L, a, nb, lane, out);
+    STAMP(7);
     if (lane == 63) {
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
@@ -777,7 +806,8 @@ template <int NS, bool MERGE>
 static int launch_proj(const uint8_t *W, const float *xin, const DecodeCtx &c, const float *residual, float *y, int N, int K, hipStream_t st) {
     constexpr int ROWS = NS == 1 ? 2 : 1, WPB = NS >= 3 ? 16 : 4;   // long rows: 1024-thread workgroups share the row quantisation
     const int waves = (N + ROWS - 1) / ROWS;
-    const size_t lds = act_lds_bytes(K, MERGE) + (MERGE ? (size_t)(c.heads * c.nsplit + c.heads) * 4 : 0);
+    const size_t lds = act_lds_bytes(K, MERGE) + (MERGE ? (size_t)(3 * c.heads * c.nsplit + c.heads) * 4 : 0);
+    if (MERGE && (c.nsplit > 16 || c.heads * c.nsplit > 64 * WPB)) return MLLM_HIP_ERR_SHAPE;   // cache_limit <= 1024 in the fused decode path
     hipLaunchKernelGGL((dec_proj_kernel<NS, ROWS, MERGE, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, xin, c.fa_ws, c.heads, c.D, c.nsplit, W,
                        residual, y, N, K, g_dbg);
     return MH_LAUNCH_OK("dec_proj");
