@@ -46,3 +46,102 @@ def vision_forward(w: Weights, cfg, pix, grid, stages=None):
     y = y.reshape(-1, MM)
     y = orc.gelu(w.lin(y, "visual.merger.mlp.0", MM))
     return w.lin(y, "visual.merger.mlp.2", cfg.hidden)
+
+
+def rope_index(cfg, ids, grid):
+    """get_rope_index (modeling_qwen2_vl.hpp:436-595) for batch 1 and at most one image grid; returns pos [3][S] fp32."""
+    ids = [int(v) for v in ids]
+    S = len(ids)
+    if grid is None:
+        return np.tile(np.arange(S, dtype=np.float32), (3, 1))
+    lp = [[], [], []]
+    st, cur = 0, 0
+    n_img = sum(1 for j in range(S - 1) if ids[j] == cfg.vision_start_token_id and ids[j + 1] == cfg.image_token_id)
+    n_starts = sum(1 for j in range(S - 1) if ids[j] == cfg.vision_start_token_id)
+    remain = n_img
+    for _ in range(n_starts):
+        ed = S
+        if remain > 0:
+            for j in range(st, S):
+                if ids[j] == cfg.image_token_id:
+                    ed = j
+                    break
+        if ed == S:
+            break
+        t, h, w = [int(v) for v in grid]
+        remain -= 1
+        gt, gh, gw = t, h // cfg.v_merge, w // cfg.v_merge
+        tl = ed - st
+        if tl > 0:
+            for k in range(tl):
+                for a in range(3):
+                    lp[a].append(cur + k)
+            cur += tl
+        for ti in range(gt):
+            for hi in range(gh):
+                for wi in range(gw):
+                    lp[0].append(cur + ti); lp[1].append(cur + hi); lp[2].append(cur + wi)
+        cur = max(lp[0][-1], lp[1][-1], lp[2][-1])
+        st = ed + gt * gh * gw
+    if st < S:
+        for k in range(S - st):
+            for a in range(3):
+                lp[a].append(cur + 1 + k)
+    pos = np.zeros((3, S), dtype=np.float32)
+    for a in range(3):
+        n = min(S, len(lp[a]))
+        pos[a, :n] = np.asarray(lp[a][:n], dtype=np.float32)
+    return pos
+
+
+class LLM:
+    """Qwen2VLModel::Forward (modeling_qwen2_vl.hpp:376-403) + the demo's greedy loop (examples/demo_qwen2_vl.cpp:53-63) composed
+    from oracle ops, with the fp16 K/V slabs of CPUKVCache.cpp:10-131 kept as uint16 arrays."""
+
+    def __init__(self, w: Weights, cfg):
+        self.w, self.cfg = w, cfg
+        self.k = [np.zeros((0, cfg.kv_heads * cfg.head_dim), dtype=np.uint16) for _ in range(cfg.layers)]
+        self.v = [np.zeros((0, cfg.kv_heads * cfg.head_dim), dtype=np.uint16) for _ in range(cfg.layers)]
+        self.last_pos = -1.0
+
+    def forward(self, ids, pos, image_embeds=None, stages=None):
+        w, c = self.w, self.cfg
+        H, D, heads, kvh = c.hidden, c.head_dim, c.heads, c.kv_heads
+        ids = np.asarray(ids, dtype=np.int32)
+        S = ids.size
+        emb_name = "model.embed_tokens.weight"
+        x = orc.embedding(ids, w.f.raw(emb_name), w.f.dtype(emb_name), H)
+        if image_embeds is not None:
+            x[ids == c.image_token_id] = image_embeds
+        s, co = orc.mrope_table(c.rope_theta, D, pos)
+        for i in range(c.layers):
+            p = f"model.layers.{i}."
+            y = orc.rmsnorm(x, w.v(p + "input_layernorm.weight"), c.rms_eps)
+            q = w.lin(y, p + "self_attn.q_proj", heads * D)
+            k = w.lin(y, p + "self_attn.k_proj", kvh * D)
+            v = w.lin(y, p + "self_attn.v_proj", kvh * D, out_f16=True)
+            q = orc.rope_apply(q, S, heads, D, s, co)
+            k16 = orc.rope_apply(k, S, kvh, D, s, co, out_f16=True)
+            self.k[i] = np.concatenate([self.k[i], k16.reshape(S, kvh * D)])
+            self.v[i] = np.concatenate([self.v[i], v.reshape(S, kvh * D)])
+            o = orc.attention(q, self.k[i], self.v[i], S, self.k[i].shape[0], heads, kvh, D, True)
+            r = w.lin(o, p + "self_attn.o_proj", H, bias=False) + x
+            y = orc.rmsnorm(r, w.v(p + "post_attention_layernorm.weight"), c.rms_eps)
+            g = w.lin(y, p + "mlp.gate_proj", c.inter, bias=False)
+            u = w.lin(y, p + "mlp.up_proj", c.inter, bias=False)
+            x = w.lin(orc.silu(g) * u, p + "mlp.down_proj", H, bias=False) + r
+            if stages is not None:
+                stages[f"layer{i}"] = x.copy()
+        x = orc.rmsnorm(x[-1:], w.v("model.norm.weight"), c.rms_eps)
+        logits = orc.linear(x, w.f.raw(emb_name), w.f.dtype(emb_name), c.vocab)
+        self.last_pos = float(pos.max())
+        return logits[0]
+
+    def prefill(self, ids, pix=None, grid=None, stages=None):
+        emb = vision_forward(self.w, self.cfg, pix, grid) if pix is not None else None
+        pos = rope_index(self.cfg, ids, grid if pix is not None else None)
+        return self.forward(ids, pos, emb, stages)
+
+    def decode(self, token):
+        pos = np.full((3, 1), self.last_pos + 1.0, dtype=np.float32)
+        return self.forward([token], pos)

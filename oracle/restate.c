@@ -11,6 +11,7 @@
  * (-ffp-contract=off: every fused multiply-add below is an explicit fmaf() where the reference's AVX2 code uses an
  *  FMA intrinsic; plain a*b+c stays two roundings.)
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -294,7 +295,7 @@ void orc_layernorm(const float *x, const float *w, const float *b, float *y, int
         float sum = 0.0F, ssq = 0.0F;
         for (int d = 0; d < dim; ++d) sum += xr[d];
         float mean = sum / dim;
-        for (int d = 0; d < dim; ++d) { float c = xr[d] - mean; ssq += c * c; yr[d] = c; }
+        for (int d = 0; d < dim; ++d) { float c = xr[d] - mean; ssq = fmaf(c, c, ssq); yr[d] = c; }   /* contracted by the reference build */
         float rms = sqrtf(ssq / dim + eps);
         for (int d = 0; d < dim; ++d) yr[d] = b ? w[d] * yr[d] / rms + b[d] : w[d] * yr[d] / rms;
     }
@@ -457,46 +458,97 @@ void orc_vision_rope_apply(const float *x, int S, int H, int D, const float *ang
             }
 }
 
-/* ------------------------------------------------------------------------------------------------------------
- * A13: attention.  O = softmax(Q K^T / sqrt(D) + causal) V with GQA (kv_head = q_head / (Hq/Hkv),
- * FlashAttention2.hpp:164), causal offset delta = Sk - Sq (:324), scale applied inside the exponent (:451-457),
- * K/V fp16 widened to fp32 (:1446-1455) or fp32.  The reference tiles (Br=Bc=4, online softmax); this restatement is
- * the untiled definition with double accumulation, to which the tiled fp32 result agrees to ~1e-6 relative --
- * parity for A13 is therefore a tolerance check, stated in the tests.
- * Q [Sq][Hq][D] fp32, K/V [Sk][Hkv][D] (f16 or f32), O [Sq][Hq][D] fp32.
- * ---------------------------------------------------------------------------------------------------------- */
+/* A12/A13: F_FA2 (CPUFlashAttention2Func.hpp:52-125 -> compute/FlashAttention2.hpp), restated in the reference's own
+ * evaluation order (x86 AVX2 build) so that results are bit-identical:
+ *   - tiles Br = Bc = 4 when Sq >= 4, else Br = Bc = 1 (CPUFlashAttention2Func.hpp:71-72); Sq == 1 takes __fa2_decode
+ *     (:225-274 / :1346-1394), which is the same recurrence with one key per tile;
+ *   - mma0 (:314-357, :1432-1470): per (row, key) 8 fp32 lanes, lane l accumulating d = 8i + l by fma, then
+ *     _mm256_hadd_ps (:39-46) = ((l0+l4)+(l1+l5)) + ((l2+l6)+(l3+l7));
+ *   - causal (:351-357): tiles wholly right of the diagonal are skipped by every stage; entries j > i of the tile whose
+ *     row end meets its column end are set to lowest(); other tiles are NOT masked (the reference's behaviour when
+ *     Sk - Sq is not tile aligned -- kept);
+ *   - softmax (:430-465, :1556-1599): m' = max(m, row); c = expf((m - m') * scale); p = expf((s - m') * scale);
+ *     sum = ((p0 + p1) + p2) + p3; logsum = fmaf(logsum, c, sum) (GCC contracts it: vfmadd132ss in the built reference);
+ *   - rescale (:577-595) acc_o *= c, mma1 (:614-636) acc_o = fmaf(p_j, v_j, acc_o) for j in tile order;
+ *   - scale_and_store (:682-718): acc_o * (1.0f / logsum);
+ *   - leftover columns: the fp32 class uses Sk % Bc (:152), the fp16-KV class Sk % Tc (:1277, Tc = Sk / Bc) -- both kept.
+ * expf is the libm one the reference calls. */
+static inline float orc_hadd8(const float l[8]) {
+    return ((l[0] + l[4]) + (l[1] + l[5])) + ((l[2] + l[6]) + (l[3] + l[7]));
+}
+static inline float orc_kv_at(const void *P, int f16, size_t i) {
+    return f16 ? orc_f16_to_f32(((const uint16_t *)P)[i]) : ((const float *)P)[i];
+}
+#define ORC_NEG_INF (-FLT_MAX)
+/* one (row tile, column tile) step; nr x nc live entries, Bt = tile pitch of acc_s */
+static void orc_fa2_tile(const float *Q, const void *K, const void *V, int kv_f16, size_t ldq, size_t ldk, int D, int r0, int nr, int c0, int nc,
+                         int Bt, int delta, int causal, float scale, float *acc_s, float *acc_o, float *mx, float *logsum) {
+    if (causal && (c0 - delta > (r0 + nr - 1))) return;
+    for (int r = 0; r < nr; ++r)
+        for (int c = 0; c < nc; ++c) {
+            float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float *q = Q + (size_t)(r0 + r) * ldq;
+            size_t ko = (size_t)(c0 + c) * ldk;
+            for (int i = 0; i < D; i += 8)
+                for (int t = 0; t < 8; ++t) l[t] = fmaf(q[i + t], orc_kv_at(K, kv_f16, ko + i + t), l[t]);
+            acc_s[r * Bt + c] = orc_hadd8(l);
+        }
+    if (causal && (r0 + nr == (c0 + nc) - delta))
+        for (int r = 0; r < nr; ++r)
+            for (int c = 0; c < nc; ++c)
+                if (c > r) acc_s[r * Bt + c] = ORC_NEG_INF;
+    for (int r = 0; r < nr; ++r) {
+        float prev = mx[r], m = prev;
+        for (int c = 0; c < nc; ++c) m = fmaxf(m, acc_s[r * Bt + c]);
+        mx[r] = m;
+        float cs = expf((prev - m) * scale);
+        float sum = 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            float v = expf((acc_s[r * Bt + c] - m) * scale);
+            acc_s[r * Bt + c] = v;
+            sum += v;
+        }
+        logsum[r] = fmaf(logsum[r], cs, sum);
+        float *o = acc_o + (size_t)r * D;
+        for (int d = 0; d < D; ++d) o[d] = o[d] * cs;
+        for (int d = 0; d < D; ++d) {
+            float a = o[d];
+            for (int c = 0; c < nc; ++c) a = fmaf(acc_s[r * Bt + c], orc_kv_at(V, kv_f16, (size_t)(c0 + c) * ldk + d), a);
+            o[d] = a;
+        }
+    }
+}
 void orc_attention(const float *Q, const void *K, const void *V, int kv_f16, float *O, int Sq, int Sk, int Hq, int Hkv, int D, int causal) {
     const float scale = 1.0f / sqrtf((float)D);
     const int grp = Hq / Hkv, delta = Sk - Sq;
-#pragma omp parallel for collapse(2)
-    for (int h = 0; h < Hq; ++h)
-        for (int i = 0; i < Sq; ++i) {
-            int kvh = h / grp;
-            int lim = causal ? (i + delta + 1) : Sk;
-            if (lim > Sk) lim = Sk;
-            double *p = (double *)malloc(sizeof(double) * (lim > 0 ? lim : 1));
-            const float *q = Q + ((size_t)i * Hq + h) * D;
-            double mx = -1e300;
-            for (int j = 0; j < lim; ++j) {
-                double s = 0;
-                size_t ko = ((size_t)j * Hkv + kvh) * D;
-                for (int d = 0; d < D; ++d) s += (double)q[d] * (kv_f16 ? orc_f16_to_f32(((const uint16_t *)K)[ko + d]) : ((const float *)K)[ko + d]);
-                p[j] = s;
-                if (s > mx) mx = s;
+    const int Bt = Sq >= 4 ? 4 : 1;
+    const size_t ldq = (size_t)Hq * D, ldk = (size_t)Hkv * D;
+    const int Tr = Sq / Bt, Tr_left = Sq % Bt, Tc = Sk / Bt;
+    int Tc_left;
+    if (Sq == 1) Tc_left = Sk % Bt;                       /* __fa2_decode, both classes (:232, :1353) */
+    else Tc_left = kv_f16 ? (Tc ? Sk % Tc : 0) : Sk % Bt;  /* __fa2_prefill_append (:152 vs :1277) */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int h = 0; h < Hq; ++h) {
+        const int kvh = h / grp;
+        const float *Qh = Q + (size_t)h * D;
+        const void *Kh = kv_f16 ? (const void *)((const uint16_t *)K + (size_t)kvh * D) : (const void *)((const float *)K + (size_t)kvh * D);
+        const void *Vh = kv_f16 ? (const void *)((const uint16_t *)V + (size_t)kvh * D) : (const void *)((const float *)V + (size_t)kvh * D);
+        float acc_s[16], mx[4], logsum[4];
+        float *acc_o = (float *)malloc(sizeof(float) * 4 * D);
+        for (int tr = 0; tr < Tr + (Tr_left ? 1 : 0); ++tr) {
+            const int r0 = tr * Bt, nr = tr < Tr ? Bt : Tr_left;
+            for (int r = 0; r < 4; ++r) { mx[r] = ORC_NEG_INF; logsum[r] = 0.0f; }
+            for (int i = 0; i < 4 * D; ++i) acc_o[i] = 0.0f;
+            for (int tc = 0; tc < Tc; ++tc) orc_fa2_tile(Qh, Kh, Vh, kv_f16, ldq, ldk, D, r0, nr, tc * Bt, Bt, Bt, delta, causal, scale, acc_s, acc_o, mx, logsum);
+            if (Tc_left) orc_fa2_tile(Qh, Kh, Vh, kv_f16, ldq, ldk, D, r0, nr, Tc * Bt, Tc_left, Bt, delta, causal, scale, acc_s, acc_o, mx, logsum);
+            for (int r = 0; r < nr; ++r) {
+                const float rl = 1.0f / logsum[r];
+                float *o = O + (size_t)(r0 + r) * ldq + (size_t)h * D;
+                for (int d = 0; d < D; ++d) o[d] = acc_o[(size_t)r * D + d] * rl;
             }
-            double l = 0;
-            for (int j = 0; j < lim; ++j) { p[j] = exp((p[j] - mx) * (double)scale); l += p[j]; }
-            float *o = O + ((size_t)i * Hq + h) * D;
-            for (int d = 0; d < D; ++d) {
-                double a = 0;
-                for (int j = 0; j < lim; ++j) {
-                    size_t vo = ((size_t)j * Hkv + kvh) * D + d;
-                    a += p[j] * (kv_f16 ? orc_f16_to_f32(((const uint16_t *)V)[vo]) : ((const float *)V)[vo]);
-                }
-                o[d] = (float)(a / l);
-            }
-            free(p);
         }
+        free(acc_o);
+    }
 }
 
 /* A16/A17: patch-embed convolution with kernel == stride, VALID: one output pixel = vec_dot_fp32 over the flattened
