@@ -27,7 +27,8 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "decode_launch.h"), os.path.join(HERE, "..", "include", "mllm_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "decode_launch.h", "q4k_dot.h", "q40_dot.h", "kernels_attn_core.h")]
+    headers.append(os.path.join(HERE, "..", "include", "mllm_hip.h"))
     objs = []
     procs = []
     for s in HIP_SOURCES:

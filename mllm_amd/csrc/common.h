@@ -27,6 +27,8 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 __device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
 
+// NOTE: sqrtf() is the correctly rounded square root here (v_sqrt_f32 + refinement); __fsqrt_rn() lowers to the bare 1-ulp
+// v_sqrt_f32 on gfx950 and must not be used where the reference calls sqrtf/std::sqrt.
 // nearest_int of ggml (Quantize.hpp:174-180): magic-add, round-to-nearest-even. Explicit _rn ops: no contraction.
 __device__ __forceinline__ int nearest_int(float v) {
     float val = __fadd_rn(v, 12582912.0f);
@@ -128,6 +130,45 @@ __device__ __forceinline__ float first_flagged(bool flag, float mine) {
     const int src = __ffsll((long long)mask) - 1;
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), src));
 }
+
+// expf exactly as the reference's attention gets it from glibc 2.35 libm on an AVX2+FMA x86-64 host (__expf_fma: N = 32 table,
+// cubic in double, kd = fma(InvLn2N, x, Shift), r = fma(InvLn2N, x, -(kd - Shift))); oracle/restate.c:orc_expf is the same
+// restatement and is checked against libm on ~10^9 arguments.  Finite or -inf arguments only.
+__device__ __forceinline__ float glibc_expf(float x) {
+    static constexpr uint64_t T[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+        0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+        0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+        0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+    if (x < -0x1.9fe368p6f) return 0.0f;
+    if (x < -0x1.9d1d9ep6f) return 0x1p-149f;
+    if (x > 0x1.62e42ep6f) return __int_as_float(0x7f800000);
+    const double xd = (double)x, InvLn2N = 0x1.71547652b82fep+5, Shift = 0x1.8p+52;
+    double kd = __fma_rn(InvLn2N, xd, Shift);
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd = kd - Shift;
+    const double r = __fma_rn(InvLn2N, xd, -kd);
+    const double sc = __longlong_as_double((long long)(T[ki & 31] + (ki << 47)));
+    const double z = __fma_rn(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+    const double r2 = r * r;
+    double y = __fma_rn(r, 0x1.62e42ff0c52d6p-6, 1.0);
+    y = __fma_rn(z, r2, y);
+    return (float)(y * sc);
+}
+// inclusive max scan over the 64 lanes of a wave (lane i ends with max of lanes 0..i)
+__device__ __forceinline__ float wave_scan_max(float v) {
+    v = fmaxf(v, MH_DPPF(v, v, 0x111 /* row_shr:1 */, 0xF));
+    v = fmaxf(v, MH_DPPF(v, v, 0x112 /* row_shr:2 */, 0xF));
+    v = fmaxf(v, MH_DPPF(v, v, 0x114 /* row_shr:4 */, 0xF));
+    v = fmaxf(v, MH_DPPF(v, v, 0x118 /* row_shr:8 */, 0xF));
+    v = fmaxf(v, MH_DPPF(v, v, DPP_BCAST15, 0xA));
+    v = fmaxf(v, MH_DPPF(v, v, DPP_BCAST31, 0xC));
+    return v;
+}
+// value of lane i-1 (lane 0 receives `first`)
+__device__ __forceinline__ float wave_shift_up(float v, float first) { return MH_DPPF(first, v, 0x138 /* wave_shr:1 */, 0xF); }
 
 // 6-bit scale/min unpack of block_q4_K (get_scale_min_k4, ggml QuantizeQ4.cpp:177-184) from the 3 scale dwords.
 // Returns sc in the low byte lanes of `sc8[2]` (8 bytes) and mins in `mn8[2]`, the kmask form of VecDotQ4.cpp:231-236.

@@ -71,6 +71,7 @@ struct MllmFile {
 
 struct LinearW {          // one (possibly row-concatenated) Linear
     void *w = nullptr;    // Q4_K blocks [N][K/256] or fp32 [N][K]
+    void *wp = nullptr;   // the same rows packed for the M >= 16 GEMM (mllm_hip_q4k_prepack): prefill / vision read these
     float *bias = nullptr;
     int N = 0, K = 0, dtype = MLLM_HIP_Q4_K;
 };
@@ -109,6 +110,8 @@ struct mllm_hip_qwen2vl {
     float *rope_sin = nullptr, *rope_cos = nullptr;
     uint16_t *kslab = nullptr, *vslab = nullptr;
     void *fa_ws = nullptr;
+    void *xpack = nullptr;
+    size_t xpack_bytes = 0;
     // vision activations
     int max_patch = 0;
     float *vx = nullptr, *vr = nullptr, *vqkv = nullptr, *vattn = nullptr, *vfc = nullptr, *vact = nullptr, *vpix = nullptr, *vsin = nullptr, *vcos = nullptr,
@@ -171,6 +174,12 @@ static int load_linear_q4k(M *m, const MllmFile &f, const std::vector<std::strin
         ro += Ns[i];
     }
     lw->w = w; lw->N = N; lw->K = K; lw->dtype = MLLM_HIP_Q4_K;
+    {
+        uint8_t *wp;
+        EH(m->dalloc(&wp, mllm_hip_q4k_prepack_bytes(N, K)));
+        EH(mllm_hip_q4k_prepack(w, N, K, wp, m->st));
+        lw->wp = wp;
+    }
     if (bias) {
         EH(m->dalloc(&lw->bias, (size_t)N * 4));
         size_t bo = 0;
@@ -314,6 +323,7 @@ extern "C" void mllm_hip_qwen2vl_destroy(mllm_hip_qwen2vl *m) {
     if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
     if (m->graph) hipGraphDestroy(m->graph);
     for (void *p : m->allocs) hipFree(p);
+    if (m->xpack) hipFree(m->xpack);
     if (m->ev0) hipEventDestroy(m->ev0);
     if (m->ev1) hipEventDestroy(m->ev1);
     if (m->st) hipStreamDestroy(m->st);
@@ -368,6 +378,17 @@ static void rope_index(const M *m, const int32_t *ids, int S, const int32_t *gri
 
 // Linear on q8k planes with the GEMV/GEMM dispatch
 static int lin(M *m, const LinearW &w, const Q8Planes &x, void *y, int ydt, int64_t ldy, const float *res, int Mrows) {
+    if (Mrows >= 16) {
+        const size_t need_b = mllm_hip_q4k_prepack_bytes(Mrows, w.K);
+        if (need_b > m->xpack_bytes) {   // activation-side pack scratch, grown on demand (prefill only, never inside a captured graph)
+            HH(hipStreamSynchronize(m->st));
+            if (m->xpack) HH(hipFree(m->xpack));
+            m->xpack = nullptr; m->xpack_bytes = 0;
+            HH(hipMalloc(&m->xpack, need_b));
+            m->xpack_bytes = need_b;
+        }
+        return mllm_hip_linear_q4kp_q8k(w.wp, w.bias, x.qs, x.d, x.bs, m->xpack, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
+    }
     return mllm_hip_linear_q4k_q8k(w.w, w.bias, x.qs, x.d, x.bs, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
 }
 

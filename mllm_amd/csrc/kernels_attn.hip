@@ -1,278 +1,218 @@
-// mllm_amd/csrc/kernels_attn.hip -- A13: flash_attention_2_forward for gfx950 (compute/FlashAttention2.hpp:2236-2284).
+// mllm_amd/csrc/kernels_attn.hip -- A13: flash_attention_2_forward for gfx950, in the reference's evaluation order.
 //
-// Semantics kept from the reference: fp32 Q, fp16 (LLM KV cache) or fp32 (vision) K/V widened to fp32, fp32 accumulate,
-// GQA kv_head = q_head / (Hq/Hkv) (:164), causal offset delta = Sk - Sq (:324), scores scaled inside the exponent
-// p = expf((s - max) * scale) (:451-457), online max/sum.  The reference's tile-aligned causal quirk is NOT
-// reproduced: masking here is exact per element.
-//
-// prefill (Sq > 1): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, an fp32 fma chain -- no bf16 rounding of Q/K/V/P).
-//   One wave owns 32 query rows.  S^T = K Q^T is computed with the key on the accumulator ROW and the query on the LANE
-//   (A = K tile from LDS, B = Q from registers), so every lane owns one query's softmax state and the row reductions are
-//   in-register plus one cross-half shuffle.  P then feeds O^T = V^T P directly as the B operand: k-step s of lane half
-//   h is accumulator register s, i.e. key (s&3)+8(s>>2)+4h -- the A operand (V^T from LDS) is addressed with the same
-//   key permutation (cdna_hip_programming.md §3 "accumulator tile as the next MFMA's operand").
-// decode (Sq == 1): HBM/latency-bound KV stream; lane = key for the scores, lane = 2 output dims for P V, keys split over
-//   waves and workgroups, partial (max, sum, out) merged by a second small kernel.  Sk can come from device memory so a
-//   captured graph serves every step.
-#include <cmath>
-
+// The reference (compute/FlashAttention2.hpp) walks key tiles of Bc = 4 (Bc = 1 when Sq == 1) with an online softmax; its
+// result depends on that order (fp32 is not associative, expf of a different running max differs in the last bit), and the
+// model amplifies last-bit differences through the Q8_K re-quantisation of every Linear.  So these kernels keep the order and
+// spread across the chip only what is independent:
+//   scores    s[r][j]: 8 fp32 chains per (row, key) (chain l takes d = 8i + l), folded ((l0+l4)+(l1+l5)) + ((l2+l6)+(l3+l7))
+//             (mma0 :314-357 / :1432-1470, _mm256_hadd_ps :39-46)                         -- one thread per key, all rows
+//   softmax   m' = max(m, tile) is a prefix maximum -> DPP scan over the tiles; c = expf((m - m') scale), p = expf((s - m') scale),
+//             sum = ((p0+p1)+p2)+p3 (:430-465)                                             -- one lane per key tile
+//   P V       o[r][d] = fma(p_j, v_j[d], o[r][d] * c) in key order, logsum = fma(logsum, c, sum) (:577-636; GCC contracts the
+//             logsum update: vfmadd132ss in the built reference)                           -- one thread per (row tile, d)
+// expf is glibc's (common.h:glibc_expf).  Causal masking follows :351-357 literally: tiles right of the diagonal are skipped,
+// the tile whose row end meets its column end is masked j > i, nothing else is.  Leftover columns: Sk % 4 for fp32 K/V (:152),
+// Sk % (Sk / 4) for fp16 K/V (:1277) -- both kept.
 #include "common.h"
+#include "kernels_attn_core.h"
 
 namespace mllm_hip {
 
-typedef float v16f __attribute__((ext_vector_type(16)));
+// ------------------------------------------------------------------------------------------------------------------
+// Sq >= 4: __fa2_prefill_append with Br = Bc = 4.  One workgroup = one head x RT consecutive row tiles.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D>
+struct PrefillCfg {
+    static constexpr int RT = (256 / D) < 1 ? 1 : ((256 / D) > 4 ? 4 : (256 / D));   // row tiles per workgroup
+    static constexpr int R = 4 * RT;
+    static constexpr int SP = FA_KC + 4;   // pitch of the score rows
+};
 
-template <bool KV_F16>
-__device__ __forceinline__ float ld_kv(const void *p, int64_t i) {
-    if (KV_F16) return h2f(reinterpret_cast<const uint16_t *>(p)[i]);
-    return reinterpret_cast<const float *>(p)[i];
-}
-
-// D = head dim (multiple of 2, <= 128), DT = ceil(D/32)
-template <int D, bool KV_F16>
+template <int D, bool F16>
 __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restrict__ Q, int64_t ldq, const void *__restrict__ K, int64_t ldk,
                                                           const void *__restrict__ V, int64_t ldv, float *__restrict__ O, int64_t ldo, int Sq, int Sk,
-                                                          int Hq, int Hkv, int causal) {
-    constexpr int DT = (D + 31) / 32;
-    constexpr int KP = D + 1;       // K tile row stride (odd: conflict-free ds_read_b32 across keys)
-    constexpr int VP = DT * 32;     // V tile row stride, zero padded
-    __shared__ float Ks[32 * KP];
-    __shared__ float Vs[32 * VP];
+                                                          int sk_eff, int Hq, int Hkv, int causal) {
+    using C = PrefillCfg<D>;
+    constexpr int RT = C::RT, R = C::R, SP = C::SP;
+    __shared__ __attribute__((aligned(16))) float qs[R * D];
+    __shared__ __attribute__((aligned(16))) float S[R * SP];
+    __shared__ __attribute__((aligned(16))) float Cc[RT * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float Sm[RT * 64 * 4];
+    __shared__ float m_in[R], lfin[R];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int qc = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, kvh = head / (Hq / Hkv);
-    const int q_base = blockIdx.x * 128;
-    const int qi = q_base + wid * 32 + qc;           // this lane's query row
+    const int r0 = blockIdx.x * R;
     const int delta = Sk - Sq;
-    const float scale = __fdiv_rn(1.0f, __fsqrt_rn((float)D));
-
-    float qreg[D / 2];
-    {
-        const float *qp = Q + (int64_t)min(qi, Sq - 1) * ldq + head * D;
-#pragma unroll
-        for (int s = 0; s < D / 2; ++s) qreg[s] = qp[2 * s + h];
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int i = tid; i < R * D; i += 256) {
+        const int r = i / D, d = i - r * D;
+        qs[i] = Q[(int64_t)min(r0 + r, Sq - 1) * ldq + head * D + d];
     }
-    v16f o[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[t][i] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
-
-    const int q_last = min(q_base + 127, Sq - 1);
-    const int k_end = causal ? min(Sk, q_last + delta + 1) : Sk;
-    for (int k0 = 0; k0 < k_end; k0 += 32) {
-        __syncthreads();
-        for (int e = tid; e < 32 * D; e += 256) {
-            const int i = e / D, d = e - i * D;
-            const int key = k0 + i;
-            float kv = 0.0f, vv = 0.0f;
-            if (key < Sk) {
-                kv = ld_kv<KV_F16>(K, (int64_t)key * ldk + kvh * D + d);
-                vv = ld_kv<KV_F16>(V, (int64_t)key * ldv + kvh * D + d);
+    if (tid < R) m_in[tid] = FA_NEG;
+    // phase-C ownership: thread (g, d) accumulates rows 4g..4g+3 of dim d; threads d < 4 also carry logsum of row 4g + d
+    const int g = tid / D, d = tid - g * D;
+    const bool own = g < RT;
+    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lsum = 0.0f;
+    int klim = sk_eff;
+    if (causal) klim = min(sk_eff, r0 + R + delta + 4);   // tiles beyond are skipped for every row of this workgroup
+    __syncthreads();
+    for (int chunk0 = 0; chunk0 < klim; chunk0 += FA_KC) {
+        // ---- A: scores of key chunk0 + tid against the R rows -------------------------------------------------------
+        {
+            const int j = chunk0 + tid;
+            float kr[D];
+            load_kv_row<D, F16>(kr, K, (int64_t)min(j, Sk - 1) * ldk + kvh * D);
+            const int c0 = j & ~3, nc = min(4, sk_eff - c0);
+#pragma unroll 1
+            for (int r = 0; r < R; ++r) {
+                float s = qk_dot<D>(qs + r * D, kr);
+                const int tr0 = r0 + (r & ~3), nr = min(4, Sq - tr0);
+                if (causal && (tr0 + nr == c0 + nc - delta) && (j - c0) > (r & 3)) s = FA_NEG;
+                S[r * SP + tid] = s;
             }
-            Ks[i * KP + d] = kv;
-            Vs[i * VP + d] = vv;
         }
-        if (VP > D) for (int e = tid; e < 32 * (VP - D); e += 256) { const int i = e / (VP - D), d = D + e % (VP - D); Vs[i * VP + d] = 0.0f; }
         __syncthreads();
-
-        v16f s;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < D / 2; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[qc * KP + 2 * ks + h], qreg[ks], s, 0, 0, 0);
-        // s[r] = score(key = k0 + (r&3)+8(r>>2)+4h, query = qi)
-        float mloc = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool ok = key < Sk && (!causal || key <= qi + delta);
-            s[r] = ok ? s[r] : -INFINITY;
-            mloc = fmaxf(mloc, s[r]);
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float m_use = m_new == -INFINITY ? 0.0f : m_new;
-        const float alpha = m_run == -INFINITY ? 0.0f : expf(__fmul_rn(__fsub_rn(m_run, m_use), scale));
-        float lsum = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = expf(__fmul_rn(__fsub_rn(s[r], m_use), scale)); lsum += s[r]; }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l_run = __fmaf_rn(l_run, alpha, lsum);
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const int key = (ks & 3) + 8 * (ks >> 2) + 4 * h;
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * VP + 32 * t + qc], s[ks], o[t], 0, 0, 0);
+        // ---- B: per row, scan the 64 key tiles of the chunk ----------------------------------------------------------
+        for (int r = wid; r < R; r += 4) {
+            const int c0 = chunk0 + 4 * lane;
+            const int tr0 = r0 + (r & ~3), nr = min(4, Sq - tr0);
+            const int nc = min(4, sk_eff - c0);
+            const bool live = nc > 0 && nr > 0 && !(causal && (c0 - delta > tr0 + nr - 1));
+            const float4 s4 = *reinterpret_cast<const float4 *>(S + r * SP + 4 * lane);
+            float tm = FA_NEG;
+            if (live) {
+                tm = s4.x;
+                if (nc > 1) tm = fmaxf(tm, s4.y);
+                if (nc > 2) tm = fmaxf(tm, s4.z);
+                if (nc > 3) tm = fmaxf(tm, s4.w);
             }
-    }
-    if (qi < Sq) {
-        float *op = O + (int64_t)qi * ldo + head * D;
-        const float inv_l = l_run;
+            const float carry = m_in[r];
+            const float incl = fmaxf(wave_scan_max(tm), carry);
+            const float excl = wave_shift_up(incl, carry);
+            float4 p4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float cc = 1.0f, sum = 0.0f;
+            if (live) {
+                cc = excl == incl ? 1.0f : glibc_expf((excl - incl) * scale);
+                p4.x = glibc_expf((s4.x - incl) * scale);
+                if (nc > 1) p4.y = glibc_expf((s4.y - incl) * scale);
+                if (nc > 2) p4.z = glibc_expf((s4.z - incl) * scale);
+                if (nc > 3) p4.w = glibc_expf((s4.w - incl) * scale);
+                sum = ((p4.x + p4.y) + p4.z) + p4.w;
+            }
+            *reinterpret_cast<float4 *>(S + r * SP + 4 * lane) = p4;
+            Cc[((r >> 2) * 64 + lane) * 4 + (r & 3)] = cc;
+            Sm[((r >> 2) * 64 + lane) * 4 + (r & 3)] = sum;
+            const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) m_in[r] = last;
+        }
+        __syncthreads();
+        // ---- C: rescale + P V in key order -------------------------------------------------------------------------------
+        if (own) {
+            const int ntl = min(64, (klim - chunk0 + 3) >> 2);
+#pragma unroll 2
+            for (int tl = 0; tl < ntl; ++tl) {
+                const float4 c4 = *reinterpret_cast<const float4 *>(Cc + (g * 64 + tl) * 4);
+                float vv[4];
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+                for (int k = 0; k < 4; ++k) vv[k] = kv_at<F16>(V, (int64_t)min(chunk0 + 4 * tl + k, Sk - 1) * ldv + kvh * D + d);
+                const float cr[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = 32 * t + 8 * g4 + 4 * h;
-                if (d < D) {
-                    float4 v;
-                    v.x = __fdiv_rn(o[t][4 * g4 + 0], inv_l); v.y = __fdiv_rn(o[t][4 * g4 + 1], inv_l);
-                    v.z = __fdiv_rn(o[t][4 * g4 + 2], inv_l); v.w = __fdiv_rn(o[t][4 * g4 + 3], inv_l);
-                    *reinterpret_cast<float4 *>(op + d) = v;
+                for (int r = 0; r < 4; ++r) {
+                    const float4 p = *reinterpret_cast<const float4 *>(S + (4 * g + r) * SP + 4 * tl);
+                    float a = o[r] * cr[r];
+                    a = __fmaf_rn(p.x, vv[0], a);
+                    a = __fmaf_rn(p.y, vv[1], a);
+                    a = __fmaf_rn(p.z, vv[2], a);
+                    a = __fmaf_rn(p.w, vv[3], a);
+                    o[r] = a;
                 }
+                if (d < 4) lsum = __fmaf_rn(lsum, Cc[(g * 64 + tl) * 4 + d], Sm[(g * 64 + tl) * 4 + d]);
             }
+        }
+        __syncthreads();
+    }
+    if (own && d < 4) lfin[4 * g + d] = lsum;
+    __syncthreads();
+    if (own) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = r0 + 4 * g + r;
+            if (gr < Sq) O[(int64_t)gr * ldo + head * D + d] = o[r] * (1.0f / lfin[4 * g + r]);
+        }
     }
 }
 
-// ---- decode: partials over key splits ---------------------------------------------------------------------------------
-// workspace layout per (head, split): [0] = max, [1] = sum, [2..2+D) = unnormalised out (fp32), stride WS_STRIDE floats
-constexpr int WS_STRIDE = 136;
-
-template <int D, bool KV_F16>
-__global__ __launch_bounds__(256) void fa2_decode_partial_kernel(const float *__restrict__ Q, const void *__restrict__ K, int64_t ldk,
-                                                                 const void *__restrict__ V, int64_t ldv, float *__restrict__ ws, int Sk_host,
-                                                                 const int *__restrict__ sk_dev, int Hq, int Hkv, int nsplit) {
-    __shared__ float qs[D];
-    __shared__ float red[4][WS_STRIDE];
-    __shared__ float ps[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int head = blockIdx.x, split = blockIdx.y, kvh = head / (Hq / Hkv);
-    const int Sk = sk_dev ? *sk_dev : Sk_host;
-    const float scale = __fdiv_rn(1.0f, __fsqrt_rn((float)D));
-    if (tid < D) qs[tid] = Q[head * D + tid];
+template <int D, bool F16, int NT>
+__global__ __launch_bounds__(NT) void fa2_decode_kernel(const float *__restrict__ Q, const void *__restrict__ K, int64_t ldk, const void *__restrict__ V,
+                                                        int64_t ldv, float *__restrict__ O, int Sk, const int *__restrict__ sk_dev, int Hq, int Hkv) {
+    extern __shared__ __attribute__((aligned(16))) char fa_smem[];
+    if (sk_dev) Sk = *sk_dev;
+    float2 *pc = reinterpret_cast<float2 *>(fa_smem);
+    float *qs = reinterpret_cast<float *>(fa_smem + (size_t)((Sk + 1) & ~1) * sizeof(float2));
+    float *ob = qs + D;
+    float *wred = ob + D;
+    const int head = blockIdx.x, kvh = head / (Hq / Hkv);
+    if (threadIdx.x < D) qs[threadIdx.x] = Q[head * D + threadIdx.x];
     __syncthreads();
-    const int key = split * 256 + wid * 64 + lane;
-    float s = -INFINITY;
-    if (key < Sk) {
-        float acc = 0.0f;
-        if (KV_F16) {
-            const uint4 *kp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(K) + (int64_t)key * ldk + kvh * D);
-#pragma unroll
-            for (int c = 0; c < D / 8; ++c) {
-                const uint4 u = kp[c];
-                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc = __fmaf_rn(qs[c * 8 + 2 * e], h2f((uint16_t)(w[e] & 0xffff)), acc);
-                    acc = __fmaf_rn(qs[c * 8 + 2 * e + 1], h2f((uint16_t)(w[e] >> 16)), acc);
-                }
-            }
-        } else {
-            const float4 *kp = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(K) + (int64_t)key * ldk + kvh * D);
-#pragma unroll
-            for (int c = 0; c < D / 4; ++c) {
-                const float4 u = kp[c];
-                acc = __fmaf_rn(qs[c * 4], u.x, acc); acc = __fmaf_rn(qs[c * 4 + 1], u.y, acc);
-                acc = __fmaf_rn(qs[c * 4 + 2], u.z, acc); acc = __fmaf_rn(qs[c * 4 + 3], u.w, acc);
-            }
-        }
-        s = acc;
-    }
-    const float m_w = wave_max(s);
-    const float m_use = m_w == -INFINITY ? 0.0f : m_w;
-    const float p = key < Sk ? expf(__fmul_rn(__fsub_rn(s, m_use), scale)) : 0.0f;
-    const float l_w = wave_sum(p);
-    // P V: lane owns dims 2*lane, 2*lane+1; p_j is broadcast through LDS (a shuffle cannot read lanes masked off by D < 128)
-    ps[wid][lane] = p;
-    __syncthreads();
-    float o0 = 0.0f, o1 = 0.0f;
-    const int kbase = split * 256 + wid * 64;
-    const int nk = min(64, Sk - kbase);
-    if (2 * lane < D) {
-        for (int j = 0; j < nk; ++j) {
-            const float pj = ps[wid][j];
-            const int64_t vo = (int64_t)(kbase + j) * ldv + kvh * D + 2 * lane;
-            float v0, v1;
-            if (KV_F16) {
-                const uint32_t u = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint16_t *>(V) + vo);
-                v0 = h2f((uint16_t)(u & 0xffff)); v1 = h2f((uint16_t)(u >> 16));
-            } else {
-                const float2 u = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(V) + vo);
-                v0 = u.x; v1 = u.y;
-            }
-            o0 = __fmaf_rn(pj, v0, o0);
-            o1 = __fmaf_rn(pj, v1, o1);
-        }
-    }
-    if (lane == 0) { red[wid][0] = m_w; red[wid][1] = l_w; }
-    if (2 * lane < D) { red[wid][2 + 2 * lane] = o0; red[wid][3 + 2 * lane] = o1; }
-    __syncthreads();
-    // merge the 4 waves
-    const float m_tot = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
-    const float mt = m_tot == -INFINITY ? 0.0f : m_tot;
-    float f[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) f[w] = red[w][0] == -INFINITY ? 0.0f : expf(__fmul_rn(__fsub_rn(red[w][0], mt), scale));
-    float *out = ws + ((int64_t)head * nsplit + split) * WS_STRIDE;
-    if (tid == 0) { out[0] = m_tot; out[1] = f[0] * red[0][1] + f[1] * red[1][1] + f[2] * red[2][1] + f[3] * red[3][1]; }
-    if (tid < D) out[2 + tid] = f[0] * red[0][2 + tid] + f[1] * red[1][2 + tid] + f[2] * red[2][2 + tid] + f[3] * red[3][2 + tid];
-}
-
-template <int D>
-__global__ __launch_bounds__(128) void fa2_decode_merge_kernel(const float *__restrict__ ws, float *__restrict__ O, int nsplit) {
-    const int head = blockIdx.x, tid = threadIdx.x;
-    const float scale = __fdiv_rn(1.0f, __fsqrt_rn((float)D));
-    const float *base = ws + (int64_t)head * nsplit * WS_STRIDE;
-    float m_tot = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) m_tot = fmaxf(m_tot, base[s * WS_STRIDE]);
-    const float mt = m_tot == -INFINITY ? 0.0f : m_tot;
-    float l = 0.0f, acc = 0.0f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float ms = base[s * WS_STRIDE];
-        const float f = ms == -INFINITY ? 0.0f : expf(__fmul_rn(__fsub_rn(ms, mt), scale));
-        l = __fmaf_rn(f, base[s * WS_STRIDE + 1], l);
-        if (tid < D) acc = __fmaf_rn(f, base[s * WS_STRIDE + 2 + tid], acc);
-    }
-    if (tid < D) O[head * D + tid] = __fdiv_rn(acc, l);
+    fa2_decode_head<D, F16, NT>(qs, K, ldk, V, ldv, kvh * D, Sk, pc, wred, nullptr, nullptr, -1, ob);
+    if (threadIdx.x < D) O[head * D + threadIdx.x] = ob[threadIdx.x];
 }
 }  // namespace mllm_hip
 
 using namespace mllm_hip;
 
 extern "C" size_t mllm_hip_fa2_workspace_bytes(int Sq, int Hq, int D, int max_sk) {
-    (void)Sq; (void)D;
-    const int nsplit = (max_sk + 255) / 256;
-    return (size_t)Hq * (nsplit > 0 ? nsplit : 1) * WS_STRIDE * sizeof(float);
+    (void)Sq; (void)Hq; (void)D; (void)max_sk;
+    return 256;   // the kernels keep their state in LDS; a token allocation keeps callers' bookkeeping uniform
 }
 
 template <int D, bool F16>
 static int launch_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *V, int64_t ldv, float *O, int64_t ldo, int Sq, int Sk,
-                      int Hq, int Hkv, int causal, const int *sk_dev, void *workspace, hipStream_t st) {
-    if (Sq == 1) {
-        if (!workspace) return MLLM_HIP_ERR_ARG;
-        const int nsplit = (Sk + 255) / 256;  // with sk_dev, Sk is the upper bound (cache limit)
-        hipLaunchKernelGGL((fa2_decode_partial_kernel<D, F16>), dim3(Hq, nsplit), dim3(256), 0, st, Q, K, ldk, V, ldv, (float *)workspace, Sk, sk_dev,
-                           Hq, Hkv, nsplit);
-        int rc = MH_LAUNCH_OK("fa2_decode_partial");
-        if (rc) return rc;
-        hipLaunchKernelGGL((fa2_decode_merge_kernel<D>), dim3(Hq), dim3(128), 0, st, (const float *)workspace, O, nsplit);
-        return MH_LAUNCH_OK("fa2_decode_merge");
-    }
+                      int Hq, int Hkv, int causal, const int *sk_dev, int sk_max, hipStream_t st) {
+    constexpr int NT = 1024;
+    auto decode_row = [&](const float *q, float *o, int sk, const int *skd, int skm) -> int {
+        const size_t lds = (size_t)((skm + 1) & ~1) * sizeof(float2) + (size_t)(2 * D + NT / 64 + 2) * sizeof(float);
+        if (lds > 160 * 1024) return MLLM_HIP_ERR_SHAPE;
+        auto kern = fa2_decode_kernel<D, F16, NT>;
+        if (lds > 48 * 1024) MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(Hq), dim3(NT), lds, st, q, K, ldk, V, ldv, o, sk, skd, Hq, Hkv);
+        return MH_LAUNCH_OK("fa2_decode");
+    };
+    if (Sq == 1) return decode_row(Q, O, Sk, sk_dev, sk_dev ? sk_max : Sk);
     if (sk_dev) return MLLM_HIP_ERR_ARG;
-    hipLaunchKernelGGL((fa2_prefill_kernel<D, F16>), dim3((Sq + 127) / 128, Hq), dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, Hq, Hkv,
-                       causal);
+    if (Sq < 4) {
+        // Br = Bc = 1 (CPUFlashAttention2Func.hpp:71-72): row r of __fa2_prefill_append sees keys j <= r + (Sk - Sq) when causal,
+        // all keys otherwise, one key per tile -- the decode recurrence per row
+        for (int r = 0; r < Sq; ++r) {
+            const int sk_r = causal ? min(Sk, r + (Sk - Sq) + 1) : Sk;
+            int rc = decode_row(Q + (int64_t)r * ldq, O + (int64_t)r * ldo, sk_r, nullptr, sk_r);
+            if (rc) return rc;
+        }
+        return MLLM_HIP_OK;
+    }
+    const int Tc = Sk / 4;
+    const int left = F16 ? (Tc ? Sk % Tc : 0) : Sk % 4;
+    const int sk_eff = Tc * 4 + left;
+    constexpr int R = PrefillCfg<D>::R;
+    hipLaunchKernelGGL((fa2_prefill_kernel<D, F16>), dim3((Sq + R - 1) / R, Hq), dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, sk_eff, Hq,
+                       Hkv, causal);
     return MH_LAUNCH_OK("fa2_prefill");
 }
 
 extern "C" int mllm_hip_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *V, int64_t ldv, int kv_dtype, float *O,
                             int64_t ldo, int Sq, int Sk, int Hq, int Hkv, int D, int causal, const int *sk_dev, void *workspace, void *stream) {
+    (void)workspace;
     if (Sq <= 0 || Sk <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return MLLM_HIP_ERR_SHAPE;
     if (kv_dtype != MLLM_HIP_F16 && kv_dtype != MLLM_HIP_F32) return MLLM_HIP_ERR_DTYPE;
-    // 16-byte vector loads of K/V rows in the decode kernel
+    // 16-byte vector loads of K rows
     if ((ldk % 8) || (ldv % 8)) return MLLM_HIP_ERR_SHAPE;
     hipStream_t st = as_stream(stream);
     const bool f16 = kv_dtype == MLLM_HIP_F16;
 #define FA2_CASE(DD)                                                                                                                        \
     case DD:                                                                                                                                \
-        return f16 ? launch_fa2<DD, true>(Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, Hq, Hkv, causal, sk_dev, workspace, st)                   \
-                   : launch_fa2<DD, false>(Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, Hq, Hkv, causal, sk_dev, workspace, st);
+        return f16 ? launch_fa2<DD, true>(Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, Hq, Hkv, causal, sk_dev, Sk, st)                          \
+                   : launch_fa2<DD, false>(Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, Hq, Hkv, causal, sk_dev, Sk, st);
     switch (D) {
         FA2_CASE(16)
         FA2_CASE(64)

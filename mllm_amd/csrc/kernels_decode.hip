@@ -5,16 +5,16 @@
 // workgroup and redundantly, the small activation-side work the reference does as separate ops:
 //
 //   dec_qkv     [RMSNorm(x) -> Q8_K]            . Wqkv^T + b               -> qkv fp32            (A9+A4+A1, layer 0: +A8)
-//   dec_attn    M-RoPE(q), M-RoPE(k)->fp16 slab, v->fp16 slab, flash-decode over the slab, GQA group per workgroup (A11+A12+A13)
-//   dec_oproj   [merge key splits -> attn -> Q8_K] . Wo^T + x             -> tmp                  (A13 tail+A4+A1+A20)
+//   dec_attn    M-RoPE(q), M-RoPE(k)->fp16 slab, v->fp16 slab, __fa2_decode over the slab in key order, one workgroup per head (A11+A12+A13)
+//   dec_oproj   [attn -> Q8_K]                  . Wo^T + x                -> tmp                  (A4+A1+A20)
 //   dec_gateup  [RMSNorm(tmp) -> Q8_K]          . (Wgate|Wup)^T, silu(g)*u -> act                 (A9+A4+A1+A14+A20)
 //   dec_down    [act -> Q8_K]                   . Wdown^T + tmp           -> x                    (A4+A1+A20)
 //   dec_head    [RMSNorm(x) -> Q8_0]            . Wemb^T (tied lm_head, Q4_0 planes) -> logits + per-workgroup argmax
 //   dec_next    final argmax (first maximum), token history, advance the device-side step state
 //
 // The arithmetic of every fused piece is the same sequence of fp32/int operations as the stand-alone launchers in
-// kernels_elem/linear/attn.hip (which the prefill path uses), so decode and prefill agree with each other and with the
-// oracle to the same bars.  Per-step scalars (KV length, rotary row, token id) live in device memory, so one captured
+// kernels_elem/linear/attn.hip (which the prefill path uses) and as the reference (q4k_dot.h, kernels_attn.hip: its
+// accumulation order), so decode, prefill and the oracle agree bit for bit.  Per-step scalars (KV length, rotary row, token id) live in device memory, so one captured
 // hipGraph replays every step.  Weight loads are issued BEFORE the prologue so the HBM latency of the first rows overlaps
 // the prologue's arithmetic (vmcnt counts in issue order: the prologue's own small loads are issued first).
 #include <cmath>
@@ -22,6 +22,9 @@
 
 #include "common.h"
 #include "decode_launch.h"
+#include "q4k_dot.h"
+#include "q40_dot.h"
+#include "kernels_attn_core.h"
 
 namespace mllm_hip {
 
@@ -83,7 +86,7 @@ __device__ __forceinline__ ActLds carve_act(char *smem, int K) {
     a.xf = reinterpret_cast<float *>(smem + K + ((K / 256 * 4 + 15) & ~15) + ((K / 32 * 4 + 15) & ~15));
     return a;
 }
-static inline size_t act_lds_bytes(int K, bool with_xf) {
+__host__ __device__ static inline size_t act_lds_bytes(int K, bool with_xf) {
     return (size_t)K + ((K / 256 * 4 + 15) & ~15) + ((K / 32 * 4 + 15) & ~15) + (with_xf ? (size_t)K * 4 : 0) + 64;
 }
 
@@ -159,7 +162,7 @@ __device__ __forceinline__ void wg_rmsnorm_quant(const float4 (&xv)[NV], const f
 #pragma unroll
     for (int w = 1; w < WPB; ++w) ss += red[w];
     const float m = (float)(ss / (double)dim);
-    const float inv = 1.0f / __fsqrt_rn(m + eps);
+    const float inv = 1.0f / sqrtf(m + eps);
     const int nblk = dim >> 8;
     float4 o[NV];
 #pragma unroll
@@ -182,7 +185,7 @@ struct RowLoads { uint4 hdr[ROWS][NSTEPS], q[ROWS][NSTEPS]; };
 
 template <int NSTEPS, int ROWS, int R0 = 0, int R1 = ROWS>
 __device__ __forceinline__ void issue_rows(RowLoads<NSTEPS, ROWS> &L, const uint8_t *__restrict__ W, int nb, const int *rows, int lane) {
-    const int g = lane >> 3, r = lane & 7;
+    const int g = lane >> 3, qoff = q4k_lane_qoff(lane);
 #pragma unroll
     for (int rr = R0; rr < R1; ++rr)
 #pragma unroll
@@ -191,53 +194,24 @@ __device__ __forceinline__ void issue_rows(RowLoads<NSTEPS, ROWS> &L, const uint
             const uint8_t *wb = W + ((int64_t)rows[rr] * nb + blk) * 144;
             // streamed once per token: non-temporal (keeps L2/MALL for the activations and partials that are re-read)
             L.hdr[rr][st] = ld_nt(reinterpret_cast<const uint4 *>(wb));
-            L.q[rr][st] = ld_nt(reinterpret_cast<const uint4 *>(wb + 16 + 16 * r));
+            L.q[rr][st] = ld_nt(reinterpret_cast<const uint4 *>(wb + 16 + qoff));
         }
 }
 
+// out[rr] is wave-uniform.  tab: this wave's chain table (q4k_dot.h) inside the workgroup's dynamic LDS, after the activation image
 template <int NSTEPS, int ROWS>
-__device__ __forceinline__ void dot_rows(const RowLoads<NSTEPS, ROWS> &L, const ActLds &a, int nb, int lane, float out[ROWS]) {
-    const int g = lane >> 3, r = lane & 7, j = r >> 1, tp = r & 1;
-    int4 xa[NSTEPS], xb[NSTEPS];
-    float xdv[NSTEPS];
-    int q8s[NSTEPS];
-    bool valid[NSTEPS];
-#pragma unroll
-    for (int st = 0; st < NSTEPS; ++st) {
-        const int blk = st * 8 + g;
-        valid[st] = blk < nb;
-        const int b = valid[st] ? blk : 0;
-        xa[st] = *reinterpret_cast<const int4 *>(a.qs + b * 256 + 64 * j + 16 * tp);
-        xb[st] = *reinterpret_cast<const int4 *>(a.qs + b * 256 + 64 * j + 32 + 16 * tp);
-        xdv[st] = a.d[b];
-        q8s[st] = a.q8s[b * 8 + r];
-    }
-#pragma unroll
-    for (int rr = 0; rr < ROWS; ++rr) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int st = 0; st < NSTEPS; ++st) {
-            const uint4 hdr = L.hdr[rr][st], q = L.q[rr][st];
-            const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
-            uint32_t sc8[2], mn8[2];
-            unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
-            const int sc_lo = byte_of(sc8, 2 * j), sc_hi = byte_of(sc8, 2 * j + 1), mr = byte_of(mn8, r);
-            int dl = dot4((int)(q.x & 0x0f0f0f0fu), xa[st].x, 0);
-            dl = dot4((int)(q.y & 0x0f0f0f0fu), xa[st].y, dl);
-            dl = dot4((int)(q.z & 0x0f0f0f0fu), xa[st].z, dl);
-            dl = dot4((int)(q.w & 0x0f0f0f0fu), xa[st].w, dl);
-            int dh = dot4((int)((q.x >> 4) & 0x0f0f0f0fu), xb[st].x, 0);
-            dh = dot4((int)((q.y >> 4) & 0x0f0f0f0fu), xb[st].y, dh);
-            dh = dot4((int)((q.z >> 4) & 0x0f0f0f0fu), xb[st].z, dh);
-            dh = dot4((int)((q.w >> 4) & 0x0f0f0f0fu), xb[st].w, dh);
-            int i1 = sc_lo * dl + sc_hi * dh, i2 = mr * q8s[st];
-            i1 = group8_sum(i1);
-            i2 = group8_sum(i2);
-            const float p = __fmaf_rn(xdv[st] * d, (float)i1, -((xdv[st] * dmin) * (float)i2));
-            acc += valid[st] ? p : 0.0f;
-        }
-        out[rr] = groups_total_lane63(acc);   // valid in lane 63
-    }
+__device__ __forceinline__ void dot_rows(const RowLoads<NSTEPS, ROWS> &L, const ActLds &a, int nb, int lane, float2 *tab, float (&out)[ROWS]) {
+    Q4KAct<NSTEPS> A;
+    q4k_load_act<NSTEPS>(A, a.qs, a.d, a.q8s, nb, lane);
+    q4k_dot_rows<NSTEPS, ROWS>(L.hdr, L.q, A, nb, lane, tab, out);
+}
+template <int NSTEPS, int ROWS>
+__device__ __forceinline__ float2 *wave_tab(char *smem, int K, bool with_xf, int wid) {
+    return reinterpret_cast<float2 *>(smem + ((act_lds_bytes(K, with_xf) + 15) & ~(size_t)15) + (size_t)wid * q4k_tab_bytes(NSTEPS, ROWS));
+}
+template <int NSTEPS, int ROWS>
+static inline size_t fused_lds_bytes(int K, bool with_xf, int wpb) {
+    return ((act_lds_bytes(K, with_xf) + 15) & ~(size_t)15) + (size_t)wpb * q4k_tab_bytes(NSTEPS, ROWS);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -291,7 +265,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
     issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);   // after the prologue: see dec_gateup_kernel
     __builtin_amdgcn_sched_barrier(0);
     float out[ROWS];
-    dot_rows<NSTEPS, ROWS>(L, a, nb, lane, out);
+    dot_rows<NSTEPS, ROWS>(L, a, nb, lane, wave_tab<NSTEPS, ROWS>(smem, K, false, threadIdx.x >> 6), out);
     if (lane == 63) {
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
@@ -337,7 +311,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_kernel(const float *__res
     __builtin_amdgcn_sched_barrier(0);
     STAMP(4);
     float out[2 * PAIRS];
-    dot_rows<NSTEPS, 2 * PAIRS>(L, a, nb, lane, out);
+    dot_rows<NSTEPS, 2 * PAIRS>(L, a, nb, lane, wave_tab<NSTEPS, 2 * PAIRS>(smem, K, false, threadIdx.x >> 6), out);
     STAMP(5);
     if (lane == 63) {
 #pragma unroll
@@ -352,113 +326,33 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// dec_down / dec_oproj: fp32 activation row (act, or the merged attention output) -> Q8_K -> W rows + residual -> y
-// MERGE: the activation row is first assembled from the flash-decode partials (max, sum, out[D]) of every key split.
+// dec_down / dec_oproj: fp32 activation row (act, or the attention output row) -> Q8_K -> W rows + residual -> y
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int WSD = 136;  // floats per (head, split) partial: [0] max, [1] sum, [2..2+D) out
-constexpr int KPWG = 64;  // keys per attention workgroup (one split)
-
-template <int NSTEPS, int ROWS, bool MERGE, int WPB>
-__global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *__restrict__ state, const float *__restrict__ xin, const float *__restrict__ ws, int heads, int D, int nsplit,
-                                                       const uint8_t *__restrict__ W, const float *__restrict__ residual, float *__restrict__ y, int N,
-                                                       int K, int dbg) {
+template <int NSTEPS, int ROWS, int WPB>
+__global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const float *__restrict__ xin, const uint8_t *__restrict__ W, const float *__restrict__ residual,
+                                                            float *__restrict__ y, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ActLds a = carve_act(smem, K);
-    constexpr int NT = 64 * WPB, NQ = (NSTEPS * 8 + WPB - 1) / WPB;
+    constexpr int NQ = (NSTEPS * 8 + WPB - 1) / WPB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wave = blockIdx.x * WPB + wid, nb = K >> 8;
     int rows[ROWS];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) rows[rr] = min(wave * ROWS + rr, N - 1);
     RowLoads<NSTEPS, ROWS> L;
     STAMP(0);
-    if (MERGE) {
-        // merge of the key splits (same arithmetic as fa2_decode_merge_kernel): out[h][d] = sum_s f_s o_s[d] / sum_s f_s l_s with
-        // f_s = exp((m_s - max_s m_s) * scale).  Thread (h, s) fetches (m_s, l_s) of every split speculatively together with
-        // T; the o_s values of the live splits are then fetched straight into registers while the factors are formed in LDS.
-        constexpr int NE = (NSTEPS * 2048 + NT - 1) / NT;   // output elements per thread
-        constexpr int SMAX = 16;                            // live splits held in registers (cache_limit <= 1024)
-        const float scale = 1.0f / __fsqrt_rn((float)D);
-        float *fac = a.xf + K;                 // [heads][nsplit]  f_s
-        float *lsp = fac + heads * nsplit;     // [heads][nsplit]  l_s
-        float *mbuf = lsp + heads * nsplit;    // [heads][nsplit]  m_s
-        float *lsum = mbuf + heads * nsplit;   // [heads]
-        float m_mine = -INFINITY, l_mine = 0.0f;
-        if (tid < heads * nsplit) { m_mine = ws[(int64_t)tid * WSD]; l_mine = ws[(int64_t)tid * WSD + 1]; }
-        const int nact = min(min(nsplit, SMAX), state->T / KPWG + 1);   // splits holding keys at this length
-        float ov[NE][SMAX];
+    float4 v[NQ];
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * NT;
-            const int head = e / D, dd = e - head * D;
-            const float *base = ws + (int64_t)(e < K ? head : 0) * nsplit * WSD + 2 + dd;
-#pragma unroll
-            for (int sp = 0; sp < SMAX; ++sp) ov[i][sp] = sp < nact ? base[sp * WSD] : 0.0f;
-        }
-        STAMP(1);
-        if (tid < heads * nsplit) { mbuf[tid] = m_mine; lsp[tid] = l_mine; }
-        __syncthreads();
-        if (tid < heads * nsplit) {
-            const int h = tid / nsplit, sp = tid - h * nsplit;
-            float m_tot = -INFINITY;
-            for (int q = 0; q < nact; ++q) m_tot = fmaxf(m_tot, mbuf[h * nsplit + q]);
-            const float mt = m_tot == -INFINITY ? 0.0f : m_tot;
-            fac[tid] = (sp < nact && m_mine != -INFINITY) ? expf((m_mine - mt) * scale) : 0.0f;
-        }
-        __syncthreads();
-        if (tid < heads) {
-            float l = 0.0f;
-            for (int q = 0; q < nact; ++q) l = __fmaf_rn(fac[tid * nsplit + q], lsp[tid * nsplit + q], l);
-            lsum[tid] = l;
-        }
-        __syncthreads();
-        STAMP(2);
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * NT;
-            if (e < K) {
-                const int head = e / D;
-                float acc = 0.0f;
-#pragma unroll
-                for (int sp = 0; sp < SMAX; ++sp) if (sp < nact) acc = __fmaf_rn(fac[head * nsplit + sp], ov[i][sp], acc);
-                a.xf[e] = acc / lsum[head];
-            }
-        }
-        __syncthreads();
-        {
-            float4 vq[NQ];
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int blk = wid + WPB * i;
-                vq[i] = blk < nb ? *reinterpret_cast<const float4 *>(a.xf + blk * 256 + lane * 4) : make_float4(0, 0, 0, 0);
-            }
-            STAMP(3);
-            wave_quant_blocks<NQ, WPB>(vq, lane, wid, nb, a);
-        }
-        STAMP(4);
-        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
-    } else {
-        float4 v[NQ];
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int blk = wid + WPB * i;
-            v[i] = (blk < nb && !(dbg & 4)) ? *reinterpret_cast<const float4 *>(xin + blk * 256 + lane * 4) : make_float4(lane * 0.5f, blk, -1.0f * lane, 0.25f);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 1)) wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
-        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+    for (int i = 0; i < NQ; ++i) {
+        const int blk = wid + WPB * i;
+        v[i] = blk < nb ? *reinterpret_cast<const float4 *>(xin + blk * 256 + lane * 4) : make_float4(0, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
+    issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
     __syncthreads();
     STAMP(5);
-    asm volatile("s_waitcnt vmcnt(0)");
-    STAMP(6);
     float out[ROWS];
-    if (dbg & 2) {
-#pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) { out[rr] = 0.0f;
-#pragma unroll
-            for (int st = 0; st < NSTEPS; ++st) out[rr] += __uint_as_float(L.hdr[rr][st].x ^ L.q[rr][st].y); }
-    } else
-    dot_rows<NSTEPS, ROWS>(L, a, nb, lane, out);
+    dot_rows<NSTEPS, ROWS>(L, a, nb, lane, wave_tab<NSTEPS, ROWS>(smem, K, false, wid), out);
     STAMP(7);
     if (lane == 63) {
 #pragma unroll
@@ -470,119 +364,50 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const DecodeState *_
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// dec_attn: one workgroup per (kv head, key split of 64 keys). Rotates q (all GROUP heads of the GQA group) and the new k
-// with the step's sin/cos row, appends k,v (fp16) to the slab, then flash-decode partials for the group's heads:
-// scores with 4 lanes per key (32 dims each, 16 keys per wave), P V with 2 output dims per lane over the wave's 16 keys.
-// qkv: [Hq*D | Hkv*D | Hkv*D] fp32 of this token.  Slabs: [cache_limit][Hkv*D] fp16.  D == 128.
+// dec_attn: one workgroup (1024 threads) per query head.  Rotates q and the new k with the step's sin/cos row (rope_hf:
+// fma(a,c,-(b*s)), fma(a,s,b*c)), rounds the new k, v to fp16 (what the reference's cache holds; the first head of a GQA group
+// appends them to the slab), then __fa2_decode over keys 0..T in key order (kernels_attn_core.h).
+// qkv: [Hq*D | Hkv*D | Hkv*D] fp32 of this token.  Slabs: [cache_limit][Hkv*D] fp16.  out: [Hq*D] fp32.
 // ------------------------------------------------------------------------------------------------------------------------
+constexpr int DEC_ATTN_NT = 1024;
+static inline size_t dec_attn_lds(int cache_limit, int D) {
+    return (size_t)((cache_limit + 2) & ~1) * sizeof(float2) + (size_t)(2 * D + DEC_ATTN_NT / 64 + 2) * sizeof(float);
+}
 template <int D>
-__global__ __launch_bounds__(256) void dec_attn_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
-                                                       const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
-                                                       float *__restrict__ ws, int Hq, int Hkv, int nsplit) {
-    // one workgroup per (query head, key split): the per-wave instruction chain stays short (the kernel is latency-bound,
-    // K/V rows are re-read by the heads of a GQA group from L2)
+__global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
+                                                               const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
+                                                               float *__restrict__ out, int Hq, int Hkv, int cache_limit) {
     constexpr int HALF = D / 2;
-    __shared__ float qs[D];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint16_t knew[D];
     __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
-    __shared__ float ps[4][16];
-    __shared__ float red[4][D + 8];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int head = blockIdx.x, split = blockIdx.y, gsize = Hq / Hkv, kvh = head / gsize;
+    float2 *pc = reinterpret_cast<float2 *>(smem);
+    float *qs = reinterpret_cast<float *>(smem + (size_t)((cache_limit + 2) & ~1) * sizeof(float2));
+    float *ob = qs + D, *wred = ob + D;
+    const int tid = threadIdx.x;
+    const int head = blockIdx.x, gsize = Hq / Hkv, kvh = head / gsize;
     const int HD = Hq * D, KVD = Hkv * D;
-    const int kidx = lane >> 2, part = lane & 3;                 // scores: 16 keys per wave, 4 lanes (32 dims each) per key
-    const int kbase = split * KPWG + wid * 16;
-    const int key = kbase + kidx;
-    // ---- every global load of the kernel is issued here, before anything is waited for: the slab rows of this split are
-    // read speculatively (the slabs are padded to a multiple of KPWG rows), T only masks them afterwards.
-    uint4 kk[4];
-    {
-        const uint4 *kp = reinterpret_cast<const uint4 *>(kslab + (int64_t)key * KVD + kvh * D) + part * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) kk[c] = kp[c];
-    }
-    uint32_t vv[16];
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) vv[jj] = *reinterpret_cast<const uint32_t *>(vslab + (int64_t)(kbase + jj) * KVD + kvh * D + 2 * lane);
-    const int T = state->T, Sk = T + 1;
-    float qa = 0.0f, qb = 0.0f, sn = 0.0f, cs = 0.0f, vn = 0.0f;
-    if (tid < HALF) { const float *qp = qkv + head * D; qa = qp[tid]; qb = qp[tid + HALF]; sn = sin_t[tid]; cs = cos_t[tid]; }
-    else if (tid < D) { const float *kp = qkv + HD + kvh * D; qa = kp[tid - HALF]; qb = kp[tid]; sn = sin_t[tid - HALF]; cs = cos_t[tid - HALF]; }
-    else if (tid < 2 * D) vn = qkv[HD + KVD + kvh * D + (tid - D)];
-    __builtin_amdgcn_sched_barrier(0);
-    float *outp = ws + ((int64_t)head * nsplit + split) * WSD;
-    if (split * KPWG >= Sk) {   // nothing to do for this split at the current length: neutral partial
-        if (tid < D + 2) outp[tid] = tid == 0 ? -INFINITY : 0.0f;
-        return;
-    }
-    // rope_hf: fma(a,c,-(b*s)), fma(a,s,b*c); the new key/value are rounded to fp16 (what the reference's cache holds)
+    const int T = min(state->T, cache_limit - 1), Sk = T + 1;
     if (tid < HALF) {
+        const float *qp = qkv + head * D;
+        const float qa = qp[tid], qb = qp[tid + HALF], sn = sin_t[tid], cs = cos_t[tid];
         qs[tid] = __fmaf_rn(qa, cs, -(qb * sn));
         qs[tid + HALF] = __fmaf_rn(qa, sn, qb * cs);
     } else if (tid < D) {
-        knew[tid - HALF] = f2h(__fmaf_rn(qa, cs, -(qb * sn)));
-        knew[tid] = f2h(__fmaf_rn(qa, sn, qb * cs));
+        const float *kp = qkv + HD + kvh * D;
+        const float ka = kp[tid - HALF], kb = kp[tid], sn = sin_t[tid - HALF], cs = cos_t[tid - HALF];
+        knew[tid - HALF] = f2h(__fmaf_rn(ka, cs, -(kb * sn)));
+        knew[tid] = f2h(__fmaf_rn(ka, sn, kb * cs));
     } else if (tid < 2 * D) {
-        vnew[tid - D] = f2h(vn);
+        vnew[tid - D] = f2h(qkv[HD + KVD + kvh * D + (tid - D)]);
     }
     __syncthreads();
-    if (split == T / KPWG && head % gsize == 0 && tid < D) {     // the (first head of the group, split owning position T) appends
+    if (head % gsize == 0 && tid < D) {
         kslab[(int64_t)T * KVD + kvh * D + tid] = knew[tid];
         vslab[(int64_t)T * KVD + kvh * D + tid] = vnew[tid];
     }
-    const float scale = 1.0f / __fsqrt_rn((float)D);
-    if (key == T) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) kk[c] = reinterpret_cast<const uint4 *>(knew)[part * 4 + c];
-    }
-    float s = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint32_t w[4] = {kk[c].x, kk[c].y, kk[c].z, kk[c].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int dd = part * 32 + c * 8 + 2 * e;
-            s = __fmaf_rn(qs[dd], h2f((uint16_t)(w[e] & 0xffff)), s);
-            s = __fmaf_rn(qs[dd + 1], h2f((uint16_t)(w[e] >> 16)), s);
-        }
-    }
-    float sc = group4_sum(s);
-    sc = key < Sk ? sc : -INFINITY;
-    const float m_w = wave_max(sc);
-    const float mu = m_w == -INFINITY ? 0.0f : m_w;
-    const float p = key < Sk ? expf((sc - mu) * scale) : 0.0f;
-    const float l_w = wave_sum(part == 0 ? p : 0.0f);
-    if (part == 0) ps[wid][kidx] = p;
-    __syncthreads();
-    // P V: lane owns dims 2*lane, 2*lane+1 (D == 128 -> all 64 lanes), over this wave's (up to) 16 keys
-    float o0 = 0.0f, o1 = 0.0f;
-    const int nk = min(16, Sk - kbase);
-    if (T >= kbase && T < kbase + 16) {
-        const uint32_t vt = reinterpret_cast<const uint32_t *>(vnew)[lane];
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj) if (kbase + jj == T) vv[jj] = vt;
-    }
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        if (jj < nk) {
-            const float pj = ps[wid][jj];
-            o0 = __fmaf_rn(pj, h2f((uint16_t)(vv[jj] & 0xffff)), o0);
-            o1 = __fmaf_rn(pj, h2f((uint16_t)(vv[jj] >> 16)), o1);
-        }
-    }
-    if (lane == 0) { red[wid][0] = m_w; red[wid][1] = l_w; }
-    red[wid][2 + 2 * lane] = o0;
-    red[wid][3 + 2 * lane] = o1;
-    __syncthreads();
-    if (tid < D + 2) {
-        const float m_tot = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
-        const float mt = m_tot == -INFINITY ? 0.0f : m_tot;
-        float f[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) f[w] = red[w][0] == -INFINITY ? 0.0f : expf((red[w][0] - mt) * scale);
-        if (tid == 0) outp[0] = m_tot;
-        else outp[tid] = f[0] * red[0][tid] + f[1] * red[1][tid] + f[2] * red[2][tid] + f[3] * red[3][tid];
-    }
+    fa2_decode_head<D, true, DEC_ATTN_NT>(qs, kslab, KVD, vslab, KVD, kvh * D, Sk, pc, wred, knew, vnew, T, ob);
+    if (tid < D) out[head * D + tid] = ob[tid];
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -626,7 +451,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__
     if (lane == 0) red[wid] = ss;
     __syncthreads();
     ss = red[0] + red[1] + red[2] + red[3];
-    const float inv = 1.0f / __fsqrt_rn((float)(ss / (double)K) + eps);
+    const float inv = 1.0f / sqrtf((float)(ss / (double)K) + eps);
     // Q8_0 (quantize_row_q8_0_reference): 8 lanes per 32-block
     for (int blk = tid >> 3; blk < K / 32; blk += 32) {
         const int d4 = blk * 32 + (tid & 7) * 4;
@@ -642,20 +467,9 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__
         if ((tid & 7) == 0) xdd[blk] = h2f(f2h(dd));
     }
     __syncthreads();
-    int4 xa[BPL], xb[BPL];
-    float xdv[BPL];
-    int xs8[BPL];
-#pragma unroll
-    for (int b = 0; b < BPL; ++b) {
-        const int blk = sub + 16 * b;
-        xa[b] = *reinterpret_cast<const int4 *>(xq + blk * 32);
-        xb[b] = *reinterpret_cast<const int4 *>(xq + blk * 32 + 16);
-        xdv[b] = xdd[blk];
-        const int one = 0x01010101;
-        int s = dot4(xa[b].x, one, 0); s = dot4(xa[b].y, one, s); s = dot4(xa[b].z, one, s); s = dot4(xa[b].w, one, s);
-        s = dot4(xb[b].x, one, s); s = dot4(xb[b].y, one, s); s = dot4(xb[b].z, one, s); s = dot4(xb[b].w, one, s);
-        xs8[b] = 8 * s;
-    }
+    Q40Act<BPL> A;
+    q40_load_act<BPL, 16>(A, xq, xdd, nullptr, sub);
+    float *ts = reinterpret_cast<float *>(smem + (((size_t)K * 5 + (size_t)K / 32 * 4 + 15) & ~(size_t)15)) + wid * q40_tab_floats(nblk), *td = ts + 8 * nblk * 8;
     float best = -INFINITY;
     int besti = 0x7fffffff;
     for (int base = row0; base < row1; base += 8) {
@@ -678,28 +492,18 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__
                 }
             }
         }
+        wave_lds_fence();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int b = 0; b < BPL; ++b) {
-                int i = dot4((int)(q[u][b].x & 0x0f0f0f0fu), xa[b].x, 0);
-                i = dot4((int)(q[u][b].y & 0x0f0f0f0fu), xa[b].y, i);
-                i = dot4((int)(q[u][b].z & 0x0f0f0f0fu), xa[b].z, i);
-                i = dot4((int)(q[u][b].w & 0x0f0f0f0fu), xa[b].w, i);
-                i = dot4((int)((q[u][b].x >> 4) & 0x0f0f0f0fu), xb[b].x, i);
-                i = dot4((int)((q[u][b].y >> 4) & 0x0f0f0f0fu), xb[b].y, i);
-                i = dot4((int)((q[u][b].z >> 4) & 0x0f0f0f0fu), xb[b].z, i);
-                i = dot4((int)((q[u][b].w >> 4) & 0x0f0f0f0fu), xb[b].w, i);
-                i -= xs8[b];
-                acc = __fmaf_rn(h2f(dw[u][b]) * xdv[b], (float)i, acc);
-            }
-            acc = group16_sum(acc);
-            const int rw = base + 4 * u + rsel;
-            if (rw < row1) {
-                if (sub == 0) logits[rw] = acc;
-                if (acc > best) { best = acc; besti = rw; }   // rows visited in increasing order per lane group
-            }
+            const int rl = 4 * u + rsel;
+            q40_emit<BPL, 16>(q[u], dw[u], A, sub, ts + (size_t)rl * nblk * 8, td + (size_t)rl * nblk);
+        }
+        wave_lds_fence();
+        const float acc = q40_chain(ts, td, nblk, min(8, row1 - base), lane);
+        const int rw = base + (lane >> 3);
+        if (rw < row1) {
+            if ((lane & 7) == 0) logits[rw] = acc;
+            if (acc > best) { best = acc; besti = rw; }   // rows visited in increasing order per lane group
         }
     }
     // workgroup argmax with first-index tie break
@@ -779,14 +583,20 @@ using namespace mllm_hip;
 
 namespace mllm_hip {
 
-static int g_dbg = getenv("MLLM_HIP_DBG") ? atoi(getenv("MLLM_HIP_DBG")) : 0;
-
+template <typename KernelT>
+static int allow_lds(KernelT kern, size_t lds) {
+    if (lds > 160 * 1024) return MLLM_HIP_ERR_SHAPE;
+    if (lds > 48 * 1024) MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return MLLM_HIP_OK;
+}
 template <int NS>
 static int launch_qkv(const DecodeLayer &L, const DecodeCtx &c, bool embed, const float *x, float *x_out, hipStream_t st) {
     constexpr int ROWS = NS == 1 ? 2 : 1, WPB = 4;
     const int waves = (L.qkv_N + ROWS - 1) / ROWS;
-    const size_t lds = act_lds_bytes(c.H, false);
+    const size_t lds = fused_lds_bytes<NS, ROWS>(c.H, false, WPB);
     constexpr int NV = (NS * 8 + WPB - 1) / WPB;   // quant blocks per wave
+    int rc = embed ? allow_lds(dec_qkv_kernel<NS, ROWS, true, NV, WPB>, lds) : allow_lds(dec_qkv_kernel<NS, ROWS, false, NV, WPB>, lds);
+    if (rc) return rc;
     if (embed)
         hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, true, NV, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, L.in_norm,
                            c.eps, L.Wqkv, L.bqkv, c.qkv, L.qkv_N, c.H);
@@ -799,17 +609,22 @@ template <int NS>
 static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *x, hipStream_t st) {
     constexpr int PAIRS = NS == 1 ? 2 : 1, WPB = 8;
     const int waves = (c.I + PAIRS - 1) / PAIRS;
-    hipLaunchKernelGGL((dec_gateup_kernel<NS, PAIRS, (NS * 8 + WPB - 1) / WPB, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), act_lds_bytes(c.H, false), st, x, L.post_norm, c.eps, L.Wgu, c.act, c.I, c.H);
+    const size_t lds = fused_lds_bytes<NS, 2 * PAIRS>(c.H, false, WPB);
+    auto kern = dec_gateup_kernel<NS, PAIRS, (NS * 8 + WPB - 1) / WPB, WPB>;
+    int rc = allow_lds(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, x, L.post_norm, c.eps, L.Wgu, c.act, c.I, c.H);
     return MH_LAUNCH_OK("dec_gateup");
 }
-template <int NS, bool MERGE>
-static int launch_proj(const uint8_t *W, const float *xin, const DecodeCtx &c, const float *residual, float *y, int N, int K, hipStream_t st) {
+template <int NS>
+static int launch_proj(const uint8_t *W, const float *xin, const float *residual, float *y, int N, int K, hipStream_t st) {
     constexpr int ROWS = NS == 1 ? 2 : 1, WPB = NS >= 3 ? 16 : 4;   // long rows: 1024-thread workgroups share the row quantisation
     const int waves = (N + ROWS - 1) / ROWS;
-    const size_t lds = act_lds_bytes(K, MERGE) + (MERGE ? (size_t)(3 * c.heads * c.nsplit + c.heads) * 4 : 0);
-    if (MERGE && (c.nsplit > 16 || c.heads * c.nsplit > 64 * WPB)) return MLLM_HIP_ERR_SHAPE;   // cache_limit <= 1024 in the fused decode path
-    hipLaunchKernelGGL((dec_proj_kernel<NS, ROWS, MERGE, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, xin, c.fa_ws, c.heads, c.D, c.nsplit, W,
-                       residual, y, N, K, g_dbg);
+    const size_t lds = fused_lds_bytes<NS, ROWS>(K, false, WPB);
+    auto kern = dec_proj_kernel<NS, ROWS, WPB>;
+    int rc = allow_lds(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, xin, W, residual, y, N, K);
     return MH_LAUNCH_OK("dec_proj");
 }
 
@@ -827,7 +642,6 @@ static int launch_proj(const uint8_t *W, const float *xin, const DecodeCtx &c, c
 // one fused kernel of layer `li`: 0 qkv, 1 attn, 2 o-proj, 3 gate|up, 4 down. x = layer input / output, t = post-attention residual
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st) {
     if (c.D != 128 || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
-    const int group = c.heads / c.kv_heads;
     float *x = c.x0, *t = c.x1;
     const DecodeLayer &L = layers[li];
     int rc = 0;
@@ -837,19 +651,21 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         return rc;
     case 1: {
         uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.cache_limit * c.kv_heads * c.D;
-        hipLaunchKernelGGL((dec_attn_kernel<128>), dim3(c.heads, c.nsplit), dim3(256), 0, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads,
-                           c.kv_heads, c.nsplit);
-        (void)group;
+        const size_t lds = dec_attn_lds(c.cache_limit, c.D);
+        rc = allow_lds(dec_attn_kernel<128>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((dec_attn_kernel<128>), dim3(c.heads), dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads,
+                           c.kv_heads, c.cache_limit);
         return MH_LAUNCH_OK("dec_attn");
     }
     case 2:
-        NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS, true>(L.Wo, nullptr, c, x, t, c.H, c.heads * c.D, st)));
+        NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS>(L.Wo, c.fa_ws, x, t, c.H, c.heads * c.D, st)));
         return rc;
     case 3:
         NS_DISPATCH(c.H, rc = launch_gateup<NS>(L, c, t, st));
         return rc;
     case 4:
-        NS_DISPATCH(c.I, rc = (launch_proj<NS, false>(L.Wdown, c.act, c, t, x, c.H, c.I, st)));
+        NS_DISPATCH(c.I, rc = (launch_proj<NS>(L.Wdown, c.act, t, x, c.H, c.I, st)));
         return rc;
     }
     return MLLM_HIP_ERR_ARG;
@@ -879,8 +695,8 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
     rpw = ((rpw + 7) / 8) * 8;
     const int waves = (c.vocab + rpw - 1) / rpw, blocks = (waves + 3) / 4;
     if (blocks > c.max_parts) return MLLM_HIP_ERR_SHAPE;
-    const size_t lds = (size_t)c.H * 5 + (size_t)c.H / 32 * 4 + 64;
-#define HEAD_CASE(B) case B: hipLaunchKernelGGL((dec_head_kernel<B>), dim3(blocks), dim3(256), lds, st, x, c.final_norm, 1e-6f, c.emb_qs, c.emb_d, c.logits, c.part_val, c.part_idx, c.vocab, c.H, rpw); break;
+    const size_t lds = (((size_t)c.H * 5 + (size_t)c.H / 32 * 4 + 15) & ~(size_t)15) + 4 * q40_tab_floats(c.H / 32) * sizeof(float);
+#define HEAD_CASE(B) case B: rc = allow_lds(dec_head_kernel<B>, lds); if (rc) return rc; hipLaunchKernelGGL((dec_head_kernel<B>), dim3(blocks), dim3(256), lds, st, x, c.final_norm, 1e-6f, c.emb_qs, c.emb_d, c.logits, c.part_val, c.part_idx, c.vocab, c.H, rpw); break;
     switch (c.H / 512) { HEAD_CASE(1) HEAD_CASE(2) HEAD_CASE(3) HEAD_CASE(4) HEAD_CASE(5) HEAD_CASE(6) HEAD_CASE(7) HEAD_CASE(8) }
 #undef HEAD_CASE
     rc = MH_LAUNCH_OK("dec_head");

@@ -71,13 +71,87 @@ __global__ __launch_bounds__(256) void quantize_q80_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// A18 LayerNorm statistics in the reference's order (op/CPULayerNorm.cpp:49-88): sum += x[d] and ssq = fma(c, c, ssq) are
+// sequential fp32 chains over the row (GCC cannot reassociate them; it does contract the second into an fma), so a row is
+// one lane's work.  A workgroup takes LN_ROWS rows: all 256 threads stream the rows through LDS in coalesced chunks (double
+// buffered), lanes 0..LN_ROWS-1 of wave 0 walk their row with ds_read_b128.  stats[row] = (mean, sqrtf(ssq/dim + eps)).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int LN_ROWS = 16, LN_CH = 256, LN_PITCH = LN_CH + 4;
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float *__restrict__ x, float *__restrict__ stats, int M, int dim, float eps) {
+    __shared__ __attribute__((aligned(16))) float buf[2][LN_ROWS * LN_PITCH];
+    __shared__ float mean_s[LN_ROWS];
+    const int tid = threadIdx.x, row0 = blockIdx.x * LN_ROWS;
+    const int nch = (dim + LN_CH - 1) / LN_CH;
+    float mean = 0.0f;
+    for (int pass = 0; pass < 2; ++pass) {
+        float acc = 0.0f;
+        float4 stage[4];
+        auto fetch = [&](int c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i, r = idx >> 6, c4 = idx & 63;
+                const int col = c * LN_CH + 4 * c4, row = min(row0 + r, M - 1);
+                const float *p = x + (int64_t)row * dim + col;
+                float4 v = make_float4(0, 0, 0, 0);
+                if (col + 3 < dim) v = *reinterpret_cast<const float4 *>(p);
+                else { if (col < dim) v.x = p[0]; if (col + 1 < dim) v.y = p[1]; if (col + 2 < dim) v.z = p[2]; }
+                stage[i] = v;
+            }
+        };
+        auto park = [&](int b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i, r = idx >> 6, c4 = idx & 63;
+                *reinterpret_cast<float4 *>(&buf[b][r * LN_PITCH + 4 * c4]) = stage[i];
+            }
+        };
+        fetch(0);
+        park(0);
+        __syncthreads();
+        for (int c = 0; c < nch; ++c) {
+            if (c + 1 < nch) fetch(c + 1);
+            if (tid < LN_ROWS) {
+                const float *rowp = &buf[c & 1][tid * LN_PITCH];
+                const int n = min(LN_CH, dim - c * LN_CH);
+                int k = 0;
+                if (pass == 0) {
+                    for (; k + 4 <= n; k += 4) {
+                        const float4 v = *reinterpret_cast<const float4 *>(rowp + k);
+                        acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
+                    }
+                    for (; k < n; ++k) acc = acc + rowp[k];
+                } else {
+                    for (; k + 4 <= n; k += 4) {
+                        const float4 v = *reinterpret_cast<const float4 *>(rowp + k);
+                        const float c0 = v.x - mean, c1 = v.y - mean, c2 = v.z - mean, c3 = v.w - mean;
+                        acc = __fmaf_rn(c0, c0, acc); acc = __fmaf_rn(c1, c1, acc); acc = __fmaf_rn(c2, c2, acc); acc = __fmaf_rn(c3, c3, acc);
+                    }
+                    for (; k < n; ++k) { const float cc = rowp[k] - mean; acc = __fmaf_rn(cc, cc, acc); }
+                }
+            }
+            if (c + 1 < nch) park((c + 1) & 1);
+            __syncthreads();
+        }
+        if (pass == 0) {
+            if (tid < LN_ROWS) mean_s[tid] = acc / (float)dim;
+            __syncthreads();
+            mean = tid < LN_ROWS ? mean_s[tid] : 0.0f;
+        } else if (tid < LN_ROWS && row0 + tid < M) {
+            stats[2 * (row0 + tid)] = mean;
+            stats[2 * (row0 + tid) + 1] = sqrtf(acc / (float)dim + eps);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // A9 RMSNorm (op/CPURMSNorm.cpp:31-136) / A18 LayerNorm (op/CPULayerNorm.cpp:49-88), one 256-thread workgroup per row.
 // Optional fused A4: the normalised row is quantised to q8k planes in the same pass (wave w owns blocks w, w+4, ...).
 // ------------------------------------------------------------------------------------------------------------------
 template <bool LAYERNORM>
 __global__ __launch_bounds__(256) void norm_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
                                                    float *__restrict__ y, int8_t *__restrict__ qs, float *__restrict__ qd,
-                                                   int16_t *__restrict__ bsums, int dim, float eps, int add_unit_offset) {
+                                                   int16_t *__restrict__ bsums, int dim, float eps, int add_unit_offset,
+                                                   const float *__restrict__ stats) {
     __shared__ double red[8];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float *xr = x + (int64_t)row * dim;
@@ -90,21 +164,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const float *__restrict__ x, 
         __syncthreads();
         ss = red[0] + red[1] + red[2] + red[3];
         const float m = (float)(ss / (double)dim);
-        inv = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(m, eps)));
+        inv = __fdiv_rn(1.0f, sqrtf(__fadd_rn(m, eps)));
     } else {
-        double s = 0.0;
-        for (int d = tid; d < dim; d += 256) s += (double)xr[d];
-        s = wave_sum_d(s);
-        if (lane == 0) red[wid] = s;
-        __syncthreads();
-        mean = __fdiv_rn((float)(red[0] + red[1] + red[2] + red[3]), (float)dim);
-        double ss = 0.0;
-        for (int d = tid; d < dim; d += 256) { const float c = __fsub_rn(xr[d], mean); ss += (double)__fmul_rn(c, c); }
-        ss = wave_sum_d(ss);
-        if (lane == 0) red[4 + wid] = ss;
-        __syncthreads();
-        const float var = __fdiv_rn((float)(red[4] + red[5] + red[6] + red[7]), (float)dim);
-        inv = __fsqrt_rn(__fadd_rn(var, eps));  // "rms" of the reference: the divisor
+        mean = stats[2 * row];
+        inv = stats[2 * row + 1];   // "rms" of the reference: the divisor
     }
     const bool quant = qs != nullptr;
     if (quant || (dim & 255) == 0) {
@@ -355,7 +418,8 @@ extern "C" int mllm_hip_rmsnorm(const float *x, const float *w, float *y, int8_t
     if (M <= 0) return MLLM_HIP_OK;
     if (qs && (dim % 256 != 0 || !d || !bsums)) return MLLM_HIP_ERR_SHAPE;
     if (!qs && !y) return MLLM_HIP_ERR_ARG;
-    hipLaunchKernelGGL(norm_kernel<false>, dim3(M), dim3(256), 0, as_stream(stream), x, w, (const float *)nullptr, y, qs, d, bsums, dim, eps, add_unit_offset);
+    hipLaunchKernelGGL(norm_kernel<false>, dim3(M), dim3(256), 0, as_stream(stream), x, w, (const float *)nullptr, y, qs, d, bsums, dim, eps, add_unit_offset,
+                       (const float *)nullptr);
     return MH_LAUNCH_OK("rmsnorm");
 }
 extern "C" int mllm_hip_layernorm(const float *x, const float *w, const float *b, float *y, int8_t *qs, float *d, int16_t *bsums,
@@ -363,8 +427,23 @@ extern "C" int mllm_hip_layernorm(const float *x, const float *w, const float *b
     if (M <= 0) return MLLM_HIP_OK;
     if (qs && (dim % 256 != 0 || !d || !bsums)) return MLLM_HIP_ERR_SHAPE;
     if (!qs && !y) return MLLM_HIP_ERR_ARG;
-    hipLaunchKernelGGL(norm_kernel<true>, dim3(M), dim3(256), 0, as_stream(stream), x, w, b, y, qs, d, bsums, dim, eps, 0);
+    // per-row (mean, rms) scratch: grown on demand, owned by the library (stream-ordered use only)
+    static float *stats = nullptr;
+    static int stats_rows = 0;
+    if (M > stats_rows) {
+        if (stats) MH_CHECK(hipFree(stats));
+        stats_rows = ((M + 1023) / 1024) * 1024;
+        MH_CHECK(hipMalloc(&stats, (size_t)stats_rows * 2 * sizeof(float)));
+    }
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((M + LN_ROWS - 1) / LN_ROWS), dim3(256), 0, as_stream(stream), x, stats, M, dim, eps);
+    int rc = MH_LAUNCH_OK("ln_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(norm_kernel<true>, dim3(M), dim3(256), 0, as_stream(stream), x, w, b, y, qs, d, bsums, dim, eps, 0, (const float *)stats);
     return MH_LAUNCH_OK("layernorm");
+}
+extern "C" int mllm_hip_debug_ln_stats(const float *x, float *stats, int M, int dim, float eps, void *stream) {
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((M + LN_ROWS - 1) / LN_ROWS), dim3(256), 0, as_stream(stream), x, stats, M, dim, eps);
+    return MH_LAUNCH_OK("ln_stats");
 }
 extern "C" int mllm_hip_silu(const float *x, float *y, int64_t n, void *stream) {
     if (n <= 0) return MLLM_HIP_OK;

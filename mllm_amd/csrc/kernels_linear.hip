@@ -10,6 +10,8 @@
 //     is the broadcast 6-bit min (sum_e q8[e]*min_{sb(e)} == sum_j bsums[j]*min_{j/2}, VecDotQ4.cpp:318).
 //   fp32 weights (patch-embed conv, fp32 models): f32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 fma chain).
 #include "common.h"
+#include "q4k_dot.h"
+#include "q40_dot.h"
 
 namespace mllm_hip {
 
@@ -18,52 +20,20 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------------------------
-// Q4_K x Q8_K GEMV (M == 1)
+// Q4_K x Q8_K GEMV (M == 1): q4k_dot.h holds the arithmetic (reference accumulation order, bit-exact)
 // ------------------------------------------------------------------------------------------------------------------
-struct Q4KPart { int i1, i2; };
-
-__device__ __forceinline__ void q4k_lane_dot(const uint4 hdr, const uint4 q, const int4 xa, const int4 xb, const int q8s, const int r,
-                                             int &i1, int &i2, float &d, float &dmin) {
-    d = h2f((uint16_t)(hdr.x & 0xffff));
-    dmin = h2f((uint16_t)(hdr.x >> 16));
-    uint32_t sc8[2], mn8[2];
-    unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
-    const int j = r >> 1;
-    const int sc_lo = byte_of(sc8, 2 * j), sc_hi = byte_of(sc8, 2 * j + 1), mr = byte_of(mn8, r);
-    int dl = dot4((int)(q.x & 0x0f0f0f0fu), xa.x, 0);
-    dl = dot4((int)(q.y & 0x0f0f0f0fu), xa.y, dl);
-    dl = dot4((int)(q.z & 0x0f0f0f0fu), xa.z, dl);
-    dl = dot4((int)(q.w & 0x0f0f0f0fu), xa.w, dl);
-    int dh = dot4((int)((q.x >> 4) & 0x0f0f0f0fu), xb.x, 0);
-    dh = dot4((int)((q.y >> 4) & 0x0f0f0f0fu), xb.y, dh);
-    dh = dot4((int)((q.z >> 4) & 0x0f0f0f0fu), xb.z, dh);
-    dh = dot4((int)((q.w >> 4) & 0x0f0f0f0fu), xb.w, dh);
-    i1 = sc_lo * dl + sc_hi * dh;
-    i2 = mr * q8s;
-}
-
 // NSTEPS = ceil(K/2048): wave steps per row. ROWS = rows in flight per wave (memory-level parallelism).
 template <int NSTEPS, int ROWS>
 __global__ __launch_bounds__(256) void gemv_q4k_kernel(const uint8_t *__restrict__ W, const float *__restrict__ bias, const int8_t *__restrict__ xqs,
                                                        const float *__restrict__ xd, const int16_t *__restrict__ xbsums, void *__restrict__ y, int y_f16,
                                                        const float *__restrict__ residual, int N, int nb, int rows_per_wave) {
-    const int lane = threadIdx.x & 63, g = lane >> 3, r = lane & 7;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int j = r >> 1, tp = r & 1;
-    int4 xa[NSTEPS], xb[NSTEPS];
-    float xdv[NSTEPS];
-    int q8s[NSTEPS];
-    bool valid[NSTEPS];
-#pragma unroll
-    for (int st = 0; st < NSTEPS; ++st) {
-        const int blk = st * 8 + g;
-        valid[st] = blk < nb;
-        const int b = valid[st] ? blk : 0;
-        xa[st] = *reinterpret_cast<const int4 *>(xqs + b * 256 + 64 * j + 16 * tp);
-        xb[st] = *reinterpret_cast<const int4 *>(xqs + b * 256 + 64 * j + 32 + 16 * tp);
-        xdv[st] = valid[st] ? xd[b] : 0.0f;
-        q8s[st] = (int)xbsums[b * 16 + 2 * r] + (int)xbsums[b * 16 + 2 * r + 1];
-    }
+    __shared__ float2 tab_all[4 * (ROWS < 4 ? ROWS : 4) * NSTEPS * 8 * Q4K_SLOTS];
+    const int lane = threadIdx.x & 63, g = lane >> 3, wid = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wid;
+    float2 *tab = tab_all + wid * (ROWS < 4 ? ROWS : 4) * NSTEPS * 8 * Q4K_SLOTS;
+    Q4KAct<NSTEPS> A;
+    q4k_load_act_planes<NSTEPS>(A, xqs, xd, xbsums, nb, lane);
+    const int qoff = q4k_lane_qoff(lane);
     const int row0 = wave * rows_per_wave;
     const int row1 = min(N, row0 + rows_per_wave);
     for (int row = row0; row < row1; row += ROWS) {
@@ -73,35 +43,27 @@ __global__ __launch_bounds__(256) void gemv_q4k_kernel(const uint8_t *__restrict
             const int rw = min(row + rr, row1 - 1);
 #pragma unroll
             for (int st = 0; st < NSTEPS; ++st) {
-                const int blk = valid[st] ? st * 8 + g : 0;
+                const int blk = A.valid[st] ? st * 8 + g : 0;
                 const uint8_t *wb = W + ((int64_t)rw * nb + blk) * 144;
                 hdr[rr][st] = *reinterpret_cast<const uint4 *>(wb);
-                q[rr][st] = *reinterpret_cast<const uint4 *>(wb + 16 + 16 * r);
+                q[rr][st] = *reinterpret_cast<const uint4 *>(wb + 16 + qoff);
             }
         }
+        float out[ROWS];
+        wave_lds_fence();   // the previous iteration's chain reads are done before the table is overwritten
+        q4k_dot_rows<NSTEPS, ROWS>(hdr, q, A, nb, lane, tab, out);
+        if (lane == 0) {
 #pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int st = 0; st < NSTEPS; ++st) {
-                int i1, i2;
-                float d, dmin;
-                q4k_lane_dot(hdr[rr][st], q[rr][st], xa[st], xb[st], q8s[st], r, i1, i2, d, dmin);
-                i1 = group8_sum(i1);
-                i2 = group8_sum(i2);
-                // d = y.d * fp16(x.d) ; dmin = y.d * fp16(x.dmin)  (VecDotQ4.cpp:228-229)
-                const float p = __fmaf_rn(__fmul_rn(xdv[st], d), (float)i1, -__fmul_rn(__fmul_rn(xdv[st], dmin), (float)i2));
-                acc += valid[st] ? p : 0.0f;
-            }
-            acc = groups_total_lane63(acc);
-            const int rw = row + rr;
-            if (lane == 63 && rw < row1) {
-                float v = acc;
-                if (bias) v = __fadd_rn(v, bias[rw]);
-                if (y_f16) reinterpret_cast<uint16_t *>(y)[rw] = f2h(v);
-                else {
-                    if (residual) v = __fadd_rn(v, residual[rw]);
-                    reinterpret_cast<float *>(y)[rw] = v;
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int rw = row + rr;
+                if (rw < row1) {
+                    float v = out[rr];
+                    if (bias) v = v + bias[rw];
+                    if (y_f16) reinterpret_cast<uint16_t *>(y)[rw] = f2h(v);
+                    else {
+                        if (residual) v = v + residual[rw];
+                        reinterpret_cast<float *>(y)[rw] = v;
+                    }
                 }
             }
         }
@@ -110,36 +72,30 @@ __global__ __launch_bounds__(256) void gemv_q4k_kernel(const uint8_t *__restrict
 
 // ------------------------------------------------------------------------------------------------------------------
 // Q4_0 (nibble/scale planes) x Q8_0 GEMV (M == 1): the tied lm_head (modeling_qwen2_vl.hpp:399 -> CPUmmFunction ->
-// vec_dot_q4_0_q8_0, VecDotQ4.cpp:514-545). LPR lanes per row, BPL blocks per lane (K = 32*LPR*BPL), 64/LPR rows per wave pass.
+// vec_dot_q4_0_q8_0, VecDotQ4.cpp:514-545): per 32-block, acc[t] = fma(fp16(x.d) * fp16(y.d), float(s_t), acc[t]) with
+// s_t the dot of bytes 4t..4t+3 of (nibbles - 8) (low nibbles = bytes 0..15, high = 16..31), blocks in order, then
+// hsum_float_8.  LPR lanes per row, BPL blocks per lane (K = 32*LPR*BPL): every lane forms the 8 class sums of its blocks,
+// parks them in a per-wave LDS table [row][block][8] and 8 lanes per row walk the table in block order (q40_chain).
 // ------------------------------------------------------------------------------------------------------------------
 template <int BPL, int LPR>
 __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict__ Wqs, const uint16_t *__restrict__ Wd, const float *__restrict__ bias,
                                                        const int8_t *__restrict__ xqs, const uint16_t *__restrict__ xd, float *__restrict__ y, int N,
                                                        int rows_per_wave) {
-    constexpr int RPW = 64 / LPR;  // rows per wave pass
-    const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nblk = BPL * LPR;
-    int4 xa[BPL], xb[BPL];
-    float xdv[BPL];
-    int xs8[BPL];
-#pragma unroll
-    for (int b = 0; b < BPL; ++b) {
-        const int blk = sub + LPR * b;
-        xa[b] = *reinterpret_cast<const int4 *>(xqs + blk * 32);
-        xb[b] = *reinterpret_cast<const int4 *>(xqs + blk * 32 + 16);
-        xdv[b] = h2f(xd[blk]);
-        const int one = 0x01010101;
-        int s = dot4(xa[b].x, one, 0); s = dot4(xa[b].y, one, s); s = dot4(xa[b].z, one, s); s = dot4(xa[b].w, one, s);
-        s = dot4(xb[b].x, one, s); s = dot4(xb[b].y, one, s); s = dot4(xb[b].z, one, s); s = dot4(xb[b].w, one, s);
-        xs8[b] = 8 * s;
-    }
+    extern __shared__ __attribute__((aligned(16))) char q40_smem[];
+    constexpr int RPW = 64 / LPR;            // rows per load pass
+    constexpr int NPASS = 8 / RPW;           // load passes per 8-row chain pass
+    constexpr int nblk = BPL * LPR;
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, wid = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wid;
+    float *ts = reinterpret_cast<float *>(q40_smem) + wid * q40_tab_floats(nblk), *td = ts + 8 * nblk * 8;
+    Q40Act<BPL> A;
+    q40_load_act<BPL, LPR>(A, xqs, nullptr, xd, sub);
     const int row0 = wave * rows_per_wave, row1 = min(N, row0 + rows_per_wave);
-    for (int base = row0; base < row1; base += 2 * RPW) {
-        uint4 q[2][BPL];
-        uint16_t dw[2][BPL];
+    for (int base = row0; base < row1; base += 8) {
+        uint4 q[NPASS][BPL];
+        uint16_t dw[NPASS][BPL];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NPASS; ++u) {
             const int rw = min(base + RPW * u + rsel, row1 - 1);
 #pragma unroll
             for (int b = 0; b < BPL; ++b) {
@@ -148,158 +104,267 @@ __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict
                 dw[u][b] = Wd[bi];
             }
         }
+        wave_lds_fence();
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int b = 0; b < BPL; ++b) {
-                int i = dot4((int)(q[u][b].x & 0x0f0f0f0fu), xa[b].x, 0);
-                i = dot4((int)(q[u][b].y & 0x0f0f0f0fu), xa[b].y, i);
-                i = dot4((int)(q[u][b].z & 0x0f0f0f0fu), xa[b].z, i);
-                i = dot4((int)(q[u][b].w & 0x0f0f0f0fu), xa[b].w, i);
-                i = dot4((int)((q[u][b].x >> 4) & 0x0f0f0f0fu), xb[b].x, i);
-                i = dot4((int)((q[u][b].y >> 4) & 0x0f0f0f0fu), xb[b].y, i);
-                i = dot4((int)((q[u][b].z >> 4) & 0x0f0f0f0fu), xb[b].z, i);
-                i = dot4((int)((q[u][b].w >> 4) & 0x0f0f0f0fu), xb[b].w, i);
-                i -= xs8[b];  // (nib - 8) * q8 summed
-                acc = __fmaf_rn(__fmul_rn(h2f(dw[u][b]), xdv[b]), (float)i, acc);
-            }
-            acc = LPR == 16 ? group16_sum(acc) : group8_sum(acc);
-            const int rw = base + RPW * u + rsel;
-            if (sub == 0 && rw < row1) y[rw] = bias ? __fadd_rn(acc, bias[rw]) : acc;
+        for (int u = 0; u < NPASS; ++u) {
+            const int rl = RPW * u + rsel;
+            q40_emit<BPL, LPR>(q[u], dw[u], A, sub, ts + (size_t)rl * nblk * 8, td + (size_t)rl * nblk);
         }
+        wave_lds_fence();
+        const float acc = q40_chain(ts, td, nblk, min(8, row1 - base), lane);
+        const int rw = base + (lane >> 3);
+        if ((lane & 7) == 0 && rw < row1) y[rw] = bias ? acc + bias[rw] : acc;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Q4_K x Q8_K GEMM (M >= 16) on int8 MFMA. Workgroup = 4 waves (2 along M x 2 along N); wave tile = 32 (M) x 64 (N).
-// v_mfma_i32_32x32x32_i8 operand maps: lane l (row/col = l&31, h = l>>5) holds k = 16h .. 16h+15 of its A row / B column
-// (16 int8 = 4 VGPRs); C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*h.
-// A row m = activation row (q8 plane), B column n = weight row: one MFMA covers one 32-wide Q4_K sub-block.
+// Q4_K x Q8_K GEMM (M >= 16) in the reference's accumulation order, on v_mfma_f32_32x32x16_f16.
+//
+// Per (activation row m, weight row n) the reference keeps 8 + 4 fp32 chains over the super-blocks (q4k_dot.h).  The
+// integer partial sums that feed a chain step are exact in fp32 whatever order they are added in, so they are formed on
+// the matrix cores: for column class t of super-block i,  sumi[t] = sum_{sb < 8} sc[sb] * dot4(q4[sb][4t..], q8[sb][4t..])
+// is a K = 32 dot product of (q4 * sc) (<= 945, exact in fp16) with q8 (exact in fp16) = two 32x32x16 MFMAs with a zero C;
+// the mins product prod[u] = mn[2u] q8s[2u] + mn[2u+1] q8s[2u+1] is one more MFMA per u with q8s split into an even part
+// (|.| <= 4064, even: exact in fp16) and its low bit.  The fp32 chain step acc = fma(d_m d_n, sum, acc) then runs on the
+// VALU over the 16 accumulator registers, once per class / mins lane.
+// Operands are pre-swizzled so every MFMA operand is one coalesced 16-byte (8-byte for mins) load per lane:
+//   weights  q4k_prepack: Bw[n/32][i][t][p][h][n%32][8 f16]  (k = 4 low nibbles * sc[2j], 4 high nibbles * sc[2j+1], j = 2p+h)
+//                         Bm[n/32][i][u][n%32][4 f16] = (mn[2u], mn[2u], mn[2u+1], mn[2u+1]);  Bd[n/32][i][n%32] = (d, dmin)
+//   acts     q8k_prepack: Ax[m/32][i][t][p][h][m%32][8 f16]  (q8[64j+4t+b], q8[64j+32+4t+b]);
+//                         Am[m/32][i][u][m%32][4 f16] = (even(q8s[2u]), q8s[2u]&1, even(q8s[2u+1]), q8s[2u+1]&1);  Ad[m/32][i][m%32] = y.d
+// A = activations (C rows = m), B = weights (C cols = n).  Lane l: col = l & 31, h = l >> 5, C reg r -> row (r&3) + 8 (r>>2) + 4h.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_q4k_kernel(const uint8_t *__restrict__ W, const float *__restrict__ bias, const int8_t *__restrict__ xqs,
-                                                       const float *__restrict__ xd, void *__restrict__ y, int y_f16, int64_t ldy,
-                                                       const float *__restrict__ residual, int M, int N, int K) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int col = lane & 31, h = lane >> 5;
-    const int nb = K >> 8;
-    const int m0 = blockIdx.y * 64 + (wid >> 1) * 32;
-    const int n0 = blockIdx.x * 128 + (wid & 1) * 64;
-    if (m0 >= M) return;
-    const int am = min(m0 + col, M - 1);                       // A row of this lane (clamped: rows >= M are never stored)
-    const int8_t *arow = xqs + (int64_t)am * K + 16 * h;
-    const uint8_t *wrow[2];
-    bool nvalid[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + nt * 32 + col;
-        nvalid[nt] = n < N;
-        wrow[nt] = W + (int64_t)min(n, N - 1) * nb * 144;
-    }
-    v16f facc[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) facc[nt][i] = 0.0f;
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 
-    for (int blk = 0; blk < nb; ++blk) {
-        v4i a[8];
-#pragma unroll
-        for (int sb = 0; sb < 8; ++sb) a[sb] = *reinterpret_cast<const v4i *>(arow + blk * 256 + sb * 32);
-        float dxr[16];  // y.d of the 16 rows this lane's accumulators belong to
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rm = min(m0 + (i & 3) + 8 * (i >> 2) + 4 * h, M - 1);
-            dxr[i] = xd[(int64_t)rm * nb + blk];
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const uint8_t *wb = wrow[nt] + (int64_t)blk * 144;
-            const uint4 hdr = *reinterpret_cast<const uint4 *>(wb);
-            const float dw = h2f((uint16_t)(hdr.x & 0xffff)), dmw = h2f((uint16_t)(hdr.x >> 16));
-            uint32_t sc8[2], mn8[2];
-            unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
-            v16i acc1, acc2;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { acc1[i] = 0; acc2[i] = 0; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint4 q = *reinterpret_cast<const uint4 *>(wb + 16 + 32 * j + 16 * h);
-                v4i blo, bhi;
-                blo[0] = (int)(q.x & 0x0f0f0f0fu); blo[1] = (int)(q.y & 0x0f0f0f0fu); blo[2] = (int)(q.z & 0x0f0f0f0fu); blo[3] = (int)(q.w & 0x0f0f0f0fu);
-                bhi[0] = (int)((q.x >> 4) & 0x0f0f0f0fu); bhi[1] = (int)((q.y >> 4) & 0x0f0f0f0fu);
-                bhi[2] = (int)((q.z >> 4) & 0x0f0f0f0fu); bhi[3] = (int)((q.w >> 4) & 0x0f0f0f0fu);
-                v16i zero;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) zero[i] = 0;
-                const int s0 = byte_of(sc8, 2 * j), s1 = byte_of(sc8, 2 * j + 1);
-                const int mb0 = byte_of(mn8, 2 * j) * 0x01010101, mb1 = byte_of(mn8, 2 * j + 1) * 0x01010101;
-                v4i bm0 = {mb0, mb0, mb0, mb0}, bm1 = {mb1, mb1, mb1, mb1};
-                const v16i p0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[2 * j], blo, zero, 0, 0, 0);
-                const v16i p1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[2 * j + 1], bhi, zero, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[2 * j], bm0, acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[2 * j + 1], bm1, acc2, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc1[i] += s0 * p0[i] + s1 * p1[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = __fmaf_rn(__fmul_rn(dxr[i], dw), (float)acc1[i], -__fmul_rn(__fmul_rn(dxr[i], dmw), (float)acc2[i]));
-                facc[nt][i] += p;
-            }
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + nt * 32 + col;
-        if (!nvalid[nt]) continue;
-        const float bv = bias ? bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (m >= M) continue;
-            float v = facc[nt][i];
-            if (bias) v = __fadd_rn(v, bv);
-            if (y_f16) reinterpret_cast<uint16_t *>(y)[(int64_t)m * ldy + n] = f2h(v);
-            else {
-                if (residual) v = __fadd_rn(v, residual[(int64_t)m * ldy + n]);
-                reinterpret_cast<float *>(y)[(int64_t)m * ldy + n] = v;
-            }
-        }
-    }
+constexpr size_t Q4KP_W_PER_BLK = 32 * 512, Q4KP_M_PER_BLK = 32 * 4 * 8, Q4KP_D_PER_BLK = 32 * 8;   // bytes per (32-row tile, super-block)
+__host__ __device__ static inline size_t q4kp_tile_blocks(int rows, int nb) { return (size_t)((rows + 31) / 32) * nb; }
+static inline size_t q4kp_bytes(int rows, int K) {
+    const size_t tb = q4kp_tile_blocks(rows, K / 256);
+    return tb * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK + Q4KP_D_PER_BLK);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// fp32 GEMM y = x W^T (+bias) on v_mfma_f32_32x32x2_f32: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; exact fp32 fma
-// chain in k order. One wave per 32x32 tile, 4 waves (2x2) per workgroup. K % 8 == 0.
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ W, const float *__restrict__ bias, const float *__restrict__ x,
-                                                       float *__restrict__ y, int64_t ldy, int M, int N, int K) {
+// one thread per (row n, super-block i, chunk j): 4 classes x ... -> writes 8 x 16-byte fragments (t = 0..7) of (p, h) = (j >> 1, j & 1)
+__global__ __launch_bounds__(256) void q4k_prepack_kernel(const uint8_t *__restrict__ W, uint8_t *__restrict__ out, int N, int nb) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int j = (int)(gid & 3);
+    const int64_t ni = gid >> 2;
+    const int i = (int)(ni % nb);
+    const int n = (int)(ni / nb);
+    if (n >= ((N + 31) / 32) * 32) return;
+    const size_t tb = q4kp_tile_blocks(N, nb);
+    v8h *Bw = reinterpret_cast<v8h *>(out);
+    v4h *Bm = reinterpret_cast<v4h *>(out + tb * Q4KP_W_PER_BLK);
+    float2 *Bd = reinterpret_cast<float2 *>(out + tb * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK));
+    const size_t tile = (size_t)(n >> 5) * nb + i;
+    const int nin = n & 31, p = j >> 1, h = j & 1;
+    const bool live = n < N;
+    const uint8_t *wb = W + ((int64_t)(live ? n : 0) * nb + i) * 144;
+    const uint4 hdr = *reinterpret_cast<const uint4 *>(wb);
+    uint32_t sc8[2], mn8[2];
+    unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
+    const float s_lo = live ? (float)byte_of(sc8, 2 * j) : 0.0f, s_hi = live ? (float)byte_of(sc8, 2 * j + 1) : 0.0f;
+    const uint4 qa = *reinterpret_cast<const uint4 *>(wb + 16 + 32 * j), qb = *reinterpret_cast<const uint4 *>(wb + 16 + 32 * j + 16);
+    const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        v8h o;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            o[bb] = (_Float16)((float)((qw[t] >> (8 * bb)) & 0xF) * s_lo);
+            o[4 + bb] = (_Float16)((float)((qw[t] >> (8 * bb + 4)) & 0xF) * s_hi);
+        }
+        Bw[((tile * 8 + t) * 2 + p) * 64 + h * 32 + nin] = o;
+    }
+    // mins of u = j: (mn[2u], mn[2u], mn[2u+1], mn[2u+1]); scales of the block by j == 0
+    v4h mo;
+    mo[0] = mo[1] = (_Float16)(live ? (float)byte_of(mn8, 2 * j) : 0.0f);
+    mo[2] = mo[3] = (_Float16)(live ? (float)byte_of(mn8, 2 * j + 1) : 0.0f);
+    Bm[(tile * 4 + j) * 32 + nin] = mo;
+    if (j == 0) Bd[tile * 32 + nin] = live ? make_float2(h2f((uint16_t)(hdr.x & 0xffff)), h2f((uint16_t)(hdr.x >> 16))) : make_float2(0.0f, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void q8k_prepack_kernel(const int8_t *__restrict__ xqs, const float *__restrict__ xd, const int16_t *__restrict__ xbsums,
+                                                          uint8_t *__restrict__ out, int M, int nb) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int j = (int)(gid & 3);
+    const int64_t mi = gid >> 2;
+    const int i = (int)(mi % nb);
+    const int m = (int)(mi / nb);
+    if (m >= ((M + 31) / 32) * 32) return;
+    const size_t tb = q4kp_tile_blocks(M, nb);
+    v8h *Ax = reinterpret_cast<v8h *>(out);
+    v4h *Am = reinterpret_cast<v4h *>(out + tb * Q4KP_W_PER_BLK);
+    float *Ad = reinterpret_cast<float *>(out + tb * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK));
+    const size_t tile = (size_t)(m >> 5) * nb + i;
+    const int min_ = m & 31, p = j >> 1, h = j & 1;
+    const bool live = m < M;
+    const int8_t *xb = xqs + ((int64_t)(live ? m : 0) * nb + i) * 256 + 64 * j;
+    const uint4 la = *reinterpret_cast<const uint4 *>(xb), lb = *reinterpret_cast<const uint4 *>(xb + 16);
+    const uint4 ha = *reinterpret_cast<const uint4 *>(xb + 32), hb = *reinterpret_cast<const uint4 *>(xb + 48);
+    const uint32_t lo[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w}, hi[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        v8h o;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            o[bb] = (_Float16)(live ? (float)(int8_t)((lo[t] >> (8 * bb)) & 0xff) : 0.0f);
+            o[4 + bb] = (_Float16)(live ? (float)(int8_t)((hi[t] >> (8 * bb)) & 0xff) : 0.0f);
+        }
+        Ax[((tile * 8 + t) * 2 + p) * 64 + h * 32 + min_] = o;
+    }
+    const int16_t *bs = xbsums + ((int64_t)(live ? m : 0) * nb + i) * 16 + 4 * j;
+    const int q0 = live ? (int)bs[0] + (int)bs[1] : 0, q1 = live ? (int)bs[2] + (int)bs[3] : 0;
+    v4h mo;
+    mo[0] = (_Float16)(float)(q0 & ~1); mo[1] = (_Float16)(float)(q0 & 1);
+    mo[2] = (_Float16)(float)(q1 & ~1); mo[3] = (_Float16)(float)(q1 & 1);
+    Am[(tile * 4 + j) * 32 + min_] = mo;
+    if (j == 0) Ad[tile * 32 + min_] = live ? xd[(int64_t)m * nb + i] : 0.0f;
+}
+
+// one wave per 32 (m) x 32 (n) tile; 4 waves per workgroup = 2 m-tiles x 2 n-tiles
+__global__ __launch_bounds__(256) void gemm_q4k_kernel(const uint8_t *__restrict__ Wp, const uint8_t *__restrict__ Xp, const float *__restrict__ bias,
+                                                       void *__restrict__ y, int y_f16, int64_t ldy, const float *__restrict__ residual, int M, int N,
+                                                       int nb) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * 64 + (wid >> 1) * 32, n0 = blockIdx.x * 64 + (wid & 1) * 32;
-    if (m0 >= M || n0 >= N) return;
-    const float *ar = x + (int64_t)min(m0 + col, M - 1) * K;
-    const float *br = W + (int64_t)min(n0 + col, N - 1) * K;
-    v16f acc;
+    const int mt = blockIdx.y * 2 + (wid >> 1), nt = blockIdx.x * 2 + (wid & 1);
+    if (mt * 32 >= M || nt * 32 >= N) return;
+    const size_t tbw = q4kp_tile_blocks(N, nb), tbx = q4kp_tile_blocks(M, nb);
+    const v8h *Bw = reinterpret_cast<const v8h *>(Wp) + (size_t)nt * nb * 8 * 2 * 64 + lane;
+    const v4h *Bm = reinterpret_cast<const v4h *>(Wp + tbw * Q4KP_W_PER_BLK) + (size_t)nt * nb * 4 * 32 + col;
+    const float2 *Bd = reinterpret_cast<const float2 *>(Wp + tbw * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK)) + (size_t)nt * nb * 32 + col;
+    const v8h *Ax = reinterpret_cast<const v8h *>(Xp) + (size_t)mt * nb * 8 * 2 * 64 + lane;
+    const v4h *Am = reinterpret_cast<const v4h *>(Xp + tbx * Q4KP_W_PER_BLK) + (size_t)mt * nb * 4 * 32 + col;
+    const float *Ad = reinterpret_cast<const float *>(Xp + tbx * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK)) + (size_t)mt * nb * 32 + 4 * h;
+    v16f acc[8], accm[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    for (int k = 0; k < K; k += 8) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(ar + k), a1 = *reinterpret_cast<const float4 *>(ar + k + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(br + k), b1 = *reinterpret_cast<const float4 *>(br + k + 4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a0.y : a0.x, h ? b0.y : b0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a0.w : a0.z, h ? b0.w : b0.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1.y : a1.x, h ? b1.y : b1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1.w : a1.z, h ? b1.w : b1.z, acc, 0, 0, 0);
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accm[u][r] = 0.0f;
+    v16f zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+    const v8h hz = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int i = 0; i < nb; ++i) {
+        const float2 dw = Bd[(size_t)i * 32];
+        float dd[16], dm[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 dx = *reinterpret_cast<const float4 *>(Ad + (size_t)i * 32 + 8 * g4);   // rows 8 g4 + 4h + (0..3)
+            const float dxs[4] = {dx.x, dx.y, dx.z, dx.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dd[4 * g4 + e] = dxs[e] * dw.x;        // y.d * fp16(x.d)
+                dm[4 * g4 + e] = (-dxs[e]) * dw.y;     // -y.d * fp16(x.dmin)
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const size_t o = ((size_t)i * 8 + t) * 2 * 64;
+            v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ax[o], Bw[o], zero, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ax[o + 64], Bw[o + 64], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = __fmaf_rn(dd[r], c[r], acc[t][r]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v8h a = hz, b = hz;
+            if (h == 0) {
+                const v4h a4 = Am[((size_t)i * 4 + u) * 32], b4 = Bm[((size_t)i * 4 + u) * 32];
+                a[0] = a4[0]; a[1] = a4[1]; a[2] = a4[2]; a[3] = a4[3];
+                b[0] = b4[0]; b[1] = b4[1]; b[2] = b4[2]; b[3] = b4[3];
+            }
+            const v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accm[u][r] = __fmaf_rn(dm[r], c[r], accm[u][r]);
+        }
     }
-    const int n = n0 + col;
+    const int n = nt * 32 + col;
     if (n >= N) return;
     const float bv = bias ? bias[n] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (m < M) y[(int64_t)m * ldy + n] = bias ? __fadd_rn(acc[i], bv) : acc[i];
+    for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= M) continue;
+        const float hs = ((acc[0][r] + acc[4][r]) + (acc[2][r] + acc[6][r])) + ((acc[1][r] + acc[5][r]) + (acc[3][r] + acc[7][r]));
+        float v = hs + ((accm[0][r] + accm[2][r]) + (accm[1][r] + accm[3][r]));
+        if (bias) v = v + bv;
+        if (y_f16) reinterpret_cast<uint16_t *>(y)[(int64_t)m * ldy + n] = f2h(v);
+        else {
+            if (residual) v = v + residual[(int64_t)m * ldy + n];
+            reinterpret_cast<float *>(y)[(int64_t)m * ldy + n] = v;
+        }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fp32 GEMM y = x W^T (+bias) in vec_dot_fp32's order (VecDotFP32.cpp:31-58): 32 fp32 chains per output (chain c takes
+// k = 32 s + c), folded sum0+sum2, sum1+sum3, +, then lanes l/l+4, l/l+1, l/l+2 -- xor 16, 8, 4, 1, 2 over the chain
+// index -- then the K % 32 leftovers by fma in order.  32 lanes = the 32 chains of a TM x TN block of outputs.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int F32_TM = 8, F32_TN = 4;
+#define SWZ_XOR(v, k) __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x1f | ((k) << 10)))
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ W, const float *__restrict__ bias, const float *__restrict__ x,
+                                                       float *__restrict__ y, int64_t ldy, int M, int N, int K) {
+    const int c = threadIdx.x & 31, gi = threadIdx.x >> 5;
+    const int m0 = blockIdx.y * (2 * F32_TM) + (gi >> 2) * F32_TM, n0 = blockIdx.x * (4 * F32_TN) + (gi & 3) * F32_TN;
+    const float *xr[F32_TM], *wr[F32_TN];
+#pragma unroll
+    for (int i = 0; i < F32_TM; ++i) xr[i] = x + (int64_t)min(m0 + i, M - 1) * K;
+#pragma unroll
+    for (int j = 0; j < F32_TN; ++j) wr[j] = W + (int64_t)min(n0 + j, N - 1) * K;
+    float acc[F32_TM][F32_TN];
+#pragma unroll
+    for (int i = 0; i < F32_TM; ++i)
+#pragma unroll
+        for (int j = 0; j < F32_TN; ++j) acc[i][j] = 0.0f;
+    const int np = K & ~31;
+    for (int k = c; k < np; k += 32) {
+        float xv[F32_TM], wv[F32_TN];
+#pragma unroll
+        for (int i = 0; i < F32_TM; ++i) xv[i] = xr[i][k];
+#pragma unroll
+        for (int j = 0; j < F32_TN; ++j) wv[j] = wr[j][k];
+#pragma unroll
+        for (int i = 0; i < F32_TM; ++i)
+#pragma unroll
+            for (int j = 0; j < F32_TN; ++j) acc[i][j] = __fmaf_rn(wv[j], xv[i], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < F32_TM; ++i)
+#pragma unroll
+        for (int j = 0; j < F32_TN; ++j) {
+            float v = acc[i][j];
+            v = v + SWZ_XOR(v, 16);
+            v = v + SWZ_XOR(v, 8);
+            v = v + SWZ_XOR(v, 4);
+            v = v + SWZ_XOR(v, 1);
+            v = v + SWZ_XOR(v, 2);
+            acc[i][j] = v;
+        }
+    for (int k = np; k < K; ++k) {
+        float xv[F32_TM], wv[F32_TN];
+#pragma unroll
+        for (int i = 0; i < F32_TM; ++i) xv[i] = xr[i][k];
+#pragma unroll
+        for (int j = 0; j < F32_TN; ++j) wv[j] = wr[j][k];
+#pragma unroll
+        for (int i = 0; i < F32_TM; ++i)
+#pragma unroll
+            for (int j = 0; j < F32_TN; ++j) acc[i][j] = __fmaf_rn(wv[j], xv[i], acc[i][j]);
+    }
+    // lane c stores output (i, j) = (c / TN, c % TN) of the block
+#pragma unroll
+    for (int i = 0; i < F32_TM; ++i)
+#pragma unroll
+        for (int j = 0; j < F32_TN; ++j)
+            if (c == i * F32_TN + j && m0 + i < M && n0 + j < N) y[(int64_t)(m0 + i) * ldy + n0 + j] = bias ? acc[i][j] + bias[n0 + j] : acc[i][j];
 }
 
 static int launch_gemv_q4k(const void *W, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums, void *y, int y_f16,
@@ -334,6 +399,33 @@ static int launch_gemv_q4k(const void *W, const float *bias, const int8_t *xqs, 
 
 using namespace mllm_hip;
 
+extern "C" size_t mllm_hip_q4k_prepack_bytes(int rows, int K) { return K % 256 ? 0 : q4kp_bytes(rows, K); }
+extern "C" int mllm_hip_q4k_prepack(const void *W, int N, int K, void *out, void *stream) {
+    if (K % 256 != 0 || K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
+    const int nb = K / 256;
+    const int64_t threads = (int64_t)((N + 31) / 32) * 32 * nb * 4;
+    hipLaunchKernelGGL(q4k_prepack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), (const uint8_t *)W, (uint8_t *)out, N, nb);
+    return MH_LAUNCH_OK("q4k_prepack");
+}
+// GEMM on pre-packed weights; xpack = scratch of mllm_hip_q4k_prepack_bytes(M, K) bytes for the activation side
+extern "C" int mllm_hip_linear_q4kp_q8k(const void *Wpacked, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums, void *xpack,
+                                        void *y, int y_dtype, int64_t ldy, const float *residual, int M, int N, int K, void *stream) {
+    if (K % 256 != 0 || K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
+    if (y_dtype != MLLM_HIP_F32 && y_dtype != MLLM_HIP_F16) return MLLM_HIP_ERR_DTYPE;
+    if (M <= 0) return MLLM_HIP_OK;
+    if (!Wpacked || !xpack) return MLLM_HIP_ERR_ARG;
+    const int nb = K / 256;
+    hipStream_t st = as_stream(stream);
+    const int64_t threads = (int64_t)((M + 31) / 32) * 32 * nb * 4;
+    hipLaunchKernelGGL(q8k_prepack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, xqs, xd, xbsums, (uint8_t *)xpack, M, nb);
+    int rc = MH_LAUNCH_OK("q8k_prepack");
+    if (rc) return rc;
+    dim3 grid((N + 63) / 64, (M + 63) / 64);
+    hipLaunchKernelGGL(gemm_q4k_kernel, grid, dim3(256), 0, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16, ldy, residual,
+                       M, N, nb);
+    return MH_LAUNCH_OK("gemm_q4k");
+}
+
 extern "C" int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums, void *y,
                                        int y_dtype, int64_t ldy, const float *residual, int M, int N, int K, void *stream) {
     if (K % 256 != 0 || K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
@@ -351,9 +443,16 @@ extern "C" int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const i
         }
         return MLLM_HIP_OK;
     }
-    dim3 grid((N + 127) / 128, (M + 63) / 64);
-    hipLaunchKernelGGL(gemm_q4k_kernel, grid, dim3(256), 0, st, (const uint8_t *)W, bias, xqs, xd, y, y_f16, ldy, residual, M, N, K);
-    return MH_LAUNCH_OK("gemm_q4k");
+    // raw Q4_K blocks with M >= 16: pack both sides into stream-ordered scratch, then the packed GEMM (callers that keep the
+    // weights resident pre-pack once with mllm_hip_q4k_prepack and call mllm_hip_linear_q4kp_q8k)
+    void *wp = nullptr, *xp = nullptr;
+    MH_CHECK(hipMallocAsync(&wp, q4kp_bytes(N, K), st));
+    MH_CHECK(hipMallocAsync(&xp, q4kp_bytes(M, K), st));
+    int rc = mllm_hip_q4k_prepack(W, N, K, wp, stream);
+    if (!rc) rc = mllm_hip_linear_q4kp_q8k(wp, bias, xqs, xd, xbsums, xp, y, y_dtype, ldy, residual, M, N, K, stream);
+    MH_CHECK(hipFreeAsync(wp, st));
+    MH_CHECK(hipFreeAsync(xp, st));
+    return rc;
 }
 
 extern "C" int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, const float *bias, const int8_t *xqs, const uint16_t *xd,
@@ -364,7 +463,8 @@ extern "C" int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, c
     const int bpl = K / 32 / lpr;
     if (bpl > 8) return MLLM_HIP_ERR_SHAPE;
     hipStream_t st = as_stream(stream);
-    const int target_waves = 256 * 8, rpp = 2 * (64 / lpr);
+    const int target_waves = 256 * 8, rpp = 8;
+    const size_t lds = 4 * q40_tab_floats(K / 32) * sizeof(float);
     int rows_per_wave = (N + target_waves - 1) / target_waves;
     rows_per_wave = ((rows_per_wave + rpp - 1) / rpp) * rpp;
     const int waves = (N + rows_per_wave - 1) / rows_per_wave;
@@ -372,7 +472,7 @@ extern "C" int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, c
         const int8_t *xq = xqs + (int64_t)m * K;
         const uint16_t *xdd = xd + (int64_t)m * (K / 32);
         float *ym = y + (int64_t)m * ldy;
-#define Q40_CASE(B, L) if (bpl == B && lpr == L) hipLaunchKernelGGL((gemv_q40_kernel<B, L>), dim3((waves + 3) / 4), dim3(256), 0, st, Wqs, Wd, bias, xq, xdd, ym, N, rows_per_wave);
+#define Q40_CASE(B, L) if (bpl == B && lpr == L) hipLaunchKernelGGL((gemv_q40_kernel<B, L>), dim3((waves + 3) / 4), dim3(256), lds, st, Wqs, Wd, bias, xq, xdd, ym, N, rows_per_wave);
         Q40_CASE(1, 16) Q40_CASE(2, 16) Q40_CASE(3, 16) Q40_CASE(4, 16) Q40_CASE(5, 16) Q40_CASE(6, 16) Q40_CASE(7, 16) Q40_CASE(8, 16)
         Q40_CASE(1, 8) Q40_CASE(3, 8) Q40_CASE(5, 8) Q40_CASE(7, 8)
 #undef Q40_CASE
@@ -383,9 +483,9 @@ extern "C" int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, c
 }
 
 extern "C" int mllm_hip_linear_f32(const float *W, const float *bias, const float *x, float *y, int64_t ldy, int M, int N, int K, void *stream) {
-    if (K % 8 != 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
+    if (K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
     if (M <= 0) return MLLM_HIP_OK;
-    dim3 grid((N + 63) / 64, (M + 63) / 64);
+    dim3 grid((N + 4 * F32_TN - 1) / (4 * F32_TN), (M + 2 * F32_TM - 1) / (2 * F32_TM));
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), W, bias, x, y, ldy, M, N, K);
     return MH_LAUNCH_OK("gemm_f32");
 }

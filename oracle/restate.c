@@ -458,6 +458,60 @@ void orc_vision_rope_apply(const float *x, int S, int H, int D, const float *ang
             }
 }
 
+/* expf as the reference's attention calls it (FlashAttention2.hpp:451,457): glibc 2.35 libm, x86-64 FMA variant (the ifunc
+ * picks it on every AVX2+FMA host; the HIP kernels carry the same restatement, so it is checked here against the libm of
+ * the machine the goldens were made on).  Published algorithm (sysdeps/ieee754/flt-32/e_expf.c, N = 32 table, cubic in
+ * double), with the contractions of the -mfma build: kd = fma(InvLn2N, x, Shift); r = fma(InvLn2N, x, -(kd - Shift)). */
+static const uint64_t ORC_EXP2F_T[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+float orc_expf(float x) {
+    uint32_t ix;
+    memcpy(&ix, &x, 4);
+    const uint32_t abstop = (ix >> 20) & 0x7ff;
+    if (abstop >= 0x42b) { /* |x| >= 88 or nan */
+        if (ix == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8) return x + x;
+        if (x > 0x1.62e42ep6f) return INFINITY;
+        if (x < -0x1.9fe368p6f) return 0.0f;
+        if (x < -0x1.9d1d9ep6f) return 0x1p-149f; /* __math_may_uflowf: 0x1.4p-75f squared, rounded */
+    }
+    const double xd = (double)x, InvLn2N = 0x1.71547652b82fep+5, Shift = 0x1.8p+52;
+    double kd = fma(InvLn2N, xd, Shift);
+    uint64_t ki;
+    memcpy(&ki, &kd, 8);
+    kd = kd - Shift;
+    const double r = fma(InvLn2N, xd, -kd);
+    uint64_t t = ORC_EXP2F_T[ki & 31] + (ki << 47);
+    double sc;
+    memcpy(&sc, &t, 8);
+    const double z = fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+    const double r2 = r * r;
+    double y = fma(r, 0x1.62e42ff0c52d6p-6, 1.0);
+    y = fma(z, r2, y);
+    return (float)(y * sc);
+}
+/* number of inputs (out of n, spread over [lo, hi] plus every float within +-span ulps of the break points) whose
+ * orc_expf differs from this machine's libm expf */
+long orc_expf_mismatches(float lo, float hi, long n, uint64_t seed) {
+    long bad = 0;
+    uint64_t st = seed * 6364136223846793005ull + 1442695040888963407ull;
+#pragma omp parallel for reduction(+ : bad)
+    for (long i = 0; i < n; ++i) {
+        uint64_t z = (st + (uint64_t)i * 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        const float u = (float)((double)(z >> 11) * (1.0 / 9007199254740992.0));
+        const float x = lo + (hi - lo) * u;
+        const float a = orc_expf(x), b = expf(x);
+        if (memcmp(&a, &b, 4) != 0) bad++;
+    }
+    return bad;
+}
+
 /* A12/A13: F_FA2 (CPUFlashAttention2Func.hpp:52-125 -> compute/FlashAttention2.hpp), restated in the reference's own
  * evaluation order (x86 AVX2 build) so that results are bit-identical:
  *   - tiles Br = Bc = 4 when Sq >= 4, else Br = Bc = 1 (CPUFlashAttention2Func.hpp:71-72); Sq == 1 takes __fa2_decode

@@ -1,6 +1,7 @@
 """End-to-end GPU parity: the engine's Qwen2-VL graph (vision tower + LLM, prefill + greedy decode) against golden outputs of
 the reference's own Qwen2VLModel run on its x86 CPU backend on the same synthetic Q4_K .mllm (tests/golden/qwen2vl_tiny.npz,
-made by oracle/make_golden.py).  Bars (BASELINE.json north_star): identical greedy token ids, logits within 1e-3."""
+made by oracle/make_golden.py).  BASELINE.json's north_star asks for identical greedy token ids and logits within 1e-3; the
+kernels keep the reference's operation order, so the bar held here is stricter: every logit bit-identical."""
 import os
 
 import numpy as np
@@ -34,7 +35,7 @@ def test_tiny_prefill_and_decode_match_reference(tiny_model, tiny_gold):
         toks.append(tok)
         maxerr = max(maxerr, float(np.max(np.abs(logits - g["logits"][s]))))
     assert toks == g["tokens"].tolist(), (toks, g["tokens"].tolist())
-    assert maxerr <= 1e-3, maxerr
+    assert maxerr == 0.0, maxerr
 
 
 def test_tiny_text_only_prompt(tiny_model, tiny_gold):
@@ -48,7 +49,7 @@ def test_tiny_text_only_prompt(tiny_model, tiny_gold):
         toks.append(tok)
         maxerr = max(maxerr, float(np.max(np.abs(logits - g["logits_text"][s]))))
     assert toks == g["tokens_text"].tolist()
-    assert maxerr <= 1e-3, maxerr
+    assert maxerr == 0.0, maxerr
 
 
 def test_vision_tower_matches_reference(tiny_model, tiny_gold):
@@ -57,7 +58,7 @@ def test_vision_tower_matches_reference(tiny_model, tiny_gold):
     out = torch.empty((16, cfg.hidden), dtype=torch.float32, device="cuda")
     m.vision(pix, grid, out.data_ptr())
     err = float(np.max(np.abs(out.cpu().numpy() - tiny_gold["image_embeds"])))
-    assert err <= 1e-3, err
+    assert err == 0.0, err
 
 
 def test_generate_equals_stepwise_decode_and_clear_kvcache_resets(tiny_model):

@@ -1,0 +1,74 @@
+"""Full-size GPU parity (BASELINE.json configs[3] shape: Qwen2-VL-2B, Q4_K, 448x448 image + 24-token prompt, KV limit 800) against
+golden outputs of the reference's own run on the same synthetic .mllm (tests/golden/qwen2vl_2b_ref*.npz, made by
+oracle/make_golden.py --full from oracle/_ref/ref_qwen2vl / ref_ops): greedy ids identical, every sampled logit bit-identical
+(the goldens keep the top-64 logits and every 97th logit of the dumped steps), the vision tower's image_embeds bit-identical."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from mllm_amd import lib, synth, weights  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    cfg = synth.qwen2vl_2b()
+    path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
+    m = lib.Qwen2VL(cfg, path)
+    yield cfg, m
+    m.close()
+
+
+def _sample_err(g, i, logits):
+    return float(max(np.abs(logits[g["top_idx"][i]] - g["top_val"][i]).max(), np.abs(logits[::97] - g["strided"][i]).max()))
+
+
+def _run(m, g, first):
+    steps = {int(s): i for i, s in enumerate(g["steps"])}
+    tok, logits, _ = first()
+    toks, errs = [tok], [_sample_err(g, steps[0], logits)]
+    for s in range(1, len(g["tokens"])):
+        tok, logits, _ = m.decode(tok)
+        toks.append(tok)
+        if s in steps:
+            errs.append(_sample_err(g, steps[s], logits))
+    return toks, errs
+
+
+def test_full_vision_tower_bit_exact(full_model):
+    cfg, m = full_model
+    pix, grid, _ = synth.qwen2vl_inputs(cfg, (32, 32), 24)
+    out = torch.empty((256, cfg.hidden), dtype=torch.float32, device="cuda")
+    m.vision(pix, grid, out.data_ptr())
+    ref = np.load(os.path.join(GOLD, "qwen2vl_2b_ref_vision.npz"))["image_embeds"]
+    got = out.cpu().numpy()
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+
+
+def test_full_text_prompt_bit_exact(full_model):
+    cfg, m = full_model
+    g = np.load(os.path.join(GOLD, "qwen2vl_2b_ref_text.npz"))
+    m.clear_kvcache()
+    toks, errs = _run(m, g, lambda: m.prefill(g["ids"]))
+    assert toks == g["tokens"].tolist(), sum(a == b for a, b in zip(toks, g["tokens"].tolist()))
+    assert max(errs) == 0.0, errs
+
+
+def test_full_image_prompt_bit_exact(full_model):
+    cfg, m = full_model
+    g = np.load(os.path.join(GOLD, "qwen2vl_2b_ref.npz"))
+    pix, grid, ids = synth.qwen2vl_inputs(cfg, (32, 32), 24)
+    m.clear_kvcache()
+    toks, errs = _run(m, g, lambda: m.prefill(ids, pix, grid))
+    assert toks == g["tokens"].tolist(), sum(a == b for a, b in zip(toks, g["tokens"].tolist()))
+    assert max(errs) == 0.0, errs
+    # generate() (device-side argmax, hipGraph replay) reproduces the stepwise ids
+    m.clear_kvcache()
+    tok, _, _ = m.prefill(ids, pix, grid)
+    gen, _ = m.generate(tok, len(g["tokens"]) - 1)
+    assert [tok] + gen.tolist() == g["tokens"].tolist()

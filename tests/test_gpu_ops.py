@@ -1,8 +1,8 @@
 """GPU parity tests proper: every HIP launcher of the hot path (called through the C ABI) against the oracle on seeded inputs
-and against the committed golden vectors of the reference.  Bars: integer / byte / index results bit-exact; fp32 results
-bit-exact where the kernel keeps the reference's operation order (elementwise, LUT, rotary, norm scale), otherwise within
-the tolerance written next to the assert (dot products: the per-super-block integer sums are exact, only the order of the
-final fp32 additions differs from the AVX2 lanes)."""
+and against the committed golden vectors of the reference.  Bar: bit-exact -- integer / byte / index results and fp32 results alike: the kernels keep the reference's operation order
+(AVX2 lane chains of the dot products, FA2 tile recurrence with glibc expf, sequential LayerNorm sums).  The one stated
+exception is RMSNorm's double-precision sum of squares (tree instead of sequential: the fp32 mean can move by one ulp with
+probability ~1e-9 per row)."""
 import numpy as np
 import pytest
 
@@ -72,8 +72,7 @@ def test_linear_q4k_gemv_vs_oracle(M, K, N):
     Wq, x, b = _q4k_case(M, K, N, K + N)
     y = ops.linear_q4k(Wq, x, N, bias=b)
     ref = orc.linear(x, Wq, orc.Q4_K, N, b)
-    # int-exact per super-block; fp32 combine order differs from the 8+4 AVX2 lanes: <= a few ulp of sum |terms|
-    assert md(y, ref) <= 2e-5 * max(1.0, float(np.abs(ref).max())), md(y, ref)
+    assert eq(y, ref), md(y, ref)
 
 
 @pytest.mark.parametrize("M,K,N", [(16, 256, 128), (64, 1536, 256), (282, 1536, 2048), (100, 8960, 192), (1024, 1280, 384), (33, 512, 96)])
@@ -81,29 +80,29 @@ def test_linear_q4k_gemm_vs_oracle(M, K, N):
     Wq, x, b = _q4k_case(M, K, N, M + K + N)
     y = ops.linear_q4k(Wq, x, N, bias=b)
     ref = orc.linear(x, Wq, orc.Q4_K, N, b)
-    assert md(y, ref) <= 2e-5 * max(1.0, float(np.abs(ref).max())), md(y, ref)
+    assert eq(y, ref), md(y, ref)
 
 
 def test_linear_q4k_fp16_out_and_residual():
     Wq, x, b = _q4k_case(1, 1536, 256, 5)
     y16 = ops.linear_q4k(Wq, x, 256, bias=b, out_f16=True)
     ref16 = orc.f16_to_f32(orc.linear(x, Wq, orc.Q4_K, 256, b, out_f16=True))
-    assert md(y16.float(), ref16) <= 2e-3 * float(np.abs(ref16).max())       # one fp16 ulp
+    assert eq(y16.float(), ref16), md(y16.float(), ref16)
     res = rng(1).standard_normal((1, 256)).astype(np.float32)
     y = ops.linear_q4k(Wq, x, 256, bias=None, residual=res)
     ref = orc.linear(x, Wq, orc.Q4_K, 256) + res
-    assert md(y, ref) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    assert eq(y, ref), md(y, ref)
     Wq2, x2, _ = _q4k_case(40, 512, 128, 6)
     res2 = rng(2).standard_normal((40, 128)).astype(np.float32)
     y2 = ops.linear_q4k(Wq2, x2, 128, residual=res2)
-    assert md(y2, orc.linear(x2, Wq2, orc.Q4_K, 128) + res2) <= 2e-5 * 8
+    assert eq(y2, orc.linear(x2, Wq2, orc.Q4_K, 128) + res2)
 
 
 def test_linear_golden_reference(ops_gold):
     g = ops_gold
     for x, yref in ((g["lin_x5"], g["lin_y5"]), (g["lin_x1"], g["lin_y1"])):
         y = ops.linear_q4k(g["lin_w"], x, 96, bias=g["lin_b"])
-        assert md(y, yref) <= 2e-5 * max(1.0, float(np.abs(yref).max()))
+        assert eq(y, yref), md(y, yref)
 
 
 def test_linear_is_linear_in_weights_rows_and_zero_input():
@@ -129,13 +128,13 @@ def test_linear_q40_vs_oracle(K, N):
     x = r.standard_normal((1, K)).astype(np.float32)
     y = ops.linear_q40(Wq, x, N)
     ref = orc.linear(x, Wq, orc.Q4_0, N)
-    assert md(y, ref) <= 2e-5 * max(1.0, float(np.abs(ref).max())), md(y, ref)
+    assert eq(y, ref), md(y, ref)
 
 
 def test_tied_head_and_embedding_golden(ops_gold):
     g = ops_gold
     y = ops.linear_q40(g["emb_w"], g["mm_x"], 160)
-    assert md(y, g["mm_y"]) <= 2e-5 * max(1.0, float(np.abs(g["mm_y"]).max()))
+    assert eq(y, g["mm_y"]), md(y, g["mm_y"])
     e = ops.embedding_q40(g["emb_ids"], g["emb_w"], 160, 512)
     assert eq(e, g["emb_y"])
 
@@ -143,15 +142,15 @@ def test_tied_head_and_embedding_golden(ops_gold):
 def test_linear_f32_and_patch_convs(ops_gold):
     g = ops_gold
     y = ops.linear_f32(g["linf_w"], g["linf_x"])
-    assert md(y, g["linf_y"]) <= 1e-5
+    assert eq(y, g["linf_y"]), md(y, g["linf_y"])
     y = ops.patch_gemm(g["conv3_x"], g["conv3_w"])
-    assert md(y, g["conv3_y"]) <= 2e-5
+    assert eq(y, g["conv3_y"]), md(y, g["conv3_y"])
     y = ops.conv2d_patch(g["conv2_x"], 8, 3, 12, g["conv2_w"], 8, 4, g["conv2_b"])
-    assert md(y, g["conv2_y"].reshape(2, 8, 3)) <= 2e-5
+    assert eq(y, g["conv2_y"].reshape(2, 8, 3)), md(y, g["conv2_y"].reshape(2, 8, 3))
     r = rng(9)
     px, W = r.standard_normal((1024, 1176)).astype(np.float32), (r.standard_normal((1280, 1176)) * 0.02).astype(np.float32)
     y = ops.patch_gemm(px, W)
-    assert md(y, orc.patch_gemm(px, W)) <= 5e-5
+    assert eq(y, orc.patch_gemm(px, W))
 
 
 # ---- A9 / A18 --------------------------------------------------------------------------------------------------------------
@@ -174,10 +173,15 @@ def test_rmsnorm(ops_gold):
 def test_layernorm(ops_gold):
     g = ops_gold
     y = ops.layernorm(g["norm_x"], g["norm_w"], g["norm_b"], 1e-6)
-    assert md(y, g["ln_y"]) <= 3e-6
+    assert eq(y, g["ln_y"]), md(y, g["ln_y"])
     x = rng(6).standard_normal((9, 1280)).astype(np.float32) * 2 + 0.3
     y, q = ops.layernorm(x, g["norm_w"][:1].repeat(1280), None, 1e-6, quant=True)
-    assert md(y, orc.layernorm(x, g["norm_w"][:1].repeat(1280), None, 1e-6)) <= 5e-6
+    assert eq(y, orc.layernorm(x, g["norm_w"][:1].repeat(1280), None, 1e-6))
+    x = rng(7).standard_normal((1024, 1280)).astype(np.float32) * 3 - 0.2       # the vision tower's shape: 64 workgroups of 16 rows
+    wv, bv = rng(8).standard_normal(1280).astype(np.float32), rng(9).standard_normal(1280).astype(np.float32)
+    assert eq(ops.layernorm(x, wv, bv, 1e-6), orc.layernorm(x, wv, bv, 1e-6))
+    x = rng(10).standard_normal((5, 100)).astype(np.float32)                    # ragged dim (no float4 tail, one partial chunk)
+    assert eq(ops.layernorm(x, wv[:100], bv[:100], 1e-5), orc.layernorm(x, wv[:100], bv[:100], 1e-5))
     q2 = ops.quantize_q8k(y)
     assert eq(q.qs, q2.qs.cpu().numpy())
 
@@ -235,14 +239,16 @@ def test_rotary_bit_exact(ops_gold):
 def test_fa2_golden_fp32_kv(ops_gold):
     g = ops_gold
     o = ops.flash_attention2(g["fa_q"], g["fa_k"], g["fa_v"], 40, 40, 2, 2, 16, False)
-    assert md(o, g["fa_o"]) <= 3e-6, md(o, g["fa_o"])
+    assert eq(o, g["fa_o"]), md(o, g["fa_o"])
     o = ops.flash_attention2(g["fac_q"], g["fac_k"], g["fac_v"], 12, 12, 4, 2, 16, True)
-    assert md(o, g["fac_o"]) <= 3e-6, md(o, g["fac_o"])
+    assert eq(o, g["fac_o"]), md(o, g["fac_o"])
 
 
 @pytest.mark.parametrize("Sq,Sk,Hq,Hkv,D,causal,f16", [
     (282, 282, 12, 2, 128, True, True), (1, 283, 12, 2, 128, True, True), (1, 800, 12, 2, 128, True, True), (1, 1, 12, 2, 128, True, True),
-    (130, 130, 16, 16, 80, False, False), (7, 40, 4, 4, 64, True, True), (64, 64, 2, 1, 16, True, False), (1, 257, 16, 16, 64, True, True)])
+    (130, 130, 16, 16, 80, False, False), (7, 40, 4, 4, 64, True, True), (64, 64, 2, 1, 16, True, False), (1, 257, 16, 16, 64, True, True),
+    (1024, 1024, 2, 2, 80, False, False), (5, 5, 2, 2, 64, True, True), (6, 7, 2, 1, 64, True, False), (3, 11, 2, 2, 64, True, True),
+    (2, 2, 1, 1, 16, False, False), (21, 23, 4, 2, 128, True, True), (300, 300, 4, 2, 128, True, True), (9, 270, 2, 2, 80, False, True)])
 def test_fa2_vs_oracle(Sq, Sk, Hq, Hkv, D, causal, f16):
     r = rng(Sq * 3 + Sk + D)
     q = r.standard_normal((Sq, Hq * D)).astype(np.float32)
@@ -255,7 +261,7 @@ def test_fa2_vs_oracle(Sq, Sk, Hq, Hkv, D, causal, f16):
     else:
         o = ops.flash_attention2(q, k, v, Sq, Sk, Hq, Hkv, D, causal)
         ref = orc.attention(q, k, v, Sq, Sk, Hq, Hkv, D, causal)
-    assert md(o, ref) <= 5e-6 * max(1.0, float(np.abs(ref).max())), md(o, ref)
+    assert eq(o, ref), md(o, ref)
 
 
 def test_fa2_online_softmax_rescale_is_forced():
@@ -267,7 +273,7 @@ def test_fa2_online_softmax_rescale_is_forced():
     v = r.standard_normal((Sk, 128)).astype(np.float32)
     k[90] = q[95] * 3
     o = ops.flash_attention2(q, k, v, Sq, Sk, 1, 1, 128, True)
-    assert md(o, orc.attention(q, k, v, Sq, Sk, 1, 1, 128, True)) <= 1e-5
+    assert eq(o, orc.attention(q, k, v, Sq, Sk, 1, 1, 128, True))
 
 
 def test_fa2_decode_reads_sk_from_device():
@@ -278,4 +284,4 @@ def test_fa2_decode_reads_sk_from_device():
     sk = torch.tensor([300], dtype=torch.int32, device="cuda")
     o = ops.flash_attention2(q, torch.from_numpy(k), torch.from_numpy(v), 1, 800, 12, 2, 128, True, sk_dev=sk)
     ref = orc.attention(q, k[:300].view(np.uint16), v[:300].view(np.uint16), 1, 300, 12, 2, 128, True)
-    assert md(o, ref) <= 5e-6 * max(1.0, float(np.abs(ref).max()))
+    assert eq(o, ref), md(o, ref)
