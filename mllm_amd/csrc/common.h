@@ -25,7 +25,13 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 
 // ---- device helpers -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-__device__ __forceinline__ uint16_t f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
+// fp32 -> fp16 of an ALREADY ROUNDED fp32 value (the reference stores fp32 results, then converts: two roundings).  The empty asm
+// pins the fp32 value in a register; without it the compiler folds a preceding fma/add into v_fma_mixlo_f16, which rounds the
+// exact result once and differs from the reference in ~2^-13 of the values.
+__device__ __forceinline__ uint16_t f2h(float f) {
+    asm volatile("" : "+v"(f));
+    return __half_as_ushort(__float2half_rn(f));
+}
 
 // NOTE: sqrtf() is the correctly rounded square root here (v_sqrt_f32 + refinement); __fsqrt_rn() lowers to the bare 1-ulp
 // v_sqrt_f32 on gfx950 and must not be used where the reference calls sqrtf/std::sqrt.

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -332,6 +333,11 @@ extern "C" void mllm_hip_qwen2vl_destroy(mllm_hip_qwen2vl *m) {
 extern "C" int mllm_hip_qwen2vl_clear_kvcache(mllm_hip_qwen2vl *m) { m->cache_len = 0; m->last_pos = -1.0f; return MLLM_HIP_OK; }
 extern "C" int64_t mllm_hip_qwen2vl_decode_weight_bytes(const mllm_hip_qwen2vl *m) { return m->decode_weight_bytes; }
 extern "C" void *mllm_hip_qwen2vl_stream(mllm_hip_qwen2vl *m) { return (void *)m->st; }
+// bring-up aid (not part of include/mllm_hip.h): device pointers of the prefill activations, 0 h0, 1 h1, 2 qkv, 3 attn, 4 gate|up, 5 act
+extern "C" void *mllm_hip_qwen2vl_debug_ptr(mllm_hip_qwen2vl *m, int which) {
+    switch (which) { case 0: return m->h0; case 1: return m->h1; case 2: return m->qkv; case 3: return m->attn; case 4: return m->gu; case 5: return m->act; case 6: return m->kslab; case 7: return m->vslab; }
+    return nullptr;
+}
 
 // get_rope_index (modeling_qwen2_vl.hpp:436-595), batch 1, images only. pos = [3][S].
 static void rope_index(const M *m, const int32_t *ids, int S, const int32_t *grid, bool has_img, std::vector<float> &pos) {
@@ -466,7 +472,8 @@ static int forward_llm(M *m, int S, const float *pos3) {
         HH(hipStreamSynchronize(st));  // host vectors go out of scope
     }
     float *h = m->h0, *h2 = m->h1;
-    for (int li = 0; li < c.layers; ++li) {
+    const int n_layers = getenv("MLLM_HIP_MAX_LAYERS") ? std::min(c.layers, atoi(getenv("MLLM_HIP_MAX_LAYERS"))) : c.layers;   // bring-up aid
+    for (int li = 0; li < n_layers; ++li) {
         auto &L = m->layers[li];
         uint16_t *kl = m->kslab + (size_t)li * c.cache_limit * m->KVD, *vl = m->vslab + (size_t)li * c.cache_limit * m->KVD;
         EH(mllm_hip_rmsnorm(h, L.in_norm, nullptr, m->xq.qs, m->xq.d, m->xq.bs, S, H, c.rms_eps, 0, st));

@@ -235,6 +235,22 @@ def test_rotary_bit_exact(ops_gold):
     assert eq(ops.rope_apply(g["vrope_x"], 16, 2, 16, s, c), g["vrope_y"])
 
 
+def test_rotary_fp16_store_rounds_twice_like_the_reference():
+    """fp32 rotate result, THEN fp16: a fused fma->fp16 (one rounding) differs in ~2^-13 of the values; 400k values catch it."""
+    S, H, D = 400, 8, 128
+    x = rng(31).standard_normal((S, H * D)).astype(np.float32)
+    pos = np.tile(np.arange(S, dtype=np.float32), (3, 1))
+    s, c = lib.mrope_table(1000000.0, D, pos)
+    k16 = ops.rope_apply(x, S, H, D, s, c, out_f16=True)
+    assert eq(k16.view(torch.int16), orc.rope_apply(x, S, H, D, s, c, out_f16=True).view(np.int16))
+    Wq, xx, b = _q4k_case(64, 512, 256, 77)
+    y16 = ops.linear_q4k(Wq, xx, 256, bias=b, out_f16=True)       # GEMM epilogue (bias add, then fp16)
+    assert eq(y16.view(torch.int16), orc.linear(xx, Wq, orc.Q4_K, 256, b, out_f16=True).view(np.int16))
+    Wq, xx, b = _q4k_case(1, 1536, 4096, 78)
+    y16 = ops.linear_q4k(Wq, xx, 4096, bias=b, out_f16=True)      # GEMV epilogue
+    assert eq(y16.view(torch.int16), orc.linear(xx, Wq, orc.Q4_K, 4096, b, out_f16=True).view(np.int16))
+
+
 # ---- A13 ---------------------------------------------------------------------------------------------------------------------
 def test_fa2_golden_fp32_kv(ops_gold):
     g = ops_gold
