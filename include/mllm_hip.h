@@ -136,6 +136,9 @@ int mllm_hip_rope_apply(const float *x, int64_t ldx, const float *sin_t, const f
                         int out_dtype, int64_t ldo, int S, int H, int D, void *stream);
 /* fp32 -> fp16 strided copy: V rows into the cache slab (the fp16 store branch of mat_mul, Matmul.cpp:262-268) */
 int mllm_hip_store_f16(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *stream);
+/* same values, transposed: out[c * ldo + s].  The resident engine keeps its V slab as [Hkv*D][cache rows] so that the sequential
+ * P.V walk of __fa2_decode (FlashAttention2.hpp:1075-1110) reads one dim's values contiguously in key order. */
+int mllm_hip_store_f16_t(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *stream);
 
 /* ---- A13: flash_attention_2_forward (compute/FlashAttention2.hpp:2236-2284; fp16-KV impl :1212, fp32-KV impl :87).
  *      O = softmax(Q K^T / sqrt(D) + causal) V, GQA kv_head = q_head / (Hq/Hkv), causal offset Sk - Sq, fp32 accumulate.
@@ -145,6 +148,9 @@ int mllm_hip_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, const 
                  int64_t ldo, int Sq, int Sk, int Hq, int Hkv, int D, int causal, const int *sk_dev, void *workspace,
                  void *stream);
 size_t mllm_hip_fa2_workspace_bytes(int Sq, int Hq, int D, int max_sk);
+/* attention on the engine's KV layout: K fp16 rows `[Sk][Hkv*D]`, V fp16 transposed `[Hkv*D][ldvt]` (mllm_hip_store_f16_t) */
+int mllm_hip_fa2_vt(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *Vt, int64_t ldvt, float *O, int64_t ldo,
+                    int Sq, int Sk, int Hq, int Hkv, int D, int causal, void *stream);
 
 /* ---- A16/A17: patch-embedding convolution with kernel == stride as a GEMM over flattened receptive fields
  *      (compute/Convolution.cpp:35-82,179-235): out[n][oc] = vec_dot_fp32(W[oc], patch[n]) + bias ------------------- */

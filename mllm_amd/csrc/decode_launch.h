@@ -29,7 +29,8 @@ struct DecodeCtx {
     int *part_idx, *tok_dev, *history;
     const float *rope_sin, *rope_cos;   // [cache_limit][D/2], row = DecodeState::step
     float *cur_sin, *cur_cos;           // [D/2]: the row of the step about to run (refreshed by dec_next)
-    uint16_t *kslab, *vslab;
+    uint16_t *kslab, *vslab;            // K: [layers][cache_limit][Hkv*D]; V transposed: [layers][Hkv*D][vt_ld]
+    int vt_ld;
 };
 
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st);

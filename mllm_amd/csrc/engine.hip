@@ -110,6 +110,7 @@ struct mllm_hip_qwen2vl {
     int8_t *x80_qs = nullptr; uint16_t *x80_d = nullptr;
     float *rope_sin = nullptr, *rope_cos = nullptr;
     uint16_t *kslab = nullptr, *vslab = nullptr;
+    int vt_ld = 0;
     void *fa_ws = nullptr;
     void *xpack = nullptr;
     size_t xpack_bytes = 0;
@@ -287,8 +288,11 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
     CK(m->dalloc(&m->x80_qs, (size_t)H)); CK(m->dalloc(&m->x80_d, (size_t)(H / 32) * 2));
     CK(m->dalloc(&m->rope_sin, (size_t)T * (m->D / 2) * 4)); CK(m->dalloc(&m->rope_cos, (size_t)T * (m->D / 2) * 4));
     // + 64 rows: the decode attention reads whole 64-key splits speculatively
-    CK(m->dalloc(&m->kslab, ((size_t)c.layers * T + 64) * m->KVD * 2)); CK(m->dalloc(&m->vslab, ((size_t)c.layers * T + 64) * m->KVD * 2));
-    hipMemset(m->kslab, 0, ((size_t)c.layers * T + 64) * m->KVD * 2); hipMemset(m->vslab, 0, ((size_t)c.layers * T + 64) * m->KVD * 2);
+    // K slab [layers][T][KVD] (the reference's BSHD cache rows); V slab transposed [layers][KVD][vt_ld], vt_ld = T rounded up + 128 keys
+    // of zero padding (the decode walk over-reads whole 16-byte vectors; prefill reads 4 keys at a time)
+    m->vt_ld = ((T + 63) & ~63) + 128;
+    CK(m->dalloc(&m->kslab, ((size_t)c.layers * T + 64) * m->KVD * 2)); CK(m->dalloc(&m->vslab, (size_t)c.layers * m->KVD * m->vt_ld * 2));
+    hipMemset(m->kslab, 0, ((size_t)c.layers * T + 64) * m->KVD * 2); hipMemset(m->vslab, 0, (size_t)c.layers * m->KVD * m->vt_ld * 2);
     m->nsplit = (T + 63) / 64;
     {
         size_t wsb = mllm_hip_fa2_workspace_bytes(1, c.heads, m->D, T), wsd = (size_t)c.heads * m->nsplit * 136 * 4;
@@ -305,7 +309,7 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
         d.nsplit = m->nsplit; d.max_parts = m->max_parts; d.eps = c.rms_eps; d.emb_qs = m->emb_qs; d.emb_d = m->emb_d; d.final_norm = m->final_norm;
         d.x0 = m->h0; d.x1 = m->h1; d.qkv = m->qkv; d.act = m->act; d.logits = m->logits; d.fa_ws = (float *)m->fa_ws; d.part_val = m->part_val;
         d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos; d.cur_sin = m->cur_sin; d.cur_cos = m->cur_cos;
-        d.kslab = m->kslab; d.vslab = m->vslab; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
+        d.kslab = m->kslab; d.vslab = m->vslab; d.vt_ld = m->vt_ld; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
         for (auto &L : m->layers) {
             DecodeLayer dl;
             dl.in_norm = L.in_norm; dl.post_norm = L.post_norm; dl.Wqkv = (const uint8_t *)L.qkv.w; dl.bqkv = L.qkv.bias; dl.qkv_N = L.qkv.N;
@@ -475,14 +479,14 @@ static int forward_llm(M *m, int S, const float *pos3) {
     const int n_layers = getenv("MLLM_HIP_MAX_LAYERS") ? std::min(c.layers, atoi(getenv("MLLM_HIP_MAX_LAYERS"))) : c.layers;   // bring-up aid
     for (int li = 0; li < n_layers; ++li) {
         auto &L = m->layers[li];
-        uint16_t *kl = m->kslab + (size_t)li * c.cache_limit * m->KVD, *vl = m->vslab + (size_t)li * c.cache_limit * m->KVD;
+        uint16_t *kl = m->kslab + (size_t)li * c.cache_limit * m->KVD, *vl = m->vslab + (size_t)li * m->KVD * m->vt_ld;
         EH(mllm_hip_rmsnorm(h, L.in_norm, nullptr, m->xq.qs, m->xq.d, m->xq.bs, S, H, c.rms_eps, 0, st));
         EH(lin(m, L.qkv, m->xq, m->qkv, MLLM_HIP_F32, m->QKV, nullptr, S));
         // q_rope in place; k_rope -> fp16 slab rows [T0, T0+S); v -> fp16 slab (KVCache zero-copy append)
         EH(mllm_hip_rope_apply(m->qkv, m->QKV, m->rope_sin, m->rope_cos, D / 2, m->qkv, MLLM_HIP_F32, m->QKV, S, c.heads, D, st));
         EH(mllm_hip_rope_apply(m->qkv + m->HD, m->QKV, m->rope_sin, m->rope_cos, D / 2, kl + (size_t)T0 * m->KVD, MLLM_HIP_F16, m->KVD, S, c.kv_heads, D, st));
-        EH(mllm_hip_store_f16(m->qkv + m->HD + m->KVD, m->QKV, vl + (size_t)T0 * m->KVD, m->KVD, S, m->KVD, st));
-        EH(mllm_hip_fa2(m->qkv, m->QKV, kl, m->KVD, vl, m->KVD, MLLM_HIP_F16, m->attn, m->HD, S, T0 + S, c.heads, c.kv_heads, D, 1, nullptr, m->fa_ws, st));
+        EH(mllm_hip_store_f16_t(m->qkv + m->HD + m->KVD, m->QKV, vl + T0, m->vt_ld, S, m->KVD, st));
+        EH(mllm_hip_fa2_vt(m->qkv, m->QKV, kl, m->KVD, vl, m->vt_ld, m->attn, m->HD, S, T0 + S, c.heads, c.kv_heads, D, 1, st));
         EH(mllm_hip_quantize_q8k(m->attn, m->xq.qs, m->xq.d, m->xq.bs, S, m->HD, st));
         EH(lin(m, L.o, m->xq, h2, MLLM_HIP_F32, H, h, S));                          // tmp = o_proj(attn) + x
         EH(mllm_hip_rmsnorm(h2, L.post_norm, nullptr, m->xq.qs, m->xq.d, m->xq.bs, S, H, c.rms_eps, 0, st));

@@ -28,7 +28,8 @@ struct PrefillCfg {
     static constexpr int SP = FA_KC + 4;   // pitch of the score rows
 };
 
-template <int D, bool F16>
+// VT: V is the transposed fp16 slab (element (key j, dim d) at V[(kvh*D + d) * ldv + j], ldv % 4 == 0, rows zero padded)
+template <int D, bool F16, bool VT = false>
 __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restrict__ Q, int64_t ldq, const void *__restrict__ K, int64_t ldk,
                                                           const void *__restrict__ V, int64_t ldv, float *__restrict__ O, int64_t ldo, int Sq, int Sk,
                                                           int sk_eff, int Hq, int Hkv, int causal) {
@@ -114,8 +115,14 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
             for (int tl = 0; tl < ntl; ++tl) {
                 const float4 c4 = *reinterpret_cast<const float4 *>(Cc + (g * 64 + tl) * 4);
                 float vv[4];
+                if (VT) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(V) + (int64_t)(kvh * D + d) * ldv + chunk0 + 4 * tl);
+                    vv[0] = h2f((uint16_t)(w.x & 0xffff)); vv[1] = h2f((uint16_t)(w.x >> 16));
+                    vv[2] = h2f((uint16_t)(w.y & 0xffff)); vv[3] = h2f((uint16_t)(w.y >> 16));
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) vv[k] = kv_at<F16>(V, (int64_t)min(chunk0 + 4 * tl + k, Sk - 1) * ldv + kvh * D + d);
+                    for (int k = 0; k < 4; ++k) vv[k] = kv_at<F16>(V, (int64_t)min(chunk0 + 4 * tl + k, Sk - 1) * ldv + kvh * D + d);
+                }
                 const float cr[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -143,20 +150,20 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
     }
 }
 
-template <int D, bool F16, int NT>
+template <int D, bool F16, int NT, bool VT>
 __global__ __launch_bounds__(NT) void fa2_decode_kernel(const float *__restrict__ Q, const void *__restrict__ K, int64_t ldk, const void *__restrict__ V,
-                                                        int64_t ldv, float *__restrict__ O, int Sk, const int *__restrict__ sk_dev, int Hq, int Hkv) {
+                                                        int64_t ldv, float *__restrict__ O, int Sk, const int *__restrict__ sk_dev, int cap, int nslots, int Hq,
+                                                        int Hkv) {
     extern __shared__ __attribute__((aligned(16))) char fa_smem[];
-    if (sk_dev) Sk = *sk_dev;
-    float2 *pc = reinterpret_cast<float2 *>(fa_smem);
-    float *qs = reinterpret_cast<float *>(fa_smem + (size_t)((Sk + 1) & ~1) * sizeof(float2));
-    float *ob = qs + D;
-    float *wred = ob + D;
     const int head = blockIdx.x, kvh = head / (Hq / Hkv);
-    if (threadIdx.x < D) qs[threadIdx.x] = Q[head * D + threadIdx.x];
+    DecodePrefetch<D, F16, NT, VT> P;
+    fa2_decode_prefetch<D, F16, NT, VT>(P, K, ldk, V, ldv, kvh * D, cap, nslots);
+    if (sk_dev) Sk = min(*sk_dev, cap);
+    const DecodeLds L = carve_decode(fa_smem, cap, D, NT, nslots);
+    if (threadIdx.x < D) L.qs[threadIdx.x] = Q[head * D + threadIdx.x];
     __syncthreads();
-    fa2_decode_head<D, F16, NT>(qs, K, ldk, V, ldv, kvh * D, Sk, pc, wred, nullptr, nullptr, -1, ob);
-    if (threadIdx.x < D) O[head * D + threadIdx.x] = ob[threadIdx.x];
+    fa2_decode_head<D, F16, NT, VT>(L, P, K, ldk, V, ldv, kvh * D, Sk, cap, nullptr, nullptr, -1);
+    if (threadIdx.x < D) O[head * D + threadIdx.x] = L.ob[threadIdx.x];
 }
 }  // namespace mllm_hip
 
@@ -167,16 +174,18 @@ extern "C" size_t mllm_hip_fa2_workspace_bytes(int Sq, int Hq, int D, int max_sk
     return 256;   // the kernels keep their state in LDS; a token allocation keeps callers' bookkeeping uniform
 }
 
-template <int D, bool F16>
+template <int D, bool F16, bool VT = false>
 static int launch_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *V, int64_t ldv, float *O, int64_t ldo, int Sq, int Sk,
                       int Hq, int Hkv, int causal, const int *sk_dev, int sk_max, hipStream_t st) {
     constexpr int NT = 1024;
     auto decode_row = [&](const float *q, float *o, int sk, const int *skd, int skm) -> int {
-        const size_t lds = (size_t)((skm + 1) & ~1) * sizeof(float2) + (size_t)(2 * D + NT / 64 + 2) * sizeof(float);
+        constexpr int ELT = F16 ? 2 : 4;
+        const int nslots = decode_lds_slots(skm, D, NT, ELT, VT);
+        const size_t lds = decode_lds_bytes(skm, D, NT, ELT, nslots, VT);
         if (lds > 160 * 1024) return MLLM_HIP_ERR_SHAPE;
-        auto kern = fa2_decode_kernel<D, F16, NT>;
+        auto kern = fa2_decode_kernel<D, F16, NT, VT>;
         if (lds > 48 * 1024) MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(Hq), dim3(NT), lds, st, q, K, ldk, V, ldv, o, sk, skd, Hq, Hkv);
+        hipLaunchKernelGGL(kern, dim3(Hq), dim3(NT), lds, st, q, K, ldk, V, ldv, o, sk, skd, skm, nslots, Hq, Hkv);
         return MH_LAUNCH_OK("fa2_decode");
     };
     if (Sq == 1) return decode_row(Q, O, Sk, sk_dev, sk_dev ? sk_max : Sk);
@@ -195,7 +204,7 @@ static int launch_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, c
     const int left = F16 ? (Tc ? Sk % Tc : 0) : Sk % 4;
     const int sk_eff = Tc * 4 + left;
     constexpr int R = PrefillCfg<D>::R;
-    hipLaunchKernelGGL((fa2_prefill_kernel<D, F16>), dim3((Sq + R - 1) / R, Hq), dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, sk_eff, Hq,
+    hipLaunchKernelGGL((fa2_prefill_kernel<D, F16, VT>), dim3((Sq + R - 1) / R, Hq), dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, sk_eff, Hq,
                        Hkv, causal);
     return MH_LAUNCH_OK("fa2_prefill");
 }
@@ -221,4 +230,17 @@ extern "C" int mllm_hip_fa2(const float *Q, int64_t ldq, const void *K, int64_t 
     default: return MLLM_HIP_ERR_SHAPE;
     }
 #undef FA2_CASE
+}
+
+// Prefill on the engine's own KV layout: K rows fp16 [Sk][Hkv*D] (ldk), V transposed fp16 [Hkv*D][ldvt] (kernels_decode.hip
+// reads the same slab).  Same arithmetic as mllm_hip_fa2 with kv_dtype fp16.
+extern "C" int mllm_hip_fa2_vt(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *Vt, int64_t ldvt, float *O, int64_t ldo, int Sq, int Sk,
+                               int Hq, int Hkv, int D, int causal, void *stream) {
+    if (Sq <= 0 || Sk <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || (ldk % 8) || (ldvt % 8)) return MLLM_HIP_ERR_SHAPE;
+    hipStream_t st = as_stream(stream);
+    switch (D) {
+    case 64: return launch_fa2<64, true, true>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, Sq, Sk, Hq, Hkv, causal, nullptr, Sk, st);
+    case 128: return launch_fa2<128, true, true>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, Sq, Sk, Hq, Hkv, causal, nullptr, Sk, st);
+    default: return MLLM_HIP_ERR_SHAPE;
+    }
 }

@@ -22,9 +22,6 @@
 
 #include "common.h"
 #include "decode_launch.h"
-#include "q4k_dot.h"
-#include "q40_dot.h"
-#include "kernels_attn_core.h"
 
 namespace mllm_hip {
 
@@ -47,9 +44,22 @@ __device__ unsigned long long g_stamps[8192 * 8];
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
+#define STAMPCLK(i)                                                                                      \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();                               \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+        }                                                                                                \
+    } while (0)
 #else
 #define STAMP(i)
 #endif
+}  // namespace mllm_hip
+#include "q4k_dot.h"
+#include "q40_dot.h"
+#include "kernels_attn_core.h"
+namespace mllm_hip {
 
 __device__ __forceinline__ float v_expf_dec(float x) {  // same polynomial as kernels_elem.hip v_expf (mllm_v_expf)
     const float r = 0x1.8p23f;
@@ -367,47 +377,50 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const float *__restr
 // dec_attn: one workgroup (1024 threads) per query head.  Rotates q and the new k with the step's sin/cos row (rope_hf:
 // fma(a,c,-(b*s)), fma(a,s,b*c)), rounds the new k, v to fp16 (what the reference's cache holds; the first head of a GQA group
 // appends them to the slab), then __fa2_decode over keys 0..T in key order (kernels_attn_core.h).
-// qkv: [Hq*D | Hkv*D | Hkv*D] fp32 of this token.  Slabs: [cache_limit][Hkv*D] fp16.  out: [Hq*D] fp32.
+// qkv: [Hq*D | Hkv*D | Hkv*D] fp32 of this token.  K slab [cache_limit][Hkv*D] fp16, V slab transposed [Hkv*D][vt_ld] fp16.  out: [Hq*D] fp32.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int DEC_ATTN_NT = 1024;
-static inline size_t dec_attn_lds(int cache_limit, int D) {
-    return (size_t)((cache_limit + 2) & ~1) * sizeof(float2) + (size_t)(2 * D + DEC_ATTN_NT / 64 + 2) * sizeof(float);
-}
 template <int D>
 __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
                                                                const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
-                                                               float *__restrict__ out, int Hq, int Hkv, int cache_limit) {
+                                                               float *__restrict__ out, int Hq, int Hkv, int cache_limit, int vt_ld, int nslots) {
     constexpr int HALF = D / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint16_t knew[D];
     __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
-    float2 *pc = reinterpret_cast<float2 *>(smem);
-    float *qs = reinterpret_cast<float *>(smem + (size_t)((cache_limit + 2) & ~1) * sizeof(float2));
-    float *ob = qs + D, *wred = ob + D;
+    const DecodeLds L = carve_decode(smem, cache_limit, D, DEC_ATTN_NT, nslots);
     const int tid = threadIdx.x;
     const int head = blockIdx.x, gsize = Hq / Hkv, kvh = head / gsize;
     const int HD = Hq * D, KVD = Hkv * D;
-    const int T = min(state->T, cache_limit - 1), Sk = T + 1;
+    // the step's own small operands first (vmcnt retires in issue order), then -- speculatively, T only masks them afterwards -- the
+    // slab rows of the first pass
+    STAMP(1);
+    const int T_raw = state->T;
+    float qa = 0.0f, qb = 0.0f, sn = 0.0f, cs = 0.0f;
+    if (tid < HALF) { const float *qp = qkv + head * D; qa = qp[tid]; qb = qp[tid + HALF]; sn = sin_t[tid]; cs = cos_t[tid]; }
+    else if (tid < D) { const float *kp = qkv + HD + kvh * D; qa = kp[tid - HALF]; qb = kp[tid]; sn = sin_t[tid - HALF]; cs = cos_t[tid - HALF]; }
+    else if (tid < 2 * D) qa = qkv[HD + KVD + kvh * D + (tid - D)];
+    __builtin_amdgcn_sched_barrier(0);
+    DecodePrefetch<D, true, DEC_ATTN_NT, true> P;
+    fa2_decode_prefetch<D, true, DEC_ATTN_NT, true>(P, kslab, KVD, vslab, vt_ld, kvh * D, cache_limit, nslots);
+    __builtin_amdgcn_sched_barrier(0);
+    const int T = min(T_raw, cache_limit - 1), Sk = T + 1;
     if (tid < HALF) {
-        const float *qp = qkv + head * D;
-        const float qa = qp[tid], qb = qp[tid + HALF], sn = sin_t[tid], cs = cos_t[tid];
-        qs[tid] = __fmaf_rn(qa, cs, -(qb * sn));
-        qs[tid + HALF] = __fmaf_rn(qa, sn, qb * cs);
+        L.qs[tid] = __fmaf_rn(qa, cs, -(qb * sn));
+        L.qs[tid + HALF] = __fmaf_rn(qa, sn, qb * cs);
     } else if (tid < D) {
-        const float *kp = qkv + HD + kvh * D;
-        const float ka = kp[tid - HALF], kb = kp[tid], sn = sin_t[tid - HALF], cs = cos_t[tid - HALF];
-        knew[tid - HALF] = f2h(__fmaf_rn(ka, cs, -(kb * sn)));
-        knew[tid] = f2h(__fmaf_rn(ka, sn, kb * cs));
+        knew[tid - HALF] = f2h(__fmaf_rn(qa, cs, -(qb * sn)));
+        knew[tid] = f2h(__fmaf_rn(qa, sn, qb * cs));
     } else if (tid < 2 * D) {
-        vnew[tid - D] = f2h(qkv[HD + KVD + kvh * D + (tid - D)]);
+        vnew[tid - D] = f2h(qa);
     }
     __syncthreads();
     if (head % gsize == 0 && tid < D) {
         kslab[(int64_t)T * KVD + kvh * D + tid] = knew[tid];
-        vslab[(int64_t)T * KVD + kvh * D + tid] = vnew[tid];
+        vslab[(int64_t)(kvh * D + tid) * vt_ld + T] = vnew[tid];
     }
-    fa2_decode_head<D, true, DEC_ATTN_NT>(qs, kslab, KVD, vslab, KVD, kvh * D, Sk, pc, wred, knew, vnew, T, ob);
-    if (tid < D) out[head * D + tid] = ob[tid];
+    fa2_decode_head<D, true, DEC_ATTN_NT, true>(L, P, kslab, KVD, vslab, vt_ld, kvh * D, Sk, cache_limit, knew, vnew, T);
+    if (tid < D) out[head * D + tid] = L.ob[tid];
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -650,12 +663,13 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         NS_DISPATCH(c.H, rc = launch_qkv<NS>(L, c, li == 0, x, x, st));
         return rc;
     case 1: {
-        uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.cache_limit * c.kv_heads * c.D;
-        const size_t lds = dec_attn_lds(c.cache_limit, c.D);
+        uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.kv_heads * c.D * c.vt_ld;
+        const int nslots = decode_lds_slots(c.cache_limit, c.D, DEC_ATTN_NT, 2, true);
+        const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
         rc = allow_lds(dec_attn_kernel<128>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((dec_attn_kernel<128>), dim3(c.heads), dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads,
-                           c.kv_heads, c.cache_limit);
+                           c.kv_heads, c.cache_limit, c.vt_ld, nslots);
         return MH_LAUNCH_OK("dec_attn");
     }
     case 2:

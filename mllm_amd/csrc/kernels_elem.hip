@@ -368,6 +368,14 @@ __global__ __launch_bounds__(256) void rope_apply_kernel(const float *__restrict
         else { reinterpret_cast<float *>(out)[o] = v1; reinterpret_cast<float *>(out)[o + half] = v2; }
     }
 }
+// transposed variant: out[c * ldo + s] (the engine's V slab keeps one row per (kv head, dim) so a decode lane reads its dim contiguously in keys)
+__global__ __launch_bounds__(256) void store_f16_t_kernel(const float *__restrict__ x, int64_t ldx, uint16_t *__restrict__ out, int64_t ldo, int S, int n) {
+    const int64_t total = (int64_t)S * n;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c = (int)(t / S), s_ = (int)(t % S);
+        out[(int64_t)c * ldo + s_] = f2h(x[(int64_t)s_ * ldx + c]);
+    }
+}
 __global__ __launch_bounds__(256) void store_f16_kernel(const float *__restrict__ x, int64_t ldx, uint16_t *__restrict__ out, int64_t ldo, int S, int n) {
     const int64_t total = (int64_t)S * n;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -530,6 +538,11 @@ extern "C" int mllm_hip_store_f16(const float *x, int64_t ldx, uint16_t *out, in
     if (S <= 0 || n <= 0) return MLLM_HIP_OK;
     hipLaunchKernelGGL(store_f16_kernel, dim3(grid_for((int64_t)S * n, 256)), dim3(256), 0, as_stream(stream), x, ldx, out, ldo, S, n);
     return MH_LAUNCH_OK("store_f16");
+}
+extern "C" int mllm_hip_store_f16_t(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *stream) {
+    if (S <= 0 || n <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(store_f16_t_kernel, dim3(grid_for((int64_t)S * n, 256)), dim3(256), 0, as_stream(stream), x, ldx, out, ldo, S, n);
+    return MH_LAUNCH_OK("store_f16_t");
 }
 extern "C" int mllm_hip_im2patch_hcw(const float *img, float *patches, int H, int C, int W, int p, void *stream) {
     if (H % p || W % p) return MLLM_HIP_ERR_SHAPE;

@@ -227,6 +227,18 @@ def flash_attention2(q, k, v, Sq, Sk, Hq, Hkv, D, causal, sk_dev=None):
     return o
 
 
+def flash_attention2_vt(q, k16, v_f32, Sq, Sk, Hq, Hkv, D, causal):
+    """Same attention on the resident engine's KV layout: K fp16 rows, V stored transposed (mllm_hip_store_f16_t) with padded rows."""
+    q, k16, v_f32 = _dev(q, torch.float32), _dev(k16, torch.float16), _dev(v_f32, torch.float32)
+    ld = ((Sk + 63) // 64) * 64 + 128
+    vt = torch.zeros((Hkv * D, ld), dtype=torch.float16, device="cuda")
+    check(L.load().mllm_hip_store_f16_t(vp(v_f32), i64(Hkv * D), vp(vt), i64(ld), C.c_int(Sk), C.c_int(Hkv * D), _stream()), "store_f16_t")
+    o = torch.empty((Sq, Hq * D), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_fa2_vt(vp(q), i64(Hq * D), vp(k16), i64(Hkv * D), vp(vt), i64(ld), vp(o), i64(Hq * D), C.c_int(Sq), C.c_int(Sk), C.c_int(Hq),
+                                   C.c_int(Hkv), C.c_int(D), C.c_int(int(causal)), _stream()), "fa2_vt")
+    return o
+
+
 def patch_gemm(patches, W, bias=None):
     patches, W = _dev(patches, torch.float32), _dev(W, torch.float32)
     N, KK = patches.shape

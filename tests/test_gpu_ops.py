@@ -280,6 +280,18 @@ def test_fa2_vs_oracle(Sq, Sk, Hq, Hkv, D, causal, f16):
     assert eq(o, ref), md(o, ref)
 
 
+@pytest.mark.parametrize("Sq,Sk,Hq,Hkv,D", [(282, 282, 12, 2, 128), (40, 40, 12, 2, 128), (1, 300, 12, 2, 128), (3, 50, 4, 2, 64), (21, 23, 4, 2, 128), (1, 1, 2, 1, 128)])
+def test_fa2_on_the_engine_kv_layout(Sq, Sk, Hq, Hkv, D):
+    """K fp16 rows + V transposed fp16 (the resident slab layout): same bits as the reference layout."""
+    r = rng(Sq + 7 * Sk)
+    q = r.standard_normal((Sq, Hq * D)).astype(np.float32)
+    k16 = r.standard_normal((Sk, Hkv * D)).astype(np.float16)
+    v = r.standard_normal((Sk, Hkv * D)).astype(np.float32)
+    o = ops.flash_attention2_vt(q, torch.from_numpy(k16), v, Sq, Sk, Hq, Hkv, D, True)
+    ref = orc.attention(q, k16.view(np.uint16), v.astype(np.float16).view(np.uint16), Sq, Sk, Hq, Hkv, D, True)
+    assert eq(o, ref), md(o, ref)
+
+
 def test_fa2_online_softmax_rescale_is_forced():
     """A spiked late key forces the running max to jump in the last tile (rescale branch of the online softmax)."""
     Sq = Sk = 96
