@@ -21,6 +21,34 @@ namespace mllm_hip {
 // ------------------------------------------------------------------------------------------------------------------
 // Sq >= 4: __fa2_prefill_append with Br = Bc = 4.  One workgroup = one head x RT consecutive row tiles.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int FA_VS = 64;   // keys per staged V sub-chunk
+template <int D, bool F16, bool VT>
+struct VStage {
+    static constexpr int ELT = F16 ? 2 : 4;
+    static constexpr int ROWV = VT ? FA_VS * 2 / 16 : D * ELT / 16;       // 16-byte vectors per staged row
+    static constexpr int VEC = VT ? D * ROWV : FA_VS * ROWV;              // vectors per sub-chunk
+    static constexpr int PITCH = FA_VS * 2 + 16;
+};
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int D, bool F16, bool VT, int N>
+__device__ __forceinline__ void vs_fetch(u32x4 (&stage)[N], const void *V, int64_t ldv, int kvh, int key0, int Sk) {
+    using G = VStage<D, F16, VT>;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int vi = min((int)threadIdx.x + 256 * i, G::VEC - 1), row = vi / G::ROWV, part = vi % G::ROWV;
+        if (VT) stage[i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint16_t *>(V) + (int64_t)(kvh * D + row) * ldv + key0 + part * 8);
+        else stage[i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(V) + ((int64_t)min(key0 + row, Sk - 1) * ldv + kvh * D) * G::ELT + part * 16);
+    }
+}
+template <int D, bool F16, bool VT, int N>
+__device__ __forceinline__ void vs_park(const u32x4 (&stage)[N], char *buf) {
+    using G = VStage<D, F16, VT>;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int vi = threadIdx.x + 256 * i, row = vi / G::ROWV, part = vi % G::ROWV;
+        if (vi < G::VEC) *reinterpret_cast<u32x4 *>(buf + (VT ? (size_t)row * G::PITCH + part * 16 : (size_t)vi * 16)) = stage[i];
+    }
+}
 template <int D>
 struct PrefillCfg {
     static constexpr int RT = (256 / D) < 1 ? 1 : ((256 / D) > 4 ? 4 : (256 / D));   // row tiles per workgroup
@@ -40,6 +68,13 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
     __shared__ __attribute__((aligned(16))) float Cc[RT * 64 * 4];
     __shared__ __attribute__((aligned(16))) float Sm[RT * 64 * 4];
     __shared__ float m_in[R], lfin[R];
+    constexpr int ELT = F16 ? 2 : 4;
+    constexpr int VS_ROWV = VT ? FA_VS * 2 / 16 : D * ELT / 16;       // 16-byte vectors per staged row
+    constexpr int VS_VEC = VT ? D * VS_ROWV : FA_VS * VS_ROWV;        // vectors per sub-chunk
+    constexpr int VSV = (VS_VEC + 255) / 256;                         // per thread
+    constexpr int VS_PITCH = FA_VS * 2 + 16;
+    constexpr int VS_BYTES = VT ? D * VS_PITCH : FA_VS * D * ELT;
+    __shared__ __attribute__((aligned(16))) char vbuf[2 * VS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int head = blockIdx.y, kvh = head / (Hq / Hkv);
     const int r0 = blockIdx.x * R;
@@ -108,33 +143,51 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
             if (lane == 0) m_in[r] = last;
         }
         __syncthreads();
-        // ---- C: rescale + P V in key order -------------------------------------------------------------------------------
-        if (own) {
+        // ---- C: rescale + P V in key order.  The walk must not wait on memory: V goes through LDS in sub-chunks of FA_VS keys (double
+        // buffered; all 256 threads fetch sub-chunk s+1 while sub-chunk s is walked).  Layout in LDS: reference layout [key][D] as stored
+        // (fp32 or fp16), transposed slab [D][FA_VS keys] fp16 (pitch VS_PITCH bytes).
+        {
             const int ntl = min(64, (klim - chunk0 + 3) >> 2);
+            const int nsub = (ntl * 4 + FA_VS - 1) / FA_VS;
+            u32x4 stage[VSV];
+            vs_fetch<D, F16, VT, VSV>(stage, V, ldv, kvh, chunk0, Sk);
+#pragma unroll
+            for (int sc = 0; sc < FA_KC / FA_VS; ++sc) {     // fully unrolled: `stage` stays in registers across the prefetch
+                if (sc >= nsub) break;
+                vs_park<D, F16, VT, VSV>(stage, vbuf + (size_t)(sc & 1) * VS_BYTES);
+                __syncthreads();
+                if (sc + 1 < nsub) vs_fetch<D, F16, VT, VSV>(stage, V, ldv, kvh, chunk0 + (sc + 1) * FA_VS, Sk);
+                if (own) {
+                    const char *vb = vbuf + (size_t)(sc & 1) * VS_BYTES;
+                    const int t1 = min(ntl, (sc + 1) * (FA_VS / 4));
 #pragma unroll 2
-            for (int tl = 0; tl < ntl; ++tl) {
-                const float4 c4 = *reinterpret_cast<const float4 *>(Cc + (g * 64 + tl) * 4);
-                float vv[4];
-                if (VT) {
-                    const uint2 w = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(V) + (int64_t)(kvh * D + d) * ldv + chunk0 + 4 * tl);
-                    vv[0] = h2f((uint16_t)(w.x & 0xffff)); vv[1] = h2f((uint16_t)(w.x >> 16));
-                    vv[2] = h2f((uint16_t)(w.y & 0xffff)); vv[3] = h2f((uint16_t)(w.y >> 16));
-                } else {
+                    for (int tl = sc * (FA_VS / 4); tl < t1; ++tl) {
+                        const int kl = 4 * tl - sc * FA_VS;     // first key of the tile inside the sub-chunk
+                        const float4 c4 = *reinterpret_cast<const float4 *>(Cc + (g * 64 + tl) * 4);
+                        float vv[4];
+                        if (VT) {
+                            const uint2 w = *reinterpret_cast<const uint2 *>(vb + (size_t)d * VS_PITCH + kl * 2);
+                            vv[0] = h2f((uint16_t)(w.x & 0xffff)); vv[1] = h2f((uint16_t)(w.x >> 16));
+                            vv[2] = h2f((uint16_t)(w.y & 0xffff)); vv[3] = h2f((uint16_t)(w.y >> 16));
+                        } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) vv[k] = kv_at<F16>(V, (int64_t)min(chunk0 + 4 * tl + k, Sk - 1) * ldv + kvh * D + d);
-                }
-                const float cr[4] = {c4.x, c4.y, c4.z, c4.w};
+                            for (int k = 0; k < 4; ++k)
+                                vv[k] = F16 ? h2f(reinterpret_cast<const uint16_t *>(vb)[(kl + k) * D + d]) : reinterpret_cast<const float *>(vb)[(kl + k) * D + d];
+                        }
+                        const float cr[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 p = *reinterpret_cast<const float4 *>(S + (4 * g + r) * SP + 4 * tl);
-                    float a = o[r] * cr[r];
-                    a = __fmaf_rn(p.x, vv[0], a);
-                    a = __fmaf_rn(p.y, vv[1], a);
-                    a = __fmaf_rn(p.z, vv[2], a);
-                    a = __fmaf_rn(p.w, vv[3], a);
-                    o[r] = a;
+                        for (int r = 0; r < 4; ++r) {
+                            const float4 p = *reinterpret_cast<const float4 *>(S + (4 * g + r) * SP + 4 * tl);
+                            float a = o[r] * cr[r];
+                            a = __fmaf_rn(p.x, vv[0], a);
+                            a = __fmaf_rn(p.y, vv[1], a);
+                            a = __fmaf_rn(p.z, vv[2], a);
+                            a = __fmaf_rn(p.w, vv[3], a);
+                            o[r] = a;
+                        }
+                        if (d < 4) lsum = __fmaf_rn(lsum, Cc[(g * 64 + tl) * 4 + d], Sm[(g * 64 + tl) * 4 + d]);
+                    }
                 }
-                if (d < 4) lsum = __fmaf_rn(lsum, Cc[(g * 64 + tl) * 4 + d], Sm[(g * 64 + tl) * 4 + d]);
             }
         }
         __syncthreads();

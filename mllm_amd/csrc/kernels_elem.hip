@@ -114,17 +114,25 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float *__restrict__
                 const float *rowp = &buf[c & 1][tid * LN_PITCH];
                 const int n = min(LN_CH, dim - c * LN_CH);
                 int k = 0;
+                // 16 values per step, all four LDS reads issued before the dependent chain (the chain never waits on LDS latency)
                 if (pass == 0) {
-                    for (; k + 4 <= n; k += 4) {
-                        const float4 v = *reinterpret_cast<const float4 *>(rowp + k);
-                        acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
+                    for (; k + 16 <= n; k += 16) {
+                        const float4 v0 = *reinterpret_cast<const float4 *>(rowp + k), v1 = *reinterpret_cast<const float4 *>(rowp + k + 4);
+                        const float4 v2 = *reinterpret_cast<const float4 *>(rowp + k + 8), v3 = *reinterpret_cast<const float4 *>(rowp + k + 12);
+                        acc = acc + v0.x; acc = acc + v0.y; acc = acc + v0.z; acc = acc + v0.w;
+                        acc = acc + v1.x; acc = acc + v1.y; acc = acc + v1.z; acc = acc + v1.w;
+                        acc = acc + v2.x; acc = acc + v2.y; acc = acc + v2.z; acc = acc + v2.w;
+                        acc = acc + v3.x; acc = acc + v3.y; acc = acc + v3.z; acc = acc + v3.w;
                     }
                     for (; k < n; ++k) acc = acc + rowp[k];
                 } else {
-                    for (; k + 4 <= n; k += 4) {
-                        const float4 v = *reinterpret_cast<const float4 *>(rowp + k);
-                        const float c0 = v.x - mean, c1 = v.y - mean, c2 = v.z - mean, c3 = v.w - mean;
-                        acc = __fmaf_rn(c0, c0, acc); acc = __fmaf_rn(c1, c1, acc); acc = __fmaf_rn(c2, c2, acc); acc = __fmaf_rn(c3, c3, acc);
+                    for (; k + 16 <= n; k += 16) {
+                        const float4 v0 = *reinterpret_cast<const float4 *>(rowp + k), v1 = *reinterpret_cast<const float4 *>(rowp + k + 4);
+                        const float4 v2 = *reinterpret_cast<const float4 *>(rowp + k + 8), v3 = *reinterpret_cast<const float4 *>(rowp + k + 12);
+                        const float cc[16] = {v0.x - mean, v0.y - mean, v0.z - mean, v0.w - mean, v1.x - mean, v1.y - mean, v1.z - mean, v1.w - mean,
+                                              v2.x - mean, v2.y - mean, v2.z - mean, v2.w - mean, v3.x - mean, v3.y - mean, v3.z - mean, v3.w - mean};
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc = __fmaf_rn(cc[e], cc[e], acc);
                     }
                     for (; k < n; ++k) { const float cc = rowp[k] - mean; acc = __fmaf_rn(cc, cc, acc); }
                 }

@@ -251,40 +251,73 @@ __global__ __launch_bounds__(256) void gemm_q4k_kernel(const uint8_t *__restrict
     for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
     const v8h hz = {0, 0, 0, 0, 0, 0, 0, 0};
 
+    // One wave per SIMD (the 12 chains of a 32x32 tile fill the accumulation registers), so memory latency is hidden by the
+    // wave itself: the operands of half a super-block (4 classes = 8 A + 8 B fragments) are requested one half ahead of the
+    // MFMAs that consume them.  Even halves (classes 0..3, with the block's scales) live in *0, odd halves (classes 4..7, with
+    // the mins operands) in *1.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    v8h a0[8], b0[8], a1[8], b1[8];
+    v4h am[4], bm[4];
+    f32x4 adx[4];
+    f32x2 dwv;
+#define LOAD_EVEN(i_)                                                                                     \
+    {                                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                   \
+            const size_t o = ((size_t)(i_) * 8 + (q >> 1)) * 2 * 64 + (q & 1) * 64;                       \
+            a0[q] = Ax[o]; b0[q] = Bw[o];                                                                 \
+        }                                                                                                 \
+        _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) adx[g4] = *reinterpret_cast<const f32x4 *>(Ad + (size_t)(i_) * 32 + 8 * g4); \
+        dwv = *reinterpret_cast<const f32x2 *>(Bd + (size_t)(i_) * 32);                                   \
+    }
+#define LOAD_ODD(i_)                                                                                      \
+    {                                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                   \
+            const size_t o = ((size_t)(i_) * 8 + 4 + (q >> 1)) * 2 * 64 + (q & 1) * 64;                   \
+            a1[q] = Ax[o]; b1[q] = Bw[o];                                                                 \
+        }                                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) { am[u] = Am[((size_t)(i_) * 4 + u) * 32]; bm[u] = Bm[((size_t)(i_) * 4 + u) * 32]; } \
+    }
+    LOAD_EVEN(0)
     for (int i = 0; i < nb; ++i) {
-        const float2 dw = Bd[(size_t)i * 32];
+        LOAD_ODD(i)
         float dd[16], dm[16];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 dx = *reinterpret_cast<const float4 *>(Ad + (size_t)i * 32 + 8 * g4);   // rows 8 g4 + 4h + (0..3)
-            const float dxs[4] = {dx.x, dx.y, dx.z, dx.w};
+        for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                dd[4 * g4 + e] = dxs[e] * dw.x;        // y.d * fp16(x.d)
-                dm[4 * g4 + e] = (-dxs[e]) * dw.y;     // -y.d * fp16(x.dmin)
+                dd[4 * g4 + e] = adx[g4][e] * dwv[0];        // y.d * fp16(x.d)
+                dm[4 * g4 + e] = (-adx[g4][e]) * dwv[1];     // -y.d * fp16(x.dmin)
             }
-        }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const size_t o = ((size_t)i * 8 + t) * 2 * 64;
-            v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ax[o], Bw[o], zero, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ax[o + 64], Bw[o + 64], c, 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[2 * t], b0[2 * t], zero, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[2 * t + 1], b0[2 * t + 1], c, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = __fmaf_rn(dd[r], c[r], acc[t][r]);
+        }
+        if (i + 1 < nb) LOAD_EVEN(i + 1)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[2 * t], b1[2 * t], zero, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[2 * t + 1], b1[2 * t + 1], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[4 + t][r] = __fmaf_rn(dd[r], c[r], acc[4 + t][r]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             v8h a = hz, b = hz;
             if (h == 0) {
-                const v4h a4 = Am[((size_t)i * 4 + u) * 32], b4 = Bm[((size_t)i * 4 + u) * 32];
-                a[0] = a4[0]; a[1] = a4[1]; a[2] = a4[2]; a[3] = a4[3];
-                b[0] = b4[0]; b[1] = b4[1]; b[2] = b4[2]; b[3] = b4[3];
+                a[0] = am[u][0]; a[1] = am[u][1]; a[2] = am[u][2]; a[3] = am[u][3];
+                b[0] = bm[u][0]; b[1] = bm[u][1]; b[2] = bm[u][2]; b[3] = bm[u][3];
             }
             const v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, zero, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) accm[u][r] = __fmaf_rn(dm[r], c[r], accm[u][r]);
         }
     }
+#undef LOAD_EVEN
+#undef LOAD_ODD
     const int n = nt * 32 + col;
     if (n >= N) return;
     const float bv = bias ? bias[n] : 0.0f;
