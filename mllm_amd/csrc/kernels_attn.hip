@@ -21,184 +21,188 @@ namespace mllm_hip {
 // ------------------------------------------------------------------------------------------------------------------
 // Sq >= 4: __fa2_prefill_append with Br = Bc = 4.  One workgroup = one head x RT consecutive row tiles.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int FA_VS = 64;   // keys per staged V sub-chunk
-template <int D, bool F16, bool VT>
-struct VStage {
-    static constexpr int ELT = F16 ? 2 : 4;
-    static constexpr int ROWV = VT ? FA_VS * 2 / 16 : D * ELT / 16;       // 16-byte vectors per staged row
-    static constexpr int VEC = VT ? D * ROWV : FA_VS * ROWV;              // vectors per sub-chunk
-    static constexpr int PITCH = FA_VS * 2 + 16;
-};
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int D, bool F16, bool VT, int N>
-__device__ __forceinline__ void vs_fetch(u32x4 (&stage)[N], const void *V, int64_t ldv, int kvh, int key0, int Sk) {
-    using G = VStage<D, F16, VT>;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int vi = min((int)threadIdx.x + 256 * i, G::VEC - 1), row = vi / G::ROWV, part = vi % G::ROWV;
-        if (VT) stage[i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint16_t *>(V) + (int64_t)(kvh * D + row) * ldv + key0 + part * 8);
-        else stage[i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(V) + ((int64_t)min(key0 + row, Sk - 1) * ldv + kvh * D) * G::ELT + part * 16);
-    }
-}
-template <int D, bool F16, bool VT, int N>
-__device__ __forceinline__ void vs_park(const u32x4 (&stage)[N], char *buf) {
-    using G = VStage<D, F16, VT>;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int vi = threadIdx.x + 256 * i, row = vi / G::ROWV, part = vi % G::ROWV;
-        if (vi < G::VEC) *reinterpret_cast<u32x4 *>(buf + (VT ? (size_t)row * G::PITCH + part * 16 : (size_t)vi * 16)) = stage[i];
-    }
-}
-template <int D>
-struct PrefillCfg {
-    static constexpr int RT = (256 / D) < 1 ? 1 : ((256 / D) > 4 ? 4 : (256 / D));   // row tiles per workgroup
-    static constexpr int R = 4 * RT;
-    static constexpr int SP = FA_KC + 4;   // pitch of the score rows
-};
+// ------------------------------------------------------------------------------------------------------------------
+// Sq >= 4: __fa2_prefill_append with Br = Bc = 4, on the matrix cores.
+//
+// v_mfma_f32_32x32x2_f32 accumulates C = fma(a1, b1, fma(a0, b0, C)) -- an exact fp32 fma chain in k order (checked on the
+// device: scratch/mfma/test.hip, 0 mismatches against fmaf chains) -- so the reference's chains map onto it unchanged:
+//   scores   chain l of (row, key) takes d = 8 i + l, i ascending: one accumulator tile per l, operands (d = 8(2s+h)+l) for MFMA s;
+//            wave w owns chains 2w and 2w+1; the 8 tiles meet in LDS and are folded ((l0+l4)+(l1+l5)) + ((l2+l6)+(l3+l7));
+//   softmax  thread (row, key tile): tile maximum, prefix maximum over the 8 tiles of the chunk (+ the carried maximum),
+//            c = expf((m - m') scale), p = expf((s - m') scale), sum = ((p0+p1)+p2)+p3; logsum = fma(logsum, c, sum) per row;
+//   P V      o[row][d] = fma(p_j, v_j[d], o[row][d]) in key order = MFMAs over key pairs; the rescale o *= c sits between key
+//            tiles and is executed only for tiles in which some row's maximum moved (c is exactly 1.0f otherwise).
+// One workgroup = one head x 32 query rows (8 row tiles); key chunks of 32 (8 key tiles); wave w of the P V phase owns dims
+// 32w .. 32w+31.  K and V chunks are staged in LDS as fp32 (K pitch D+1, transposed-slab V pitch 33: conflict-free operand reads).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FA_R = 32, FA_KCH = 32;
+typedef float v16f_t __attribute__((ext_vector_type(16)));
 
-// VT: V is the transposed fp16 slab (element (key j, dim d) at V[(kvh*D + d) * ldv + j], ldv % 4 == 0, rows zero padded)
 template <int D, bool F16, bool VT = false>
 __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restrict__ Q, int64_t ldq, const void *__restrict__ K, int64_t ldk,
                                                           const void *__restrict__ V, int64_t ldv, float *__restrict__ O, int64_t ldo, int Sq, int Sk,
                                                           int sk_eff, int Hq, int Hkv, int causal) {
-    using C = PrefillCfg<D>;
-    constexpr int RT = C::RT, R = C::R, SP = C::SP;
-    __shared__ __attribute__((aligned(16))) float qs[R * D];
-    __shared__ __attribute__((aligned(16))) float S[R * SP];
-    __shared__ __attribute__((aligned(16))) float Cc[RT * 64 * 4];
-    __shared__ __attribute__((aligned(16))) float Sm[RT * 64 * 4];
-    __shared__ float m_in[R], lfin[R];
-    constexpr int ELT = F16 ? 2 : 4;
-    constexpr int VS_ROWV = VT ? FA_VS * 2 / 16 : D * ELT / 16;       // 16-byte vectors per staged row
-    constexpr int VS_VEC = VT ? D * VS_ROWV : FA_VS * VS_ROWV;        // vectors per sub-chunk
-    constexpr int VSV = (VS_VEC + 255) / 256;                         // per thread
-    constexpr int VS_PITCH = FA_VS * 2 + 16;
-    constexpr int VS_BYTES = VT ? D * VS_PITCH : FA_VS * D * ELT;
-    __shared__ __attribute__((aligned(16))) char vbuf[2 * VS_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    static_assert(D % 16 == 0 && D <= 128, "head dim");
+    constexpr int NS = D / 16;              // MFMAs per score chain
+    constexpr int KP = D + 1;               // K row pitch in LDS (odd: the per-key column reads are conflict-free)
+    constexpr int VP = VT ? 33 : D;         // V: [key][D] as stored, or [d][33] from the transposed slab
+    constexpr int NDT = (D + 31) / 32;      // 32-wide dim tiles of the output
+    constexpr int KE = FA_KCH * D / 256;    // staged elements per thread and operand
+    __shared__ float Ks[FA_KCH * KP];
+    __shared__ float Vs[VT ? D * 33 : FA_KCH * D];
+    __shared__ float Part[8 * 32 * 33];
+    __shared__ float P[32 * 33];
+    __shared__ float Cc[32 * 8], Sm[32 * 8];
+    __shared__ float m_in[32], l_s[32];
+    __shared__ int moved_any[8];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, kvh = head / (Hq / Hkv);
-    const int r0 = blockIdx.x * R;
+    const int r0 = blockIdx.x * FA_R;
     const int delta = Sk - Sq;
     const float scale = 1.0f / sqrtf((float)D);
-    for (int i = tid; i < R * D; i += 256) {
-        const int r = i / D, d = i - r * D;
-        qs[i] = Q[(int64_t)min(r0 + r, Sq - 1) * ldq + head * D + d];
+    // this lane's query operands: row r0 + col, dims 8(2s+h) + l for the wave's two chains
+    float qreg[2][NS];
+    {
+        const float *qrow = Q + (int64_t)min(r0 + col, Sq - 1) * ldq + head * D;
+#pragma unroll
+        for (int l2 = 0; l2 < 2; ++l2)
+#pragma unroll
+            for (int sI = 0; sI < NS; ++sI) qreg[l2][sI] = qrow[8 * (2 * sI + h) + 2 * wid + l2];
     }
-    if (tid < R) m_in[tid] = FA_NEG;
-    // phase-C ownership: thread (g, d) accumulates rows 4g..4g+3 of dim d; threads d < 4 also carry logsum of row 4g + d
-    const int g = tid / D, d = tid - g * D;
-    const bool own = g < RT;
-    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lsum = 0.0f;
+    if (tid < 32) { m_in[tid] = FA_NEG; l_s[tid] = 0.0f; }
     int klim = sk_eff;
-    if (causal) klim = min(sk_eff, r0 + R + delta + 4);   // tiles beyond are skipped for every row of this workgroup
-    __syncthreads();
-    for (int chunk0 = 0; chunk0 < klim; chunk0 += FA_KC) {
-        // ---- A: scores of key chunk0 + tid against the R rows -------------------------------------------------------
-        {
-            const int j = chunk0 + tid;
-            float kr[D];
-            load_kv_row<D, F16>(kr, K, (int64_t)min(j, Sk - 1) * ldk + kvh * D);
-            const int c0 = j & ~3, nc = min(4, sk_eff - c0);
-#pragma unroll 1
-            for (int r = 0; r < R; ++r) {
-                float s = qk_dot<D>(qs + r * D, kr);
-                const int tr0 = r0 + (r & ~3), nr = min(4, Sq - tr0);
-                if (causal && (tr0 + nr == c0 + nc - delta) && (j - c0) > (r & 3)) s = FA_NEG;
-                S[r * SP + tid] = s;
+    if (causal) klim = min(sk_eff, r0 + FA_R + delta + 4);   // tiles beyond are skipped for every row of this workgroup
+    v16f_t oacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[i] = 0.0f;
+    // staging registers (the next chunk is requested while the current one is consumed)
+    float kst[KE], vst[KE];
+    auto fetch = [&](int chunk0) {
+#pragma unroll
+        for (int i = 0; i < KE; ++i) {
+            const int e = tid + 256 * i;
+            {
+                const int key = e / D, dd = e - key * D;
+                kst[i] = kv_at<F16>(K, (int64_t)min(chunk0 + key, Sk - 1) * ldk + kvh * D + dd);
+            }
+            if (VT) {
+                const int dd = e / FA_KCH, key = e - dd * FA_KCH;
+                vst[i] = h2f(reinterpret_cast<const uint16_t *>(V)[(int64_t)(kvh * D + dd) * ldv + chunk0 + key]);
+            } else {
+                const int key = e / D, dd = e - key * D;
+                vst[i] = kv_at<F16>(V, (int64_t)min(chunk0 + key, Sk - 1) * ldv + kvh * D + dd);
             }
         }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < KE; ++i) {
+            const int e = tid + 256 * i;
+            { const int key = e / D, dd = e - key * D; Ks[key * KP + dd] = kst[i]; }
+            if (VT) { const int dd = e / FA_KCH, key = e - dd * FA_KCH; Vs[dd * 33 + key] = vst[i]; }
+            else Vs[e] = vst[i];
+        }
+    };
+    fetch(0);
+    for (int chunk0 = 0; chunk0 < klim; chunk0 += FA_KCH) {
+        __syncthreads();                       // the previous chunk's P V has finished with Ks / Vs / P
+        park();
+        if (tid < 8) moved_any[tid] = 0;
         __syncthreads();
-        // ---- B: per row, scan the 64 key tiles of the chunk ----------------------------------------------------------
-        for (int r = wid; r < R; r += 4) {
-            const int c0 = chunk0 + 4 * lane;
-            const int tr0 = r0 + (r & ~3), nr = min(4, Sq - tr0);
+        if (chunk0 + FA_KCH < klim) fetch(chunk0 + FA_KCH);
+        // ---- scores: two chains per wave --------------------------------------------------------------------------------------
+#pragma unroll
+        for (int l2 = 0; l2 < 2; ++l2) {
+            const int l = 2 * wid + l2;
+            v16f_t acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int sI = 0; sI < NS; ++sI) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[l2][sI], Ks[col * KP + 8 * (2 * sI + h) + l], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Part[(l * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 33 + col] = acc[i];
+        }
+        __syncthreads();
+        // ---- fold the chains, mask, softmax of (row, key tile) ----------------------------------------------------------------------
+        {
+            const int row = tid >> 3, tile = tid & 7;
+            const int c0 = chunk0 + 4 * tile;
+            const int tr0 = r0 + (row & ~3), nr = min(4, Sq - tr0);
             const int nc = min(4, sk_eff - c0);
             const bool live = nc > 0 && nr > 0 && !(causal && (c0 - delta > tr0 + nr - 1));
-            const float4 s4 = *reinterpret_cast<const float4 *>(S + r * SP + 4 * lane);
+            const bool diag = causal && (tr0 + nr == c0 + nc - delta);
+            float s4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float *pp = Part + row * 33 + 4 * tile + e;
+                float v = ((pp[0 * 1056] + pp[4 * 1056]) + (pp[1 * 1056] + pp[5 * 1056])) + ((pp[2 * 1056] + pp[6 * 1056]) + (pp[3 * 1056] + pp[7 * 1056]));
+                if (diag && e > (row & 3)) v = FA_NEG;
+                s4[e] = v;
+            }
             float tm = FA_NEG;
             if (live) {
-                tm = s4.x;
-                if (nc > 1) tm = fmaxf(tm, s4.y);
-                if (nc > 2) tm = fmaxf(tm, s4.z);
-                if (nc > 3) tm = fmaxf(tm, s4.w);
+                tm = s4[0];
+                if (nc > 1) tm = fmaxf(tm, s4[1]);
+                if (nc > 2) tm = fmaxf(tm, s4[2]);
+                if (nc > 3) tm = fmaxf(tm, s4[3]);
             }
-            const float carry = m_in[r];
-            const float incl = fmaxf(wave_scan_max(tm), carry);
-            const float excl = wave_shift_up(incl, carry);
-            float4 p4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            float cc = 1.0f, sum = 0.0f;
+            // prefix maximum over the 8 tiles of this row (8 consecutive lanes), then the carried maximum
+            float sc = tm;
+            { const float t = MH_DPPF(sc, sc, 0x111, 0xF); sc = tile >= 1 ? fmaxf(sc, t) : sc; }
+            { const float t = MH_DPPF(sc, sc, 0x112, 0xF); sc = tile >= 2 ? fmaxf(sc, t) : sc; }
+            { const float t = MH_DPPF(sc, sc, 0x114, 0xF); sc = tile >= 4 ? fmaxf(sc, t) : sc; }
+            const float carry = m_in[row];
+            const float incl = fmaxf(sc, carry);
+            const float prev = MH_DPPF(incl, incl, 0x111, 0xF);
+            const float excl = tile == 0 ? carry : prev;
+            float p4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, cc = 1.0f, sum = 0.0f;
             if (live) {
-                cc = excl == incl ? 1.0f : glibc_expf((excl - incl) * scale);
-                p4.x = glibc_expf((s4.x - incl) * scale);
-                if (nc > 1) p4.y = glibc_expf((s4.y - incl) * scale);
-                if (nc > 2) p4.z = glibc_expf((s4.z - incl) * scale);
-                if (nc > 3) p4.w = glibc_expf((s4.w - incl) * scale);
-                sum = ((p4.x + p4.y) + p4.z) + p4.w;
+                if (excl != incl) { cc = glibc_expf((excl - incl) * scale); moved_any[tile] = 1; }
+                p4[0] = glibc_expf((s4[0] - incl) * scale);
+                if (nc > 1) p4[1] = glibc_expf((s4[1] - incl) * scale);
+                if (nc > 2) p4[2] = glibc_expf((s4[2] - incl) * scale);
+                if (nc > 3) p4[3] = glibc_expf((s4[3] - incl) * scale);
+                sum = ((p4[0] + p4[1]) + p4[2]) + p4[3];
             }
-            *reinterpret_cast<float4 *>(S + r * SP + 4 * lane) = p4;
-            Cc[((r >> 2) * 64 + lane) * 4 + (r & 3)] = cc;
-            Sm[((r >> 2) * 64 + lane) * 4 + (r & 3)] = sum;
-            const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P[row * 33 + 4 * tile + e] = p4[e];
+            Cc[row * 8 + tile] = cc;
+            Sm[row * 8 + tile] = sum;
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) m_in[r] = last;
+            if (tile == 7) m_in[row] = incl;
         }
         __syncthreads();
-        // ---- C: rescale + P V in key order.  The walk must not wait on memory: V goes through LDS in sub-chunks of FA_VS keys (double
-        // buffered; all 256 threads fetch sub-chunk s+1 while sub-chunk s is walked).  Layout in LDS: reference layout [key][D] as stored
-        // (fp32 or fp16), transposed slab [D][FA_VS keys] fp16 (pitch VS_PITCH bytes).
-        {
-            const int ntl = min(64, (klim - chunk0 + 3) >> 2);
-            const int nsub = (ntl * 4 + FA_VS - 1) / FA_VS;
-            u32x4 stage[VSV];
-            vs_fetch<D, F16, VT, VSV>(stage, V, ldv, kvh, chunk0, Sk);
+        // ---- logsum per row (32 lanes of the last wave), P V per dim tile ----------------------------------------------------------------
+        if (wid == 3 && lane < 32) {
+            float l = l_s[lane];
 #pragma unroll
-            for (int sc = 0; sc < FA_KC / FA_VS; ++sc) {     // fully unrolled: `stage` stays in registers across the prefetch
-                if (sc >= nsub) break;
-                vs_park<D, F16, VT, VSV>(stage, vbuf + (size_t)(sc & 1) * VS_BYTES);
-                __syncthreads();
-                if (sc + 1 < nsub) vs_fetch<D, F16, VT, VSV>(stage, V, ldv, kvh, chunk0 + (sc + 1) * FA_VS, Sk);
-                if (own) {
-                    const char *vb = vbuf + (size_t)(sc & 1) * VS_BYTES;
-                    const int t1 = min(ntl, (sc + 1) * (FA_VS / 4));
-#pragma unroll 2
-                    for (int tl = sc * (FA_VS / 4); tl < t1; ++tl) {
-                        const int kl = 4 * tl - sc * FA_VS;     // first key of the tile inside the sub-chunk
-                        const float4 c4 = *reinterpret_cast<const float4 *>(Cc + (g * 64 + tl) * 4);
-                        float vv[4];
-                        if (VT) {
-                            const uint2 w = *reinterpret_cast<const uint2 *>(vb + (size_t)d * VS_PITCH + kl * 2);
-                            vv[0] = h2f((uint16_t)(w.x & 0xffff)); vv[1] = h2f((uint16_t)(w.x >> 16));
-                            vv[2] = h2f((uint16_t)(w.y & 0xffff)); vv[3] = h2f((uint16_t)(w.y >> 16));
-                        } else {
+            for (int t = 0; t < 8; ++t) l = __fmaf_rn(l, Cc[lane * 8 + t], Sm[lane * 8 + t]);
+            l_s[lane] = l;
+        }
+        if (wid < NDT) {
+            const int dd = 32 * wid + col;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                vv[k] = F16 ? h2f(reinterpret_cast<const uint16_t *>(vb)[(kl + k) * D + d]) : reinterpret_cast<const float *>(vb)[(kl + k) * D + d];
-                        }
-                        const float cr[4] = {c4.x, c4.y, c4.z, c4.w};
+            for (int t = 0; t < 8; ++t) {
+                if (moved_any[t]) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float4 p = *reinterpret_cast<const float4 *>(S + (4 * g + r) * SP + 4 * tl);
-                            float a = o[r] * cr[r];
-                            a = __fmaf_rn(p.x, vv[0], a);
-                            a = __fmaf_rn(p.y, vv[1], a);
-                            a = __fmaf_rn(p.z, vv[2], a);
-                            a = __fmaf_rn(p.w, vv[3], a);
-                            o[r] = a;
-                        }
-                        if (d < 4) lsum = __fmaf_rn(lsum, Cc[(g * 64 + tl) * 4 + d], Sm[(g * 64 + tl) * 4 + d]);
-                    }
+                    for (int i = 0; i < 16; ++i) oacc[i] = oacc[i] * Cc[((i & 3) + 8 * (i >> 2) + 4 * h) * 8 + t];
+                }
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) {
+                    const int key = 4 * t + 2 * kp + h;
+                    const float vb = dd < D ? (VT ? Vs[dd * 33 + key] : Vs[key * D + dd]) : 0.0f;
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(P[col * 33 + key], vb, oacc, 0, 0, 0);
                 }
             }
         }
-        __syncthreads();
     }
-    if (own && d < 4) lfin[4 * g + d] = lsum;
     __syncthreads();
-    if (own) {
+    if (wid < NDT) {
+        const int dd = 32 * wid + col;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gr = r0 + 4 * g + r;
-            if (gr < Sq) O[(int64_t)gr * ldo + head * D + d] = o[r] * (1.0f / lfin[4 * g + r]);
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (r0 + row < Sq && dd < D) O[(int64_t)(r0 + row) * ldo + head * D + dd] = oacc[i] * (1.0f / l_s[row]);
         }
     }
 }
@@ -256,7 +260,7 @@ static int launch_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, c
     const int Tc = Sk / 4;
     const int left = F16 ? (Tc ? Sk % Tc : 0) : Sk % 4;
     const int sk_eff = Tc * 4 + left;
-    constexpr int R = PrefillCfg<D>::R;
+    constexpr int R = FA_R;
     hipLaunchKernelGGL((fa2_prefill_kernel<D, F16, VT>), dim3((Sq + R - 1) / R, Hq), dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, sk_eff, Hq,
                        Hkv, causal);
     return MH_LAUNCH_OK("fa2_prefill");
