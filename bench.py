@@ -122,8 +122,15 @@ def main():
     # ---- roofline of the dominant kernel (gate/up Q4_K GEMV, 17920 x 1536): live HIP-event timing on the engine's stream ----
     ms_launch, bytes_launch = m.time_gemv(13, 280)
     achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
+    # traffic: HBM-side bytes per launch from the PMC pass of this round (rocprofv3 --pmc FETCH_SIZE in its own run, x2 gfx950 correction;
+    # profiles/r01_pmc_fetch_size.md) -- a profiler pass cannot run inside the timed process, so the committed figure is reported
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["dec_gateup_kernel"]["fetch_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": "dec_gateup_kernel<1,2,1,8> (fused RMSNorm+Q8_K+gate|up GEMV+SiLU*mul, 17920 x 1536 Q4_K rows, launches cycle over the 28 layers so every launch streams cold HBM)", "achieved": round(achieved, 1),
-                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "us_per_launch": round(ms_launch * 1e3, 3), "algorithmic_bytes_per_launch": int(bytes_launch)}
     wbytes = m.decode_weight_bytes()
     e2e_gbs = wbytes * (K / dt) / 1e9
