@@ -222,102 +222,154 @@ __global__ __launch_bounds__(256) void q8k_prepack_kernel(const int8_t *__restri
     if (j == 0) Ad[tile * 32 + min_] = live ? xd[(int64_t)m * nb + i] : 0.0f;
 }
 
-// one wave per 32 (m) x 32 (n) tile; 4 waves per workgroup = 2 m-tiles x 2 n-tiles
-__global__ __launch_bounds__(256) void gemm_q4k_kernel(const uint8_t *__restrict__ Wp, const uint8_t *__restrict__ Xp, const float *__restrict__ bias,
-                                                       void *__restrict__ y, int y_f16, int64_t ldy, const float *__restrict__ residual, int M, int N,
-                                                       int nb) {
+// Workgroup = 512 threads = 4 tiles of 32 (m) x 32 (n) (2 m-tiles x 2 n-tiles), TWO waves per tile: the 12 chains of a tile
+// would fill a wave's registers (and spill into AGPRs, which the VALU chain step cannot address), so wave ch of a tile owns
+// classes {2ch, 2ch+1, 4+2ch, 5+2ch} and mins lanes {2ch, 2ch+1} -- 96 accumulation registers, two waves per SIMD -- and
+// the pair meets once, after the K loop, for the reference's final adds ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)), (m0+m2)+(m1+m3).
+// Operands travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: the packed fragments are already lane-linear, one 1-KiB
+// fragment = one wave instruction) into a ring of four half-super-block slots, requested three half-steps ahead of the
+// MFMAs that read them (counted s_waitcnt vmcnt(N), raw s_barrier; the DMA never passes through VGPRs).  A half-step =
+// 4 column classes = 8 A + 8 B fragments per tile; the even half carries the block's scales, the odd half the mins operands.
+// Slot: [A m0: 8 KiB][A m1][B n0][B n1][aux 4 KiB]; aux of an even half = (Ad m0, Ad m1, Bd n0, Bd n1) in 768 B,
+// of an odd half = (Am m0, Am m1, Bm n0, Bm n1), 1 KiB each.
+constexpr int GQ_SLOT = 32768 + 4096, GQ_SLOTS = 4, GQ_LDS = GQ_SLOT * GQ_SLOTS, GQ_NT = 512;
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst_in) {
+    unsigned keep;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);   // wave-uniform by construction; M0 wants an SGPR
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__global__ __launch_bounds__(GQ_NT) void gemm_q4k_kernel(const uint8_t *__restrict__ Wp, const uint8_t *__restrict__ Xp, const float *__restrict__ bias,
+                                                         void *__restrict__ y, int y_f16, int64_t ldy, const float *__restrict__ residual, int M, int N,
+                                                         int nb) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int mt = blockIdx.y * 2 + (wid >> 1), nt = blockIdx.x * 2 + (wid & 1);
-    if (mt * 32 >= M || nt * 32 >= N) return;
+    const int MT = (M + 31) / 32, NT = (N + 31) / 32;
+    const int tile = wid >> 1, ch = wid & 1, mw = tile >> 1, nw = tile & 1;
+    const int mt = blockIdx.y * 2 + mw, nt = blockIdx.x * 2 + nw;
+    const bool active = mt < MT && nt < NT;
     const size_t tbw = q4kp_tile_blocks(N, nb), tbx = q4kp_tile_blocks(M, nb);
-    const v8h *Bw = reinterpret_cast<const v8h *>(Wp) + (size_t)nt * nb * 8 * 2 * 64 + lane;
-    const v4h *Bm = reinterpret_cast<const v4h *>(Wp + tbw * Q4KP_W_PER_BLK) + (size_t)nt * nb * 4 * 32 + col;
-    const float2 *Bd = reinterpret_cast<const float2 *>(Wp + tbw * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK)) + (size_t)nt * nb * 32 + col;
-    const v8h *Ax = reinterpret_cast<const v8h *>(Xp) + (size_t)mt * nb * 8 * 2 * 64 + lane;
-    const v4h *Am = reinterpret_cast<const v4h *>(Xp + tbx * Q4KP_W_PER_BLK) + (size_t)mt * nb * 4 * 32 + col;
-    const float *Ad = reinterpret_cast<const float *>(Xp + tbx * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK)) + (size_t)mt * nb * 32 + 4 * h;
-    v16f acc[8], accm[4];
+    // DMA sources (tiles clamped: a workgroup at the edge copies a valid tile twice and does not use the copy)
+    const int mts0 = min((int)blockIdx.y * 2, MT - 1), mts1 = min((int)blockIdx.y * 2 + 1, MT - 1);
+    const int nts0 = min((int)blockIdx.x * 2, NT - 1), nts1 = min((int)blockIdx.x * 2 + 1, NT - 1);
+    const uint8_t *XpM = Xp + tbx * Q4KP_W_PER_BLK, *XpD = Xp + tbx * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK);
+    const uint8_t *WpM = Wp + tbw * Q4KP_W_PER_BLK, *WpD = Wp + tbw * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK);
+    const unsigned ring0 = (unsigned)(size_t)ring;   // LDS byte address of the ring
+    // 5 DMA instructions per wave and half-step: 4 of the 32 operand fragments + 1 aux (or a dummy into the scratch tail, so the count is uniform)
+    auto issue = [&](int hstep) {
+        const int i = hstep >> 1, hb = hstep & 1;
+        const unsigned slot = ring0 + (unsigned)((hstep & (GQ_SLOTS - 1)) * GQ_SLOT);
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * 8 + wid, region = c >> 3, f = c & 7;
+            const int tsel = region == 0 ? mts0 : (region == 1 ? mts1 : (region == 2 ? nts0 : nts1));
+            const uint8_t *src = (region < 2 ? Xp : Wp) + ((size_t)tsel * nb + i) * Q4KP_W_PER_BLK + (size_t)(8 * hb + f) * 1024 + lane * 16;
+            glds16(src, slot + (unsigned)c * 1024u);
+        }
+        const uint8_t *src = Xp + lane * 16;
+        unsigned dst = ring0 + (unsigned)GQ_LDS;   // scratch tail
+        if (hb == 0) {
+            if (wid == 0 && lane < 48) {
+                src = lane < 8    ? XpD + ((size_t)mts0 * nb + i) * 128 + lane * 16
+                      : lane < 16 ? XpD + ((size_t)mts1 * nb + i) * 128 + (lane - 8) * 16
+                      : lane < 32 ? WpD + ((size_t)nts0 * nb + i) * 256 + (lane - 16) * 16
+                                  : WpD + ((size_t)nts1 * nb + i) * 256 + (lane - 32) * 16;
+            }
+            if (wid == 0) dst = slot + 32768u;
+        } else if (wid < 4) {
+            const int tsel = wid == 0 ? mts0 : (wid == 1 ? mts1 : (wid == 2 ? nts0 : nts1));
+            src = (wid < 2 ? XpM : WpM) + ((size_t)tsel * nb + i) * 1024 + lane * 16;
+            dst = slot + 32768u + (unsigned)wid * 1024u;
+        }
+        glds16(src, dst);   // (even half, wave 0: lanes >= 48 drop 16 dummy bytes into the unused part of the aux area)
+    };
+    v16f acc[4], accm[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accm[u][r] = 0.0f;
     v16f zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
     const v8h hz = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    // One wave per SIMD (the 12 chains of a 32x32 tile fill the accumulation registers), so memory latency is hidden by the
-    // wave itself: the operands of half a super-block (4 classes = 8 A + 8 B fragments) are requested one half ahead of the
-    // MFMAs that consume them.  Even halves (classes 0..3, with the block's scales) live in *0, odd halves (classes 4..7, with
-    // the mins operands) in *1.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    v8h a0[8], b0[8], a1[8], b1[8];
-    v4h am[4], bm[4];
-    f32x4 adx[4];
-    f32x2 dwv;
-#define LOAD_EVEN(i_)                                                                                     \
-    {                                                                                                     \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                   \
-            const size_t o = ((size_t)(i_) * 8 + (q >> 1)) * 2 * 64 + (q & 1) * 64;                       \
-            a0[q] = Ax[o]; b0[q] = Bw[o];                                                                 \
-        }                                                                                                 \
-        _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) adx[g4] = *reinterpret_cast<const f32x4 *>(Ad + (size_t)(i_) * 32 + 8 * g4); \
-        dwv = *reinterpret_cast<const f32x2 *>(Bd + (size_t)(i_) * 32);                                   \
-    }
-#define LOAD_ODD(i_)                                                                                      \
-    {                                                                                                     \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                   \
-            const size_t o = ((size_t)(i_) * 8 + 4 + (q >> 1)) * 2 * 64 + (q & 1) * 64;                   \
-            a1[q] = Ax[o]; b1[q] = Bw[o];                                                                 \
-        }                                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) { am[u] = Am[((size_t)(i_) * 4 + u) * 32]; bm[u] = Bm[((size_t)(i_) * 4 + u) * 32]; } \
-    }
-    LOAD_EVEN(0)
+    const int TS = 2 * nb;
+    issue(0);
+    if (TS > 1) issue(1);
+    if (TS > 2) issue(2);
+    float dd[16], dm[16];
+#pragma unroll 1
     for (int i = 0; i < nb; ++i) {
-        LOAD_ODD(i)
-        float dd[16], dm[16];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
+        for (int hb = 0; hb < 2; ++hb) {
+            const int hstep = 2 * i + hb;
+            // this wave's DMA of `hstep` has landed when at most the (up to two) younger half-steps are outstanding: 5 per half-step
+            if (hstep + 2 < TS) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (hstep + 1 < TS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // everyone's part of the slot has landed; everyone is done with slot hstep-1
+            asm volatile("" ::: "memory");
+            if (hstep + 3 < TS) issue(hstep + 3);
+            if (active) {
+                const char *slot = ring + (size_t)(hstep & (GQ_SLOTS - 1)) * GQ_SLOT;
+                // this wave's 4 + 4 fragments: classes 2ch, 2ch+1 of the half
+                const v8h *A = reinterpret_cast<const v8h *>(slot + mw * 8192 + ch * 4096) + lane, *B = reinterpret_cast<const v8h *>(slot + 16384 + nw * 8192 + ch * 4096) + lane;
+                const char *aux = slot + 32768;
+                if (hb == 0) {
+                    const f32x2 dwv = *reinterpret_cast<const f32x2 *>(aux + 256 + nw * 256 + col * 8);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                dd[4 * g4 + e] = adx[g4][e] * dwv[0];        // y.d * fp16(x.d)
-                dm[4 * g4 + e] = (-adx[g4][e]) * dwv[1];     // -y.d * fp16(x.dmin)
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 dx = *reinterpret_cast<const f32x4 *>(aux + mw * 128 + (8 * g4 + 4 * h) * 4);   // rows 8 g4 + 4h + (0..3)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            dd[4 * g4 + e] = dx[e] * dwv[0];        // y.d * fp16(x.d)
+                            dm[4 * g4 + e] = (-dx[e]) * dwv[1];     // -y.d * fp16(x.dmin)
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(2 * k) * 64], B[(2 * k) * 64], zero, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(2 * k + 1) * 64], B[(2 * k + 1) * 64], c, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[2 * hb + k][r] = __fmaf_rn(dd[r], c[r], acc[2 * hb + k][r]);
+                }
+                if (hb == 1) {
+                    const v4h *Am = reinterpret_cast<const v4h *>(aux + mw * 1024) + col, *Bm = reinterpret_cast<const v4h *>(aux + 2048 + nw * 1024) + col;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int u = 2 * ch + k;
+                        v8h a = hz, b = hz;
+                        if (h == 0) {
+                            const v4h a4 = Am[u * 32], b4 = Bm[u * 32];
+                            a[0] = a4[0]; a[1] = a4[1]; a[2] = a4[2]; a[3] = a4[3];
+                            b[0] = b4[0]; b[1] = b4[1]; b[2] = b4[2]; b[3] = b4[3];
+                        }
+                        const v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, zero, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accm[k][r] = __fmaf_rn(dm[r], c[r], accm[k][r]);
+                    }
+                }
             }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[2 * t], b0[2 * t], zero, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[2 * t + 1], b0[2 * t + 1], c, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = __fmaf_rn(dd[r], c[r], acc[t][r]);
-        }
-        if (i + 1 < nb) LOAD_EVEN(i + 1)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[2 * t], b1[2 * t], zero, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[2 * t + 1], b1[2 * t + 1], c, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[4 + t][r] = __fmaf_rn(dd[r], c[r], acc[4 + t][r]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            v8h a = hz, b = hz;
-            if (h == 0) {
-                a[0] = am[u][0]; a[1] = am[u][1]; a[2] = am[u][2]; a[3] = am[u][3];
-                b[0] = bm[u][0]; b[1] = bm[u][1]; b[2] = bm[u][2]; b[3] = bm[u][3];
-            }
-            const v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, zero, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accm[u][r] = __fmaf_rn(dm[r], c[r], accm[u][r]);
         }
     }
-#undef LOAD_EVEN
-#undef LOAD_ODD
+    // the pair meets: wave ch = 1 hands (a2+a6, a3+a7, m2, m3) to wave ch = 0 through LDS (the ring is free now)
+    float x[16], yv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = acc[0][r] + acc[2][r]; yv[r] = acc[1][r] + acc[3][r]; }
+    __syncthreads();
+    float *xch = reinterpret_cast<float *>(ring) + (size_t)tile * 64 * 64 + lane;
+    if (ch == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xch[(r) * 64] = x[r]; xch[(16 + r) * 64] = yv[r]; xch[(32 + r) * 64] = accm[0][r]; xch[(48 + r) * 64] = accm[1][r]; }
+    }
+    __syncthreads();
+    if (!active || ch == 1) return;
     const int n = nt * 32 + col;
     if (n >= N) return;
     const float bv = bias ? bias[n] : 0.0f;
@@ -325,8 +377,8 @@ __global__ __launch_bounds__(256) void gemm_q4k_kernel(const uint8_t *__restrict
     for (int r = 0; r < 16; ++r) {
         const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m >= M) continue;
-        const float hs = ((acc[0][r] + acc[4][r]) + (acc[2][r] + acc[6][r])) + ((acc[1][r] + acc[5][r]) + (acc[3][r] + acc[7][r]));
-        float v = hs + ((accm[0][r] + accm[2][r]) + (accm[1][r] + accm[3][r]));
+        const float hs = (x[r] + xch[r * 64]) + (yv[r] + xch[(16 + r) * 64]);
+        float v = hs + ((accm[0][r] + xch[(32 + r) * 64]) + (accm[1][r] + xch[(48 + r) * 64]));
         if (bias) v = v + bv;
         if (y_f16) reinterpret_cast<uint16_t *>(y)[(int64_t)m * ldy + n] = f2h(v);
         else {
@@ -454,7 +506,13 @@ extern "C" int mllm_hip_linear_q4kp_q8k(const void *Wpacked, const float *bias, 
     int rc = MH_LAUNCH_OK("q8k_prepack");
     if (rc) return rc;
     dim3 grid((N + 63) / 64, (M + 63) / 64);
-    hipLaunchKernelGGL(gemm_q4k_kernel, grid, dim3(256), 0, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16, ldy, residual,
+    constexpr int lds = GQ_LDS + 1024;   // ring + scratch tail
+    static bool attr_set = false;
+    if (!attr_set) {
+        MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_q4k_kernel, grid, dim3(GQ_NT), lds, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16, ldy, residual,
                        M, N, nb);
     return MH_LAUNCH_OK("gemm_q4k");
 }
