@@ -604,7 +604,13 @@ static int allow_lds(KernelT kern, size_t lds) {
 }
 template <int NS>
 static int launch_qkv(const DecodeLayer &L, const DecodeCtx &c, bool embed, const float *x, float *x_out, hipStream_t st) {
-    constexpr int ROWS = NS == 1 ? 2 : 1, WPB = 4;
+#ifndef QKV_ROWS
+#define QKV_ROWS 2
+#endif
+#ifndef QKV_WPB
+#define QKV_WPB 8
+#endif
+    constexpr int ROWS = NS == 1 ? QKV_ROWS : 1, WPB = QKV_WPB;
     const int waves = (L.qkv_N + ROWS - 1) / ROWS;
     const size_t lds = fused_lds_bytes<NS, ROWS>(c.H, false, WPB);
     constexpr int NV = (NS * 8 + WPB - 1) / WPB;   // quant blocks per wave
@@ -620,7 +626,13 @@ static int launch_qkv(const DecodeLayer &L, const DecodeCtx &c, bool embed, cons
 }
 template <int NS>
 static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *x, hipStream_t st) {
-    constexpr int PAIRS = NS == 1 ? 2 : 1, WPB = 8;
+#ifndef GU_PAIRS
+#define GU_PAIRS 2
+#endif
+#ifndef GU_WPB
+#define GU_WPB 8
+#endif
+    constexpr int PAIRS = NS == 1 ? GU_PAIRS : 1, WPB = GU_WPB;
     const int waves = (c.I + PAIRS - 1) / PAIRS;
     const size_t lds = fused_lds_bytes<NS, 2 * PAIRS>(c.H, false, WPB);
     auto kern = dec_gateup_kernel<NS, PAIRS, (NS * 8 + WPB - 1) / WPB, WPB>;
@@ -631,7 +643,16 @@ static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *
 }
 template <int NS>
 static int launch_proj(const uint8_t *W, const float *xin, const float *residual, float *y, int N, int K, hipStream_t st) {
-    constexpr int ROWS = NS == 1 ? 2 : 1, WPB = NS >= 3 ? 16 : 4;   // long rows: 1024-thread workgroups share the row quantisation
+#ifndef PJ_ROWS1
+#define PJ_ROWS1 2
+#endif
+#ifndef PJ_ROWS5
+#define PJ_ROWS5 1
+#endif
+#ifndef PJ_WPB1
+#define PJ_WPB1 8
+#endif
+    constexpr int ROWS = NS == 1 ? PJ_ROWS1 : PJ_ROWS5, WPB = NS >= 3 ? 16 : PJ_WPB1;   // long rows: 1024-thread workgroups share the row quantisation
     const int waves = (N + ROWS - 1) / ROWS;
     const size_t lds = fused_lds_bytes<NS, ROWS>(K, false, WPB);
     auto kern = dec_proj_kernel<NS, ROWS, WPB>;

@@ -156,3 +156,14 @@ def test_composed_llm_text_and_image_bit_exact():
     for _ in range(23):
         lg = m.decode(toks[-1]); rows.append(lg); toks.append(int(lg.argmax()))
     assert toks == g["tokens"].tolist() and np.array_equal(np.stack(rows), g["logits"])
+
+
+def test_expf_restatement_equals_libm():
+    """The attention kernels carry a restatement of glibc's expf (oracle/restate.c:orc_expf = mllm_amd/csrc/common.h:glibc_expf);
+    it must agree bit for bit with the libm the reference links against, over the argument range attention produces and beyond."""
+    import ctypes as C
+    l = orc.lib()
+    l.orc_expf_mismatches.restype = C.c_long
+    l.orc_expf_mismatches.argtypes = [C.c_float, C.c_float, C.c_long, C.c_uint64]
+    for lo, hi, n in ((-110.0, 0.0, 20_000_000), (-1.0, 0.0, 10_000_000), (-104.5, -103.0, 5_000_000), (0.0, 89.0, 5_000_000)):
+        assert l.orc_expf_mismatches(lo, hi, n, 3) == 0
