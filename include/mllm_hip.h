@@ -83,6 +83,16 @@ int mllm_hip_q4k_prepack(const void *W, int N, int K, void *out, void *stream);
 int mllm_hip_linear_q4kp_q8k(const void *Wpacked, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums,
                              void *xpack, void *y, int y_dtype, int64_t ldy, const float *residual, int M, int N, int K,
                              void *stream);
+/* producers that write the Q8_K activations straight in packed form (no separate pack pass in prefill), and the GEMM that
+ * consumes them.  Same bytes as quantise-then-pack: quantize_row_q8_K_reference (QuantizeQ8.cpp:216-251) of the fp32 rows / of
+ * the RMSNorm (CPURMSNorm.cpp:31-136) / LayerNorm (CPULayerNorm.cpp:49-88) output; `y` (fp32 normalised rows) optional. */
+int mllm_hip_quantize_q8k_packed(const float *x, void *xpack, int M, int K, void *stream);
+int mllm_hip_rmsnorm_packed(const float *x, const float *w, float *y, void *xpack, int M, int dim, float eps, int add_unit_offset,
+                            void *stream);
+int mllm_hip_layernorm_packed(const float *x, const float *w, const float *b, float *y, void *xpack, int M, int dim, float eps,
+                              void *stream);
+int mllm_hip_linear_q4kp_packed(const void *Wpacked, const float *bias, const void *xpack, void *y, int y_dtype, int64_t ldy,
+                                const float *residual, int M, int N, int K, void *stream);
 int mllm_hip_linear_f32(const float *W, const float *bias, const float *x, float *y, int64_t ldy, int M, int N, int K, void *stream);
 /* one-call forms = CPULinear::execute (backends/cpu/op/CPULinear.cpp:98-234): fp32 x in, quantise, dot, bias.
  * `workspace` must hold mllm_hip_linear_workspace_bytes(wdtype, M, K) bytes of device memory. */

@@ -386,19 +386,35 @@ static void rope_index(const M *m, const int32_t *ids, int S, const int32_t *gri
     for (int a = 0; a < 3; ++a) for (int j = 0; j < S && j < (int)lp[a].size(); ++j) pos[(size_t)a * S + j] = (float)lp[a][j];
 }
 
-// Linear on q8k planes with the GEMV/GEMM dispatch
-static int lin(M *m, const LinearW &w, const Q8Planes &x, void *y, int ydt, int64_t ldy, const float *res, int Mrows) {
-    if (Mrows >= 16) {
-        const size_t need_b = mllm_hip_q4k_prepack_bytes(Mrows, w.K);
-        if (need_b > m->xpack_bytes) {   // activation-side pack scratch, grown on demand (prefill only, never inside a captured graph)
-            HH(hipStreamSynchronize(m->st));
-            if (m->xpack) HH(hipFree(m->xpack));
-            m->xpack = nullptr; m->xpack_bytes = 0;
-            HH(hipMalloc(&m->xpack, need_b));
-            m->xpack_bytes = need_b;
-        }
-        return mllm_hip_linear_q4kp_q8k(w.wp, w.bias, x.qs, x.d, x.bs, m->xpack, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
+// ---- quantised activations feeding a Linear.  Rows >= 16 meet the GEMM, whose activation operand is a packed layout: the
+// producers (norms with fused quantisation, the quantiser) then write that layout directly into m->xpack (one scratch: every
+// quantised buffer is consumed by the very next Linear); fewer rows take the GEMV on the three Q8_K planes.
+static int ensure_xpack(M *m, int rows, int K) {
+    const size_t need_b = mllm_hip_q4k_prepack_bytes(rows, K);
+    if (need_b > m->xpack_bytes) {   // grown on demand (prefill only, never inside a captured graph)
+        HH(hipStreamSynchronize(m->st));
+        if (m->xpack) HH(hipFree(m->xpack));
+        m->xpack = nullptr; m->xpack_bytes = 0;
+        HH(hipMalloc(&m->xpack, need_b));
+        m->xpack_bytes = need_b;
     }
+    return 0;
+}
+static int q_quant(M *m, const float *x, const Q8Planes &p, int rows, int K) {
+    if (rows >= 16) { EH(ensure_xpack(m, rows, K)); return mllm_hip_quantize_q8k_packed(x, m->xpack, rows, K, m->st); }
+    return mllm_hip_quantize_q8k(x, p.qs, p.d, p.bs, rows, K, m->st);
+}
+static int q_rmsnorm(M *m, const float *x, const float *w, const Q8Planes &p, int rows, int dim, float eps) {
+    if (rows >= 16) { EH(ensure_xpack(m, rows, dim)); return mllm_hip_rmsnorm_packed(x, w, nullptr, m->xpack, rows, dim, eps, 0, m->st); }
+    return mllm_hip_rmsnorm(x, w, nullptr, p.qs, p.d, p.bs, rows, dim, eps, 0, m->st);
+}
+static int q_layernorm(M *m, const float *x, const float *w, const float *b, const Q8Planes &p, int rows, int dim, float eps) {
+    if (rows >= 16) { EH(ensure_xpack(m, rows, dim)); return mllm_hip_layernorm_packed(x, w, b, nullptr, m->xpack, rows, dim, eps, m->st); }
+    return mllm_hip_layernorm(x, w, b, nullptr, p.qs, p.d, p.bs, rows, dim, eps, m->st);
+}
+// Linear on the activations the last q_* call produced
+static int lin(M *m, const LinearW &w, const Q8Planes &x, void *y, int ydt, int64_t ldy, const float *res, int Mrows) {
+    if (Mrows >= 16) return mllm_hip_linear_q4kp_packed(w.wp, w.bias, m->xpack, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
     return mllm_hip_linear_q4k_q8k(w.w, w.bias, x.qs, x.d, x.bs, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
 }
 
@@ -418,26 +434,26 @@ static int forward_vision(M *m, const int32_t *grid, float *out) {
     EH(mllm_hip_patch_gemm_f32(m->vpix, m->patch_w, nullptr, m->vx, N, PE, V, st));
     float *x = m->vx, *r = m->vr;
     for (auto &B : m->vblocks) {
-        EH(mllm_hip_layernorm(x, B.n1w, B.n1b, nullptr, m->xq.qs, m->xq.d, m->xq.bs, N, V, 1e-6f, st));
+        EH(q_layernorm(m, x, B.n1w, B.n1b, m->xq, N, V, 1e-6f));
         EH(lin(m, B.qkv, m->xq, m->vqkv, MLLM_HIP_F32, 3 * V, nullptr, N));
         EH(mllm_hip_rope_apply(m->vqkv, 3 * V, m->vsin, m->vcos, VD / 2, m->vqkv, MLLM_HIP_F32, 3 * V, N, c.v_heads, VD, st));
         EH(mllm_hip_rope_apply(m->vqkv + V, 3 * V, m->vsin, m->vcos, VD / 2, m->vqkv + V, MLLM_HIP_F32, 3 * V, N, c.v_heads, VD, st));
         EH(mllm_hip_fa2(m->vqkv, 3 * V, m->vqkv + V, 3 * V, m->vqkv + 2 * V, 3 * V, MLLM_HIP_F32, m->vattn, V, N, N, c.v_heads, c.v_heads, VD, 0,
                         nullptr, nullptr, st));
-        EH(mllm_hip_quantize_q8k(m->vattn, m->xq.qs, m->xq.d, m->xq.bs, N, V, st));
+        EH(q_quant(m, m->vattn, m->xq, N, V));
         EH(lin(m, B.proj, m->xq, r, MLLM_HIP_F32, V, x, N));                       // residual = proj(attn) + x
-        EH(mllm_hip_layernorm(r, B.n2w, B.n2b, nullptr, m->xq.qs, m->xq.d, m->xq.bs, N, V, 1e-6f, st));
+        EH(q_layernorm(m, r, B.n2w, B.n2b, m->xq, N, V, 1e-6f));
         EH(lin(m, B.fc1, m->xq, m->vfc, MLLM_HIP_F32, VM, nullptr, N));
         EH(mllm_hip_act_lut(m->vfc, m->vact, (int64_t)N * VM, m->lut_qgelu, st));
-        EH(mllm_hip_quantize_q8k(m->vact, m->xq2.qs, m->xq2.d, m->xq2.bs, N, VM, st));
+        EH(q_quant(m, m->vact, m->xq2, N, VM));
         EH(lin(m, B.fc2, m->xq2, x, MLLM_HIP_F32, V, r, N));                        // x = fc2(act) + residual
     }
     // PatchMerger: ln_q -> view [NT][MM] -> mlp.0 -> GELU -> mlp.2
     EH(mllm_hip_layernorm(x, m->lnq_w, m->lnq_b, r, nullptr, nullptr, nullptr, N, V, 1e-6f, st));
-    EH(mllm_hip_quantize_q8k(r, m->xq2.qs, m->xq2.d, m->xq2.bs, NT, MM, st));
+    EH(q_quant(m, r, m->xq2, NT, MM));
     EH(lin(m, m->m0, m->xq2, m->vm0, MLLM_HIP_F32, MM, nullptr, NT));
     EH(mllm_hip_act_lut(m->vm0, m->vfc, (int64_t)NT * MM, m->lut_gelu, st));
-    EH(mllm_hip_quantize_q8k(m->vfc, m->xq2.qs, m->xq2.d, m->xq2.bs, NT, MM, st));
+    EH(q_quant(m, m->vfc, m->xq2, NT, MM));
     EH(lin(m, m->m2, m->xq2, out, MLLM_HIP_F32, c.hidden, nullptr, NT));
     return 0;
 }
@@ -480,19 +496,19 @@ static int forward_llm(M *m, int S, const float *pos3) {
     for (int li = 0; li < n_layers; ++li) {
         auto &L = m->layers[li];
         uint16_t *kl = m->kslab + (size_t)li * c.cache_limit * m->KVD, *vl = m->vslab + (size_t)li * m->KVD * m->vt_ld;
-        EH(mllm_hip_rmsnorm(h, L.in_norm, nullptr, m->xq.qs, m->xq.d, m->xq.bs, S, H, c.rms_eps, 0, st));
+        EH(q_rmsnorm(m, h, L.in_norm, m->xq, S, H, c.rms_eps));
         EH(lin(m, L.qkv, m->xq, m->qkv, MLLM_HIP_F32, m->QKV, nullptr, S));
         // q_rope in place; k_rope -> fp16 slab rows [T0, T0+S); v -> fp16 slab (KVCache zero-copy append)
         EH(mllm_hip_rope_apply(m->qkv, m->QKV, m->rope_sin, m->rope_cos, D / 2, m->qkv, MLLM_HIP_F32, m->QKV, S, c.heads, D, st));
         EH(mllm_hip_rope_apply(m->qkv + m->HD, m->QKV, m->rope_sin, m->rope_cos, D / 2, kl + (size_t)T0 * m->KVD, MLLM_HIP_F16, m->KVD, S, c.kv_heads, D, st));
         EH(mllm_hip_store_f16_t(m->qkv + m->HD + m->KVD, m->QKV, vl + T0, m->vt_ld, S, m->KVD, st));
         EH(mllm_hip_fa2_vt(m->qkv, m->QKV, kl, m->KVD, vl, m->vt_ld, m->attn, m->HD, S, T0 + S, c.heads, c.kv_heads, D, 1, st));
-        EH(mllm_hip_quantize_q8k(m->attn, m->xq.qs, m->xq.d, m->xq.bs, S, m->HD, st));
+        EH(q_quant(m, m->attn, m->xq, S, m->HD));
         EH(lin(m, L.o, m->xq, h2, MLLM_HIP_F32, H, h, S));                          // tmp = o_proj(attn) + x
-        EH(mllm_hip_rmsnorm(h2, L.post_norm, nullptr, m->xq.qs, m->xq.d, m->xq.bs, S, H, c.rms_eps, 0, st));
+        EH(q_rmsnorm(m, h2, L.post_norm, m->xq, S, H, c.rms_eps));
         EH(lin(m, L.gu, m->xq, m->gu, MLLM_HIP_F32, 2 * I, nullptr, S));
         EH(mllm_hip_silu_mul(m->gu, m->act, S, I, st));
-        EH(mllm_hip_quantize_q8k(m->act, m->xq2.qs, m->xq2.d, m->xq2.bs, S, I, st));
+        EH(q_quant(m, m->act, m->xq2, S, I));
         EH(lin(m, L.down, m->xq2, h, MLLM_HIP_F32, H, h2, S));                      // x = down(...) + tmp
     }
     // final norm on the last token only (norm then clip({-1}) == clip then norm), tied lm_head through Q8_0 activations

@@ -40,6 +40,54 @@ __device__ __forceinline__ void wave_quant_q8k(float4 v, int lane, int8_t *qs_bl
     if (lane == 0) *d_out = dd;
 }
 
+// Same quantisation, written straight into the activation-side operand layout of the Q4_K GEMM (kernels_linear.hip: Ax / Am / Ad of
+// q8k_prepack_kernel), so that prefill needs no separate pack pass.  Lane l holds values 4l..4l+3 of block (m, i): chunk j = l >> 4,
+// sub-block half = (l >> 3) & 1, column class t = l & 7 -> 4 fp16 at fragment (t, p = j >> 1, h = j & 1), element half*4.
+// Rows m >= M of the last 32-row tile are written as zeros (live == false).
+typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wave_quant_pack(float4 v, int lane, bool live, uint8_t *pack, size_t tb, int nb, int m, int i) {
+    float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+    float amax = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+    amax = wave_max(amax);
+    const float mine = a0 == amax ? v.x : (a1 == amax ? v.y : (a2 == amax ? v.z : v.w));
+    const float mx = first_flagged(a0 == amax || a1 == amax || a2 == amax || a3 == amax, mine);
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    float dd = 0.0f;
+    if (live && amax != 0.0f) {
+        const float iscale = __fdiv_rn(-128.0f, mx);
+        q0 = min(127, nearest_int(__fmul_rn(iscale, v.x)));
+        q1 = min(127, nearest_int(__fmul_rn(iscale, v.y)));
+        q2 = min(127, nearest_int(__fmul_rn(iscale, v.z)));
+        q3 = min(127, nearest_int(__fmul_rn(iscale, v.w)));
+        dd = __fdiv_rn(1.0f, iscale);
+    }
+    const size_t tile = (size_t)(m >> 5) * nb + i;
+    const int mi = m & 31, j = lane >> 4, hf = (lane >> 3) & 1, t = lane & 7;
+    v4h_t o;
+    o[0] = (_Float16)(float)q0; o[1] = (_Float16)(float)q1; o[2] = (_Float16)(float)q2; o[3] = (_Float16)(float)q3;
+    *reinterpret_cast<v4h_t *>(pack + ((((tile * 8 + t) * 2 + (j >> 1)) * 64 + (j & 1) * 32 + mi) * 16) + hf * 8) = o;
+    // q8s[k] = sum of the 32 values of 8-lane group k; lane 16u gathers (q8s[2u], q8s[2u+1]) -> (even part, low bit) pairs of Am
+    const int s8 = group8_sum(q0 + q1 + q2 + q3);
+    const int s8n = MH_DPP(0, s8, 0x108 /* row_shl:8 */, 0xF);
+    if ((lane & 15) == 0) {
+        v4h_t mo;
+        mo[0] = (_Float16)(float)(s8 & ~1); mo[1] = (_Float16)(float)(s8 & 1);
+        mo[2] = (_Float16)(float)(s8n & ~1); mo[3] = (_Float16)(float)(s8n & 1);
+        *reinterpret_cast<v4h_t *>(pack + tb * Q4KP_W_PER_BLK + ((tile * 4 + (lane >> 4)) * 32 + mi) * 8) = mo;
+    }
+    if (lane == 0) *reinterpret_cast<float *>(pack + tb * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK) + (tile * 32 + mi) * 4) = dd;
+}
+__global__ __launch_bounds__(256) void quantize_q8k_pack_kernel(const float *__restrict__ x, uint8_t *__restrict__ pack, int M, int nb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int Mp = (M + 31) & ~31;
+    if (blk >= (int64_t)Mp * nb) return;
+    const int m = (int)(blk / nb), i = (int)(blk % nb);
+    const bool live = m < M;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (live) v = reinterpret_cast<const float4 *>(x + ((int64_t)m * nb + i) * 256)[lane];
+    wave_quant_pack(v, lane, live, pack, q4kp_tile_blocks(M, nb), nb, m, i);
+}
 __global__ __launch_bounds__(256) void quantize_q8k_kernel(const float *__restrict__ x, int8_t *__restrict__ qs, float *__restrict__ d,
                                                            int16_t *__restrict__ bsums, int64_t n_blocks) {
     const int lane = threadIdx.x & 63;
@@ -159,9 +207,13 @@ template <bool LAYERNORM>
 __global__ __launch_bounds__(256) void norm_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
                                                    float *__restrict__ y, int8_t *__restrict__ qs, float *__restrict__ qd,
                                                    int16_t *__restrict__ bsums, int dim, float eps, int add_unit_offset,
-                                                   const float *__restrict__ stats) {
+                                                   const float *__restrict__ stats, uint8_t *__restrict__ pack, int M) {
     __shared__ double red[8];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (pack && row >= M) {   // padding rows of the last 32-row tile of the packed operand: zeros
+        for (int blk = wid; blk < (dim >> 8); blk += 4) wave_quant_pack(make_float4(0, 0, 0, 0), lane, false, pack, q4kp_tile_blocks(M, dim >> 8), dim >> 8, row, blk);
+        return;
+    }
     const float *xr = x + (int64_t)row * dim;
     float mean = 0.0f, inv = 0.0f;
     if (!LAYERNORM) {
@@ -178,7 +230,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float *__restrict__ x, 
         inv = stats[2 * row + 1];   // "rms" of the reference: the divisor
     }
     const bool quant = qs != nullptr;
-    if (quant || (dim & 255) == 0) {
+    if (quant || pack || (dim & 255) == 0) {
         const int nblk = dim >> 8;
         for (int blk = wid; blk < nblk; blk += 4) {
             const int d0 = blk * 256 + lane * 4;
@@ -206,6 +258,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float *__restrict__ x, 
                 const int64_t gblk = (int64_t)row * nblk + blk;
                 wave_quant_q8k(o, lane, qs + gblk * 256, qd + gblk, bsums + gblk * 16);
             }
+            if (pack) wave_quant_pack(o, lane, true, pack, q4kp_tile_blocks(M, nblk), nblk, row, blk);
         }
     } else {
         for (int d = tid; d < dim; d += 256) {
@@ -435,14 +488,15 @@ extern "C" int mllm_hip_rmsnorm(const float *x, const float *w, float *y, int8_t
     if (qs && (dim % 256 != 0 || !d || !bsums)) return MLLM_HIP_ERR_SHAPE;
     if (!qs && !y) return MLLM_HIP_ERR_ARG;
     hipLaunchKernelGGL(norm_kernel<false>, dim3(M), dim3(256), 0, as_stream(stream), x, w, (const float *)nullptr, y, qs, d, bsums, dim, eps, add_unit_offset,
-                       (const float *)nullptr);
+                       (const float *)nullptr, (uint8_t *)nullptr, M);
     return MH_LAUNCH_OK("rmsnorm");
 }
-extern "C" int mllm_hip_layernorm(const float *x, const float *w, const float *b, float *y, int8_t *qs, float *d, int16_t *bsums,
-                                  int M, int dim, float eps, void *stream) {
+static int layernorm_impl(const float *x, const float *w, const float *b, float *y, int8_t *qs, float *d, int16_t *bsums, uint8_t *pack,
+                          int M, int dim, float eps, void *stream) {
     if (M <= 0) return MLLM_HIP_OK;
-    if (qs && (dim % 256 != 0 || !d || !bsums)) return MLLM_HIP_ERR_SHAPE;
-    if (!qs && !y) return MLLM_HIP_ERR_ARG;
+    if ((qs || pack) && dim % 256 != 0) return MLLM_HIP_ERR_SHAPE;
+    if (qs && (!d || !bsums)) return MLLM_HIP_ERR_SHAPE;
+    if (!qs && !y && !pack) return MLLM_HIP_ERR_ARG;
     // per-row (mean, rms) scratch: grown on demand, owned by the library (stream-ordered use only)
     static float *stats = nullptr;
     static int stats_rows = 0;
@@ -454,8 +508,34 @@ extern "C" int mllm_hip_layernorm(const float *x, const float *w, const float *b
     hipLaunchKernelGGL(ln_stats_kernel, dim3((M + LN_ROWS - 1) / LN_ROWS), dim3(256), 0, as_stream(stream), x, stats, M, dim, eps);
     int rc = MH_LAUNCH_OK("ln_stats");
     if (rc) return rc;
-    hipLaunchKernelGGL(norm_kernel<true>, dim3(M), dim3(256), 0, as_stream(stream), x, w, b, y, qs, d, bsums, dim, eps, 0, (const float *)stats);
+    hipLaunchKernelGGL(norm_kernel<true>, dim3(pack ? (M + 31) & ~31 : M), dim3(256), 0, as_stream(stream), x, w, b, y, qs, d, bsums, dim, eps, 0, (const float *)stats,
+                       pack, M);
     return MH_LAUNCH_OK("layernorm");
+}
+extern "C" int mllm_hip_layernorm(const float *x, const float *w, const float *b, float *y, int8_t *qs, float *d, int16_t *bsums,
+                                  int M, int dim, float eps, void *stream) {
+    return layernorm_impl(x, w, b, y, qs, d, bsums, nullptr, M, dim, eps, stream);
+}
+// norm / quantiser variants whose Q8_K output is the packed activation operand of mllm_hip_linear_q4kp_packed (`xpack` of
+// mllm_hip_q4k_prepack_bytes(M, dim) bytes); y (fp32) optional
+extern "C" int mllm_hip_layernorm_packed(const float *x, const float *w, const float *b, float *y, void *xpack, int M, int dim, float eps, void *stream) {
+    if (!xpack) return MLLM_HIP_ERR_ARG;
+    return layernorm_impl(x, w, b, y, nullptr, nullptr, nullptr, (uint8_t *)xpack, M, dim, eps, stream);
+}
+extern "C" int mllm_hip_rmsnorm_packed(const float *x, const float *w, float *y, void *xpack, int M, int dim, float eps, int add_unit_offset, void *stream) {
+    if (M <= 0) return MLLM_HIP_OK;
+    if (!xpack || dim % 256 != 0) return MLLM_HIP_ERR_SHAPE;
+    hipLaunchKernelGGL(norm_kernel<false>, dim3((M + 31) & ~31), dim3(256), 0, as_stream(stream), x, w, (const float *)nullptr, y, (int8_t *)nullptr, (float *)nullptr,
+                       (int16_t *)nullptr, dim, eps, add_unit_offset, (const float *)nullptr, (uint8_t *)xpack, M);
+    return MH_LAUNCH_OK("rmsnorm_packed");
+}
+extern "C" int mllm_hip_quantize_q8k_packed(const float *x, void *xpack, int M, int K, void *stream) {
+    if (K % 256 != 0 || M < 0 || !xpack) return MLLM_HIP_ERR_SHAPE;
+    if (M == 0) return MLLM_HIP_OK;
+    const int nb = K / 256;
+    const int64_t blocks = (int64_t)((M + 31) & ~31) * nb;
+    hipLaunchKernelGGL(quantize_q8k_pack_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, as_stream(stream), x, (uint8_t *)xpack, M, nb);
+    return MH_LAUNCH_OK("quantize_q8k_packed");
 }
 extern "C" int mllm_hip_debug_ln_stats(const float *x, float *stats, int M, int dim, float eps, void *stream) {
     hipLaunchKernelGGL(ln_stats_kernel, dim3((M + LN_ROWS - 1) / LN_ROWS), dim3(256), 0, as_stream(stream), x, stats, M, dim, eps);

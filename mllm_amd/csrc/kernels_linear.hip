@@ -137,12 +137,6 @@ __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 
-constexpr size_t Q4KP_W_PER_BLK = 32 * 512, Q4KP_M_PER_BLK = 32 * 4 * 8, Q4KP_D_PER_BLK = 32 * 8;   // bytes per (32-row tile, super-block)
-__host__ __device__ static inline size_t q4kp_tile_blocks(int rows, int nb) { return (size_t)((rows + 31) / 32) * nb; }
-static inline size_t q4kp_bytes(int rows, int K) {
-    const size_t tb = q4kp_tile_blocks(rows, K / 256);
-    return tb * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK + Q4KP_D_PER_BLK);
-}
 
 // one thread per (row n, super-block i, chunk j): 4 classes x ... -> writes 8 x 16-byte fragments (t = 0..7) of (p, h) = (j >> 1, j & 1)
 __global__ __launch_bounds__(256) void q4k_prepack_kernel(const uint8_t *__restrict__ W, uint8_t *__restrict__ out, int N, int nb) {
@@ -492,6 +486,29 @@ extern "C" int mllm_hip_q4k_prepack(const void *W, int N, int K, void *out, void
     hipLaunchKernelGGL(q4k_prepack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), (const uint8_t *)W, (uint8_t *)out, N, nb);
     return MH_LAUNCH_OK("q4k_prepack");
 }
+static int launch_gemm_packed(const void *Wpacked, const float *bias, const void *xpack, void *y, int y_dtype, int64_t ldy, const float *residual, int M,
+                              int N, int K, hipStream_t st) {
+    const int nb = K / 256;
+    dim3 grid((N + 63) / 64, (M + 63) / 64);
+    constexpr int lds = GQ_LDS + 1024;   // ring + scratch tail
+    static bool attr_set = false;
+    if (!attr_set) {
+        MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_q4k_kernel, grid, dim3(GQ_NT), lds, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16, ldy, residual,
+                       M, N, nb);
+    return MH_LAUNCH_OK("gemm_q4k");
+}
+// GEMM on pre-packed weights and activations already in packed form (mllm_hip_quantize_q8k_packed / _rmsnorm_packed / _layernorm_packed)
+extern "C" int mllm_hip_linear_q4kp_packed(const void *Wpacked, const float *bias, const void *xpack, void *y, int y_dtype, int64_t ldy,
+                                           const float *residual, int M, int N, int K, void *stream) {
+    if (K % 256 != 0 || K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
+    if (y_dtype != MLLM_HIP_F32 && y_dtype != MLLM_HIP_F16) return MLLM_HIP_ERR_DTYPE;
+    if (M <= 0) return MLLM_HIP_OK;
+    if (!Wpacked || !xpack) return MLLM_HIP_ERR_ARG;
+    return launch_gemm_packed(Wpacked, bias, xpack, y, y_dtype, ldy, residual, M, N, K, as_stream(stream));
+}
 // GEMM on pre-packed weights; xpack = scratch of mllm_hip_q4k_prepack_bytes(M, K) bytes for the activation side
 extern "C" int mllm_hip_linear_q4kp_q8k(const void *Wpacked, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums, void *xpack,
                                         void *y, int y_dtype, int64_t ldy, const float *residual, int M, int N, int K, void *stream) {
@@ -505,16 +522,7 @@ extern "C" int mllm_hip_linear_q4kp_q8k(const void *Wpacked, const float *bias, 
     hipLaunchKernelGGL(q8k_prepack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, xqs, xd, xbsums, (uint8_t *)xpack, M, nb);
     int rc = MH_LAUNCH_OK("q8k_prepack");
     if (rc) return rc;
-    dim3 grid((N + 63) / 64, (M + 63) / 64);
-    constexpr int lds = GQ_LDS + 1024;   // ring + scratch tail
-    static bool attr_set = false;
-    if (!attr_set) {
-        MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_q4k_kernel, grid, dim3(GQ_NT), lds, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16, ldy, residual,
-                       M, N, nb);
-    return MH_LAUNCH_OK("gemm_q4k");
+    return launch_gemm_packed(Wpacked, bias, xpack, y, y_dtype, ldy, residual, M, N, K, st);
 }
 
 extern "C" int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums, void *y,

@@ -227,6 +227,29 @@ def flash_attention2(q, k, v, Sq, Sk, Hq, Hkv, D, causal, sk_dev=None):
     return o
 
 
+def linear_q4k_packed_producers(Wq, x, N, mode="quant", w=None, b=None, eps=1e-6):
+    """Prefill path of the resident engine: the producer (quantiser / RMSNorm / LayerNorm) writes the packed activation operand, the
+    GEMM consumes it.  Returns y = Linear(producer(x))."""
+    x = _dev(x, torch.float32)
+    M, K = x.shape
+    Wd = _dev(np.asarray(Wq).view(np.uint8))
+    lib_ = L.load()
+    lib_.mllm_hip_q4k_prepack_bytes.restype = C.c_size_t
+    wp = torch.empty(lib_.mllm_hip_q4k_prepack_bytes(C.c_int(N), C.c_int(K)), dtype=torch.uint8, device="cuda")
+    xp = torch.empty(lib_.mllm_hip_q4k_prepack_bytes(C.c_int(M), C.c_int(K)), dtype=torch.uint8, device="cuda")
+    check(lib_.mllm_hip_q4k_prepack(vp(Wd), C.c_int(N), C.c_int(K), vp(wp), _stream()), "q4k_prepack")
+    if mode == "quant":
+        check(lib_.mllm_hip_quantize_q8k_packed(vp(x), vp(xp), C.c_int(M), C.c_int(K), _stream()), "quantize_q8k_packed")
+    elif mode == "rms":
+        check(lib_.mllm_hip_rmsnorm_packed(vp(x), vp(_dev(w, torch.float32)), None, vp(xp), C.c_int(M), C.c_int(K), C.c_float(eps), C.c_int(0), _stream()), "rmsnorm_packed")
+    else:
+        wb = _dev(b, torch.float32) if b is not None else None
+        check(lib_.mllm_hip_layernorm_packed(vp(x), vp(_dev(w, torch.float32)), vp(wb), None, vp(xp), C.c_int(M), C.c_int(K), C.c_float(eps), _stream()), "layernorm_packed")
+    y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    check(lib_.mllm_hip_linear_q4kp_packed(vp(wp), None, vp(xp), vp(y), C.c_int(F32), i64(N), None, C.c_int(M), C.c_int(N), C.c_int(K), _stream()), "linear_q4kp_packed")
+    return y
+
+
 def flash_attention2_vt(q, k16, v_f32, Sq, Sk, Hq, Hkv, D, causal):
     """Same attention on the resident engine's KV layout: K fp16 rows, V stored transposed (mllm_hip_store_f16_t) with padded rows."""
     q, k16, v_f32 = _dev(q, torch.float32), _dev(k16, torch.float16), _dev(v_f32, torch.float32)

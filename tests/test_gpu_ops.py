@@ -98,6 +98,18 @@ def test_linear_q4k_fp16_out_and_residual():
     assert eq(y2, orc.linear(x2, Wq2, orc.Q4_K, 128) + res2)
 
 
+@pytest.mark.parametrize("M,K,N", [(40, 1536, 256), (282, 1536, 2048), (1024, 1280, 384), (33, 512, 96), (16, 256, 64)])
+def test_linear_on_packed_producers(M, K, N):
+    """Prefill path: quantiser / RMSNorm / LayerNorm write the GEMM's packed activation operand directly; same bits as norm -> Linear."""
+    Wq, x, _ = _q4k_case(M, K, N, M + 3 * K + N, bias=False)
+    r = rng(M + K)
+    w = (1 + 0.1 * r.standard_normal(K)).astype(np.float32)
+    b = (0.1 * r.standard_normal(K)).astype(np.float32)
+    assert eq(ops.linear_q4k_packed_producers(Wq, x, N, "quant"), orc.linear(x, Wq, orc.Q4_K, N))
+    assert eq(ops.linear_q4k_packed_producers(Wq, x, N, "rms", w=w), orc.linear(orc.rmsnorm(x, w, 1e-6), Wq, orc.Q4_K, N))
+    assert eq(ops.linear_q4k_packed_producers(Wq, x, N, "ln", w=w, b=b), orc.linear(orc.layernorm(x, w, b, 1e-6), Wq, orc.Q4_K, N))
+
+
 def test_linear_golden_reference(ops_gold):
     g = ops_gold
     for x, yref in ((g["lin_x5"], g["lin_y5"]), (g["lin_x1"], g["lin_y1"])):
