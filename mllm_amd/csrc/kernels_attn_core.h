@@ -142,8 +142,12 @@ struct DecodeGeom {
 template <int D, bool F16, int NT, bool VT>
 struct DecodePrefetch {
     uint4 v[4][DecodeGeom<D, F16, NT, VT>::VPT];
-    uint2 k[F16 ? D / 8 : 1];
+    uint2 k[F16 ? D / 8 : 1];     // direct form: this lane's half of its key row (strided 8-byte pieces)
+    uint4 kc[VT ? D / 16 : 1];    // staged form: coalesced 16-byte pieces of the pass-0 key rows, parked in the (not yet used) V ring
 };
+// pass-0 keys staged through LDS: rows [NT/2][D fp16] at pitch D*2+16 bytes in the ring area; needs the full 4-slot ring
+template <int D>
+__host__ __device__ constexpr int fa_kpitch() { return D * 2 + 16; }
 template <int D, bool F16, int NT, bool VT>
 __device__ __forceinline__ void fa2_decode_fetch_v(uint4 *dst, const void *V, int64_t ldv, int kvoff, int ch, int cap) {
     using G = DecodeGeom<D, F16, NT, VT>;
@@ -160,13 +164,21 @@ __device__ __forceinline__ void fa2_decode_fetch_v(uint4 *dst, const void *V, in
 template <int D, bool F16, int NT, bool VT>
 __device__ __forceinline__ void fa2_decode_prefetch(DecodePrefetch<D, F16, NT, VT> &P, const void *K, int64_t ldk, const void *V, int64_t ldv, int kvoff,
                                                     int cap, int nslots) {
-    if (F16) {
+    if (VT && nslots == 4) {
+        // coalesced: one wave instruction = 1 KiB of consecutive key rows (the strided per-lane form below costs one cache line per lane)
+        constexpr int ROWK = D * 2 / 16;
+#pragma unroll
+        for (int i = 0; i < D / 16; ++i) {
+            const int vi = threadIdx.x + NT * i, key = min(vi / ROWK, cap - 1), part = vi % ROWK;
+            P.kc[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(K) + (int64_t)key * ldk + kvoff + part * 8);
+        }
+    } else if (F16) {
         const int j = min((int)threadIdx.x >> 1, cap - 1), hf = threadIdx.x & 1;
         const uint16_t *kp = reinterpret_cast<const uint16_t *>(K) + (int64_t)j * ldk + kvoff + 4 * hf;
 #pragma unroll
         for (int i = 0; i < D / 8; ++i) P.k[i] = *reinterpret_cast<const uint2 *>(kp + 8 * i);
     }
-    (void)V; (void)ldv; (void)nslots;   // the V chunks are requested once Sk is known (fa2_decode_head): they are not needed before phase C
+    (void)V; (void)ldv;   // the V chunks are requested once Sk is known (fa2_decode_head): they are not needed before phase C
 }
 
 template <int D, bool F16, int NT, bool VT = false>
@@ -195,9 +207,19 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
     };
     STAMP(0);
     STAMPCLK(6);
+    const bool kstaged = VT && L.nslots == 4;
+    if (kstaged) {
+        constexpr int ROWK = D * 2 / 16;
+#pragma unroll
+        for (int i = 0; i < (VT ? D / 16 : 1); ++i) {
+            const int vi = tid + NT * i;
+            *reinterpret_cast<uint4 *>(L.vring + (size_t)(vi / ROWK) * fa_kpitch<D>() + (vi % ROWK) * 16) = P.kc[i];
+        }
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
         if (s < npre) fa2_decode_fetch_v<D, F16, NT, VT>(P.v[s], V, ldv, kvoff, s, cap);
+    if (kstaged) __syncthreads();
     // ---- A + B: two lanes per key (chains l = 0..3 and 4..7), NT/2 keys per pass ------------------------------------------------------
     float carry = FA_NEG;
     for (int base = 0; base < Sk; base += NT / 2) {
@@ -211,6 +233,10 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
                 if (knew && j == tnew) {
 #pragma unroll
                     for (int i = 0; i < D / 8; ++i) kw[i] = *reinterpret_cast<const uint2 *>(knew + 8 * i + 4 * hf);
+                } else if (base == 0 && kstaged) {
+                    const char *kr = L.vring + (size_t)(tid >> 1) * fa_kpitch<D>() + 8 * hf;
+#pragma unroll
+                    for (int i = 0; i < D / 8; ++i) kw[i] = *reinterpret_cast<const uint2 *>(kr + 16 * i);
                 } else if (base == 0) {
 #pragma unroll
                     for (int i = 0; i < D / 8; ++i) kw[i] = P.k[i];
