@@ -315,7 +315,60 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
         const bool refill = ch + L.nslots < nch;
         if (refill) fa2_decode_fetch_v<D, F16, NT, VT>(vref, V, ldv, kvoff, ch + L.nslots, cap);
         const int j0 = ch * FA_VCH, n = min(FA_VCH, nkv - j0);
-        if (walker) {
+        if (walker && VT) {
+            // transposed ring, 16 keys per step, LDS reads issued TWO steps ahead of the fma chain that consumes them (a three-stage register
+            // ring: raw fp16 pairs + the 16 p's + the mask), so the dependent chain never waits on LDS latency
+            const char *row = L.vring + (size_t)(ch % L.nslots) * SLOT + (size_t)tid * FA_VPITCH;
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            struct Stage { u32x4 v0, v1; f32x4 p[4]; int m; };
+            Stage S0, S1, S2;
+            auto rd = [&](int k16, Stage &S) {
+                const int kk = min(k16, FA_VCH - 16);
+                S.v0 = *reinterpret_cast<const u32x4 *>(row + kk * 2);
+                S.v1 = *reinterpret_cast<const u32x4 *>(row + kk * 2 + 16);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) S.p[q4] = *reinterpret_cast<const f32x4 *>(L.p + j0 + kk + 4 * q4);
+                S.m = *reinterpret_cast<const uint16_t *>(L.cmask + ((j0 + kk) >> 3));
+            };
+            auto step = [&](int k16, const Stage &S) {
+                const unsigned w[8] = {S.v0[0], S.v0[1], S.v0[2], S.v0[3], S.v1[0], S.v1[1], S.v1[2], S.v1[3]};
+                const int m16 = __builtin_amdgcn_readfirstlane(S.m);
+                if (m16 == 0 && k16 + 16 <= n) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) o = __fmaf_rn(S.p[k >> 2][k & 3], h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff))), o);
+                } else if (k16 + 16 <= n) {
+                    // some maximum moved inside these 16 keys: c is exactly 1.0f wherever it did not, so the rescale needs no select
+                    f32x4 cq[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + j0 + k16 + 4 * q4);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        o = o * cq[k >> 2][k & 3];
+                        o = __fmaf_rn(S.p[k >> 2][k & 3], h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff))), o);
+                    }
+                } else {
+                    f32x4 cq[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + j0 + k16 + 4 * q4);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const bool in = k16 + k < n;            // keys past the end: c = 1, p = 0, v = 0
+                        const float vk = h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff)));
+                        o = o * (in ? cq[k >> 2][k & 3] : 1.0f);
+                        o = __fmaf_rn(in ? S.p[k >> 2][k & 3] : 0.0f, in ? vk : 0.0f, o);
+                    }
+                }
+            };
+            rd(0, S0);
+            rd(16, S1);
+            for (int k16 = 0; k16 < n; k16 += 48) {
+                rd(k16 + 32, S2);
+                step(k16, S0);
+                if (k16 + 16 < n) { rd(k16 + 48, S0); step(k16 + 16, S1); }
+                if (k16 + 32 < n) { rd(k16 + 64, S1); step(k16 + 32, S2); }
+            }
+        } else if (walker) {
             // 16 keys per step, the next step's LDS reads issued before this step's fma chain
             const char *slot = L.vring + (size_t)(ch % L.nslots) * SLOT;
             float va[16], vb[16];
@@ -384,6 +437,14 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
                 if (m16 == 0 && k16 + 16 <= ns) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) lsum = lsum + ps[k];
+                } else if (k16 + 16 <= ns) {
+                    float4 cq[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const float4 *>(L.c + j0 + k16 + 4 * q4);
+                    const float cs[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
+                                          cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) lsum = __fmaf_rn(lsum, cs[k], ps[k]);
                 } else {
                     float4 cq[4];
 #pragma unroll
