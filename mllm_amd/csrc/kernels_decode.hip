@@ -649,10 +649,13 @@ static int launch_proj(const uint8_t *W, const float *xin, const float *residual
 #ifndef PJ_ROWS5
 #define PJ_ROWS5 1
 #endif
+#ifndef PJ_WPB5
+#define PJ_WPB5 8
+#endif
 #ifndef PJ_WPB1
 #define PJ_WPB1 8
 #endif
-    constexpr int ROWS = NS == 1 ? PJ_ROWS1 : PJ_ROWS5, WPB = NS >= 3 ? 16 : PJ_WPB1;   // long rows: 1024-thread workgroups share the row quantisation
+    constexpr int ROWS = NS == 1 ? PJ_ROWS1 : PJ_ROWS5, WPB = NS >= 3 ? PJ_WPB5 : PJ_WPB1;   // long rows: 1024-thread workgroups share the row quantisation
     const int waves = (N + ROWS - 1) / ROWS;
     const size_t lds = fused_lds_bytes<NS, ROWS>(K, false, WPB);
     auto kern = dec_proj_kernel<NS, ROWS, WPB>;
