@@ -148,6 +148,8 @@ struct DecodePrefetch {
 // pass-0 keys staged through LDS: rows [NT/2][D fp16] at pitch D*2+16 bytes in the ring area; needs the full 4-slot ring
 template <int D>
 __host__ __device__ constexpr int fa_kpitch() { return D * 2 + 16; }
+template <int D, int NT>
+__host__ __device__ constexpr bool fa_kstage_fits() { return (size_t)(NT / 2) * fa_kpitch<D>() <= (size_t)4 * D * (FA_VCH * 2 + 16); }
 template <int D, bool F16, int NT, bool VT>
 __device__ __forceinline__ void fa2_decode_fetch_v(uint4 *dst, const void *V, int64_t ldv, int kvoff, int ch, int cap) {
     using G = DecodeGeom<D, F16, NT, VT>;
@@ -164,7 +166,7 @@ __device__ __forceinline__ void fa2_decode_fetch_v(uint4 *dst, const void *V, in
 template <int D, bool F16, int NT, bool VT>
 __device__ __forceinline__ void fa2_decode_prefetch(DecodePrefetch<D, F16, NT, VT> &P, const void *K, int64_t ldk, const void *V, int64_t ldv, int kvoff,
                                                     int cap, int nslots) {
-    if (VT && nslots == 4) {
+    if (VT && nslots == 4 && fa_kstage_fits<D, NT>()) {
         // coalesced: one wave instruction = 1 KiB of consecutive key rows (the strided per-lane form below costs one cache line per lane)
         constexpr int ROWK = D * 2 / 16;
 #pragma unroll
@@ -207,7 +209,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
     };
     STAMP(0);
     STAMPCLK(6);
-    const bool kstaged = VT && L.nslots == 4;
+    const bool kstaged = VT && L.nslots == 4 && fa_kstage_fits<D, NT>();
     if (kstaged) {
         constexpr int ROWK = D * 2 / 16;
 #pragma unroll

@@ -292,7 +292,8 @@ def test_fa2_vs_oracle(Sq, Sk, Hq, Hkv, D, causal, f16):
     assert eq(o, ref), md(o, ref)
 
 
-@pytest.mark.parametrize("Sq,Sk,Hq,Hkv,D", [(282, 282, 12, 2, 128), (40, 40, 12, 2, 128), (1, 300, 12, 2, 128), (3, 50, 4, 2, 64), (21, 23, 4, 2, 128), (1, 1, 2, 1, 128)])
+@pytest.mark.parametrize("Sq,Sk,Hq,Hkv,D", [(282, 282, 12, 2, 128), (40, 40, 12, 2, 128), (1, 300, 12, 2, 128), (3, 50, 4, 2, 64), (21, 23, 4, 2, 128), (1, 1, 2, 1, 128),
+                                            (1, 700, 12, 2, 128), (1, 1500, 4, 2, 128), (1, 513, 2, 1, 64), (600, 600, 4, 2, 128)])
 def test_fa2_on_the_engine_kv_layout(Sq, Sk, Hq, Hkv, D):
     """K fp16 rows + V transposed fp16 (the resident slab layout): same bits as the reference layout."""
     r = rng(Sq + 7 * Sk)
