@@ -86,3 +86,25 @@ def test_kv_overflow_is_an_error_not_a_crash(tiny_model):
     with pytest.raises(lib.MllmHipError):
         m.decode(5)
     m.clear_kvcache()
+
+
+def test_long_context_crosses_the_score_pass_and_ring_boundaries(tmp_path):
+    """A 530-token text prompt + decode steps on a 640-entry cache: prefill attention over 17 key chunks, then decode attention with
+    T > 512 (second score pass, V ring refills), against the oracle's composition of the same graph (oracle/models.py)."""
+    from oracle import models as omodels
+    cfg = synth.qwen2vl_tiny()
+    path = weights.qwen2vl_file(cfg, cache_dir=str(tmp_path))
+    m = lib.Qwen2VL(cfg, path, cache_limit=640)
+    try:
+        ids = (np.arange(530, dtype=np.int64) * 7919 % 2000).astype(np.int32)
+        ref = omodels.LLM(omodels.Weights(path), cfg)
+        want = ref.prefill(ids)
+        tok, logits, _ = m.prefill(ids)
+        assert np.array_equal(logits, want), float(np.abs(logits - want).max())
+        for _ in range(5):
+            want = ref.decode(tok)
+            tok, logits, _ = m.decode(tok)
+            assert np.array_equal(logits, want), float(np.abs(logits - want).max())
+            assert tok == int(np.argmax(want))
+    finally:
+        m.close()
