@@ -140,14 +140,18 @@ __device__ __forceinline__ float first_flagged(bool flag, float mine) {
 // expf exactly as the reference's attention gets it from glibc 2.35 libm on an AVX2+FMA x86-64 host (__expf_fma: N = 32 table,
 // cubic in double, kd = fma(InvLn2N, x, Shift), r = fma(InvLn2N, x, -(kd - Shift))); oracle/restate.c:orc_expf is the same
 // restatement and is checked against libm on ~10^9 arguments.  Finite or -inf arguments only.
-__device__ __forceinline__ float glibc_expf(float x) {
-    static constexpr uint64_t T[32] = {
-        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
-        0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
-        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
-        0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
-        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
-        0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+// The 2^(i/32) table is read through `T`: kernels stage EXPF_TAB into LDS once (expf_tab_stage) -- indexed straight from constant
+// memory every call is a dependent global load (cold after each layer's weight stream) on the softmax's critical path.
+static __device__ const uint64_t EXPF_TAB[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+__device__ __forceinline__ uint64_t expf_tab_fetch() { return EXPF_TAB[threadIdx.x & 31]; }   // issue early, store with expf_tab_store
+__device__ __forceinline__ void expf_tab_store(uint64_t *lds_tab, uint64_t v) { if (threadIdx.x < 32) lds_tab[threadIdx.x] = v; }
+__device__ __forceinline__ float glibc_expf(float x, const uint64_t *T) {
     if (x < -0x1.9fe368p6f) return 0.0f;
     if (x < -0x1.9d1d9ep6f) return 0x1p-149f;
     if (x > 0x1.62e42ep6f) return __int_as_float(0x7f800000);

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
     __shared__ float Cc[32 * 8], Sm[32 * 8];
     __shared__ float m_in[32], l_s[32];
     __shared__ int moved_any[8];
+    __shared__ uint64_t etab[32];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, kvh = head / (Hq / Hkv);
     const int r0 = blockIdx.x * FA_R;
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
             for (int sI = 0; sI < NS; ++sI) qreg[l2][sI] = qrow[8 * (2 * sI + h) + 2 * wid + l2];
     }
     if (tid < 32) { m_in[tid] = FA_NEG; l_s[tid] = 0.0f; }
+    expf_tab_store(etab, expf_tab_fetch());
     int klim = sk_eff;
     if (causal) klim = min(sk_eff, r0 + FA_R + delta + 4);   // tiles beyond are skipped for every row of this workgroup
     v16f_t oacc;
@@ -157,11 +159,13 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
             const float excl = tile == 0 ? carry : prev;
             float p4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, cc = 1.0f, sum = 0.0f;
             if (live) {
-                if (excl != incl) { cc = glibc_expf((excl - incl) * scale); moved_any[tile] = 1; }
-                p4[0] = glibc_expf((s4[0] - incl) * scale);
-                if (nc > 1) p4[1] = glibc_expf((s4[1] - incl) * scale);
-                if (nc > 2) p4[2] = glibc_expf((s4[2] - incl) * scale);
-                if (nc > 3) p4[3] = glibc_expf((s4[3] - incl) * scale);
+                if (excl != incl) { cc = glibc_expf((excl - incl) * scale, etab); moved_any[tile] = 1; }
+                // all four columns unconditionally (independent chains for the scheduler); columns past the end hold finite scores of
+                // the clamped last key row and are zeroed afterwards
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p4[e] = glibc_expf((s4[e] - incl) * scale, etab);
+#pragma unroll
+                for (int e = 1; e < 4; ++e) p4[e] = e < nc ? p4[e] : 0.0f;
                 sum = ((p4[0] + p4[1]) + p4[2]) + p4[3];
             }
 #pragma unroll

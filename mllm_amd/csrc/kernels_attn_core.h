@@ -5,8 +5,11 @@
 #ifndef STAMP
 #define STAMP(i)
 #endif
-#ifndef STAMPCLK
-#define STAMPCLK(i)
+#ifndef STAMPT
+#define STAMPT(i, t)
+#endif
+#ifndef STAMPV
+#define STAMPV(i, v)
 #endif
 
 namespace mllm_hip {
@@ -94,13 +97,14 @@ __device__ __forceinline__ float qk_dot_row(const float *q, const void *base, in
 constexpr int FA_VCH = 128;
 struct DecodeLds {
     float *p, *c, *qs, *ob, *wred;
+    uint64_t *etab;      // glibc_expf's 2^(i/32) table
     uint8_t *cmask;
     char *vring;
     int nslots;
 };
 __host__ __device__ static inline size_t decode_lds_fixed(int cap, int D, int NT) {
     const size_t capr = (size_t)((cap + 63) & ~63);
-    return capr * 8 + capr / 8 + (size_t)(2 * D + NT / 64 + 2) * 4 + 64;
+    return capr * 8 + capr / 8 + (size_t)(2 * D + NT / 64 + 2) * 4 + 64 + 256;
 }
 __host__ __device__ static inline size_t decode_lds_bytes(int cap, int D, int NT, int elt, int nslots, bool vt = false) {
     return ((decode_lds_fixed(cap, D, NT) + 15) & ~(size_t)15) + (size_t)nslots * (vt ? (size_t)D * (FA_VCH * 2 + 16) : (size_t)FA_VCH * D * elt);
@@ -119,6 +123,7 @@ __device__ __forceinline__ DecodeLds carve_decode(char *smem, int cap, int D, in
     L.qs = reinterpret_cast<float *>(smem + ((capr * 8 + capr / 8 + 15) & ~(size_t)15));
     L.ob = L.qs + D;
     L.wred = L.ob + D;
+    L.etab = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(L.wred + NT / 64 + 2) + 15) & ~(uintptr_t)15);
     L.vring = smem + ((decode_lds_fixed(cap, D, NT) + 15) & ~(size_t)15);
     L.nslots = nslots;
     return L;
@@ -208,7 +213,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
         }
     };
     STAMP(0);
-    STAMPCLK(6);
+    const uint64_t etab_v = expf_tab_fetch();
     const bool kstaged = VT && L.nslots == 4 && fa_kstage_fits<D, NT>();
     if (kstaged) {
         constexpr int ROWK = D * 2 / 16;
@@ -271,6 +276,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
         // prefix maximum over keys = over lane pairs: scan the wave (both lanes of a pair hold the same s), then the wave totals
         const float wincl = wave_scan_max(s);
         if (lane == 63) L.wred[wid] = wincl;
+        if (base == 0) expf_tab_store(L.etab, etab_v);
         __syncthreads();
         float before = carry, tot = carry;
 #pragma unroll
@@ -289,10 +295,17 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
         const float up2 = wave_shift_up(up1, before);
         const float excl = hf ? up2 : up1;
         const bool moved = j < Sk && excl != incl;
-        if (j < Sk && hf == 0) {
-            L.c[j] = moved ? glibc_expf((excl - incl) * scale) : 1.0f;
-            L.p[j] = glibc_expf((s - incl) * scale);
+#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 32)
+        if (base == 0) STAMP(5);
+#endif
+        // one expf per lane: the even lane of a key's pair takes p, the odd lane c (expf(0) is exactly 1.0f when the maximum stayed)
+        if (j < Sk) {
+            const float e = glibc_expf(((hf ? excl : s) - incl) * scale, L.etab);
+            (hf ? L.c : L.p)[j] = e;
         }
+#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 32)
+        if (base == 0) STAMP(6);
+#endif
         // one mask bit per key: even lanes' ballot bits, compacted
         unsigned long long mv = __ballot(moved && hf == 0);
         mv = (mv | (mv >> 1)) & 0x3333333333333333ull; mv = (mv | (mv >> 2)) & 0x0f0f0f0f0f0f0f0full; mv = (mv | (mv >> 4)) & 0x00ff00ff00ff00ffull;
@@ -311,34 +324,58 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
     // c_j is stored as exactly 1.0f when the maximum did not move, so "o * c" and "fma(logsum, c, p)" may be evaluated for every key
     // (x * 1.0f == x, fma(x, 1.0f, p) == x + p bit for bit); the mask only spares the common step the LDS reads of c.
     float o = 0.0f, lsum = 0.0f;
+    unsigned long long nresc = 0;
     const bool walker = tid < D, summer = tid == ((D + 63) & ~63);
     uint4 vref[VPT];
     for (int ch = 0; ch < nch; ++ch) {
         const bool refill = ch + L.nslots < nch;
         if (refill) fa2_decode_fetch_v<D, F16, NT, VT>(vref, V, ldv, kvoff, ch + L.nslots, cap);
         const int j0 = ch * FA_VCH, n = min(FA_VCH, nkv - j0);
+        // the chunk's 128 mask bits, wave-uniform in SGPRs (one LDS read per chunk instead of one per step on the critical path)
+        unsigned long long chunk_mask_lo, chunk_mask_hi;
+        {
+            typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
+            const u32x4m mw = *reinterpret_cast<const u32x4m *>(L.cmask + (j0 >> 3));
+            chunk_mask_lo = (unsigned long long)__builtin_amdgcn_readfirstlane(mw[0]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(mw[1]) << 32);
+            chunk_mask_hi = (unsigned long long)__builtin_amdgcn_readfirstlane(mw[2]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(mw[3]) << 32);
+        }
         if (walker && VT) {
             // transposed ring, 16 keys per step, LDS reads issued TWO steps ahead of the fma chain that consumes them (a three-stage register
             // ring: raw fp16 pairs + the 16 p's + the mask), so the dependent chain never waits on LDS latency
             const char *row = L.vring + (size_t)(ch % L.nslots) * SLOT + (size_t)tid * FA_VPITCH;
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            struct Stage { u32x4 v0, v1; f32x4 p[4]; int m; };
+            struct Stage { u32x4 v0, v1; f32x4 p[4]; };
             Stage S0, S1, S2;
+            const unsigned long long cm_lo = chunk_mask_lo, cm_hi = chunk_mask_hi;
             auto rd = [&](int k16, Stage &S) {
                 const int kk = min(k16, FA_VCH - 16);
+#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 1)
+                S.v0 = u32x4{0x3c003c00u + kk, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; S.v1 = S.v0;
+#else
                 S.v0 = *reinterpret_cast<const u32x4 *>(row + kk * 2);
                 S.v1 = *reinterpret_cast<const u32x4 *>(row + kk * 2 + 16);
+#endif
 #pragma unroll
+#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 2)
+                for (int q4 = 0; q4 < 4; ++q4) S.p[q4] = f32x4{1.0f + k16, 2.0f, 3.0f, 4.0f + q4};
+#else
                 for (int q4 = 0; q4 < 4; ++q4) S.p[q4] = *reinterpret_cast<const f32x4 *>(L.p + j0 + kk + 4 * q4);
-                S.m = *reinterpret_cast<const uint16_t *>(L.cmask + ((j0 + kk) >> 3));
+#endif
             };
             auto step = [&](int k16, const Stage &S) {
                 const unsigned w[8] = {S.v0[0], S.v0[1], S.v0[2], S.v0[3], S.v1[0], S.v1[1], S.v1[2], S.v1[3]};
-                const int m16 = __builtin_amdgcn_readfirstlane(S.m);
+                const int m16 = (int)(((k16 & 64) ? cm_hi : cm_lo) >> (k16 & 63)) & 0xffff;
+#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 4)
+                nresc += (m16 != 0) + ((uint64_t)__builtin_popcount(m16) << 32);
+#endif
                 if (m16 == 0 && k16 + 16 <= n) {
+#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 16)
+                    o = __fmaf_rn(S.p[0][0] + S.p[1][1] + S.p[2][2] + S.p[3][3], h2f((uint16_t)(w[0] ^ w[7] ^ w[3] ^ w[4])), o);
+#else
 #pragma unroll
                     for (int k = 0; k < 16; ++k) o = __fmaf_rn(S.p[k >> 2][k & 3], h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff))), o);
+#endif
                 } else if (k16 + 16 <= n) {
                     // some maximum moved inside these 16 keys: c is exactly 1.0f wherever it did not, so the rescale needs no select
                     f32x4 cq[4];
@@ -427,43 +464,54 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
             }
         }
         else if (summer) {
-            // logsum = fma(logsum, c, p).  The last chunk also takes the appended key.
+            // logsum = fma(logsum, c, p).  The last chunk also takes the appended key.  The p's (and the mask) of the next 16 keys are
+            // read before this step's dependent adds, so the lane pays the LDS latency once per chunk instead of once per step.
             const int ns = ch == nch - 1 ? Sk - j0 : n;
-            for (int k16 = 0; k16 < ns; k16 += 16) {
-                float4 pp[4];
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            struct SStage { f32x4 p[4]; };
+            SStage A, B;
+            auto rd = [&](int k16, SStage &S) {
+                const int kk = min(k16, ((ns + 15) & ~15) - 16);
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) pp[q4] = *reinterpret_cast<const float4 *>(L.p + j0 + k16 + 4 * q4);
-                const int m16 = *reinterpret_cast<const uint16_t *>(L.cmask + ((j0 + k16) >> 3));
-                const float ps[16] = {pp[0].x, pp[0].y, pp[0].z, pp[0].w, pp[1].x, pp[1].y, pp[1].z, pp[1].w,
-                                      pp[2].x, pp[2].y, pp[2].z, pp[2].w, pp[3].x, pp[3].y, pp[3].z, pp[3].w};
+                for (int q4 = 0; q4 < 4; ++q4) S.p[q4] = *reinterpret_cast<const f32x4 *>(L.p + j0 + kk + 4 * q4);
+            };
+            auto step = [&](int k16, const SStage &S) {
+                const int m16 = (int)(((k16 & 64) ? chunk_mask_hi : chunk_mask_lo) >> (k16 & 63)) & 0xffff;
                 if (m16 == 0 && k16 + 16 <= ns) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) lsum = lsum + ps[k];
-                } else if (k16 + 16 <= ns) {
-                    float4 cq[4];
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const float4 *>(L.c + j0 + k16 + 4 * q4);
-                    const float cs[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
-                                          cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) lsum = __fmaf_rn(lsum, cs[k], ps[k]);
+                    for (int k = 0; k < 16; ++k) lsum = lsum + S.p[k >> 2][k & 3];
                 } else {
-                    float4 cq[4];
+                    f32x4 cq[4];
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const float4 *>(L.c + j0 + k16 + 4 * q4);
-                    const float cs[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
-                                          cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + j0 + k16 + 4 * q4);
+                    if (k16 + 16 <= ns) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const bool in = k16 + k < ns;
-                        lsum = __fmaf_rn(lsum, in ? cs[k] : 1.0f, in ? ps[k] : 0.0f);
+                        for (int k = 0; k < 16; ++k) lsum = __fmaf_rn(lsum, cq[k >> 2][k & 3], S.p[k >> 2][k & 3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const bool in = k16 + k < ns;
+                            lsum = __fmaf_rn(lsum, in ? cq[k >> 2][k & 3] : 1.0f, in ? S.p[k >> 2][k & 3] : 0.0f);
+                        }
                     }
                 }
+            };
+            if (ns > 0) rd(0, A);
+            for (int k16 = 0; k16 < ns; k16 += 32) {
+                rd(k16 + 16, B);
+                step(k16, A);
+                if (k16 + 16 < ns) { rd(k16 + 32, A); step(k16 + 16, B); }
             }
         }
+#if !(defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 32))
+        if (ch == nch - 1) { STAMPT(5, 0); STAMPT(6, 64); STAMPT(7, (D + 63) & ~63); }
+#endif
         __syncthreads();
         if (refill) park_chunk(ch + L.nslots, vref);
     }
+#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 4)
+    STAMPV(0, nresc);
+#endif
     if (walker && VT && vnew) {   // the appended token: rescale (always a multiply in the reference), then its value row
         o = o * L.c[Sk - 1];
         o = __fmaf_rn(L.p[Sk - 1], h2f(vnew[tid]), o);
@@ -472,8 +520,6 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
         if (nch == 0) lsum = __fmaf_rn(lsum, L.c[0], L.p[0]);   // Sk == 1 with the appended key only
         L.wred[NT / 64] = lsum;
     }
-    STAMP(5);
-    STAMPCLK(7);
     __syncthreads();
     if (walker) L.ob[tid] = o * (1.0f / L.wred[NT / 64]);
     __syncthreads();

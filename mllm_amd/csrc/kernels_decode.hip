@@ -52,6 +52,15 @@ __device__ unsigned long long g_stamps[8192 * 8];
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
+#define STAMPV(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = (v); } while (0)
+#define STAMPT(i, t)                                                                                     \
+    do {                                                                                                 \
+        if (threadIdx.x == (t) && blockIdx.x < 8192) {                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+        }                                                                                                \
+    } while (0)
 #else
 #define STAMP(i)
 #endif

@@ -1,6 +1,9 @@
 import sys, numpy as np
 sys.path.insert(0, '.')
-from mllm_amd import lib, synth, weights
+from mllm_amd import lib
+import os
+if len(sys.argv) > 1: lib.SO_PATH = os.path.abspath(sys.argv[1])
+from mllm_amd import synth, weights
 cfg = synth.qwen2vl_2b(); path = weights.qwen2vl_file(cfg)
 m = lib.Qwen2VL(cfg, path)
 for n in (8, 64, 136, 264, 392, 520, 776):
