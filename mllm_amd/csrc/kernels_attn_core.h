@@ -295,17 +295,11 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
         const float up2 = wave_shift_up(up1, before);
         const float excl = hf ? up2 : up1;
         const bool moved = j < Sk && excl != incl;
-#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 32)
-        if (base == 0) STAMP(5);
-#endif
         // one expf per lane: the even lane of a key's pair takes p, the odd lane c (expf(0) is exactly 1.0f when the maximum stayed)
         if (j < Sk) {
             const float e = glibc_expf(((hf ? excl : s) - incl) * scale, L.etab);
             (hf ? L.c : L.p)[j] = e;
         }
-#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 32)
-        if (base == 0) STAMP(6);
-#endif
         // one mask bit per key: even lanes' ballot bits, compacted
         unsigned long long mv = __ballot(moved && hf == 0);
         mv = (mv | (mv >> 1)) & 0x3333333333333333ull; mv = (mv | (mv >> 2)) & 0x0f0f0f0f0f0f0f0full; mv = (mv | (mv >> 4)) & 0x00ff00ff00ff00ffull;
@@ -324,7 +318,6 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
     // c_j is stored as exactly 1.0f when the maximum did not move, so "o * c" and "fma(logsum, c, p)" may be evaluated for every key
     // (x * 1.0f == x, fma(x, 1.0f, p) == x + p bit for bit); the mask only spares the common step the LDS reads of c.
     float o = 0.0f, lsum = 0.0f;
-    unsigned long long nresc = 0;
     const bool walker = tid < D, summer = tid == ((D + 63) & ~63);
     uint4 vref[VPT];
     for (int ch = 0; ch < nch; ++ch) {
@@ -336,8 +329,8 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
         {
             typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
             const u32x4m mw = *reinterpret_cast<const u32x4m *>(L.cmask + (j0 >> 3));
-            chunk_mask_lo = (unsigned long long)__builtin_amdgcn_readfirstlane(mw[0]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(mw[1]) << 32);
-            chunk_mask_hi = (unsigned long long)__builtin_amdgcn_readfirstlane(mw[2]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(mw[3]) << 32);
+            chunk_mask_lo = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mw[0]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mw[1]) << 32);
+            chunk_mask_hi = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mw[2]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mw[3]) << 32);
         }
         if (walker && VT) {
             // transposed ring, 16 keys per step, LDS reads issued TWO steps ahead of the fma chain that consumes them (a three-stage register
@@ -350,32 +343,17 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
             const unsigned long long cm_lo = chunk_mask_lo, cm_hi = chunk_mask_hi;
             auto rd = [&](int k16, Stage &S) {
                 const int kk = min(k16, FA_VCH - 16);
-#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 1)
-                S.v0 = u32x4{0x3c003c00u + kk, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; S.v1 = S.v0;
-#else
                 S.v0 = *reinterpret_cast<const u32x4 *>(row + kk * 2);
                 S.v1 = *reinterpret_cast<const u32x4 *>(row + kk * 2 + 16);
-#endif
 #pragma unroll
-#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 2)
-                for (int q4 = 0; q4 < 4; ++q4) S.p[q4] = f32x4{1.0f + k16, 2.0f, 3.0f, 4.0f + q4};
-#else
                 for (int q4 = 0; q4 < 4; ++q4) S.p[q4] = *reinterpret_cast<const f32x4 *>(L.p + j0 + kk + 4 * q4);
-#endif
             };
             auto step = [&](int k16, const Stage &S) {
                 const unsigned w[8] = {S.v0[0], S.v0[1], S.v0[2], S.v0[3], S.v1[0], S.v1[1], S.v1[2], S.v1[3]};
                 const int m16 = (int)(((k16 & 64) ? cm_hi : cm_lo) >> (k16 & 63)) & 0xffff;
-#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 4)
-                nresc += (m16 != 0) + ((uint64_t)__builtin_popcount(m16) << 32);
-#endif
                 if (m16 == 0 && k16 + 16 <= n) {
-#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 16)
-                    o = __fmaf_rn(S.p[0][0] + S.p[1][1] + S.p[2][2] + S.p[3][3], h2f((uint16_t)(w[0] ^ w[7] ^ w[3] ^ w[4])), o);
-#else
 #pragma unroll
                     for (int k = 0; k < 16; ++k) o = __fmaf_rn(S.p[k >> 2][k & 3], h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff))), o);
-#endif
                 } else if (k16 + 16 <= n) {
                     // some maximum moved inside these 16 keys: c is exactly 1.0f wherever it did not, so the rescale needs no select
                     f32x4 cq[4];
@@ -503,15 +481,10 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
                 if (k16 + 16 < ns) { rd(k16 + 32, A); step(k16 + 16, B); }
             }
         }
-#if !(defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 32))
         if (ch == nch - 1) { STAMPT(5, 0); STAMPT(6, 64); STAMPT(7, (D + 63) & ~63); }
-#endif
         __syncthreads();
         if (refill) park_chunk(ch + L.nslots, vref);
     }
-#if defined(MLLM_HIP_EXP) && (MLLM_HIP_EXP & 4)
-    STAMPV(0, nresc);
-#endif
     if (walker && VT && vnew) {   // the appended token: rescale (always a multiply in the reference), then its value row
         o = o * L.c[Sk - 1];
         o = __fmaf_rn(L.p[Sk - 1], h2f(vnew[tid]), o);
