@@ -170,3 +170,137 @@ def qwen2vl_inputs(c: Qwen2VLConfig, grid_hw: Tuple[int, int] = (32, 32), n_text
     text = np.random.default_rng(11).integers(0, hi, size=n_text)
     ids = np.concatenate([[c.vision_start_token_id], np.full(n_img_tok, c.image_token_id), [c.vision_end_token_id], text])
     return pix, np.array([1, gh, gw], dtype=np.int32), ids.astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the other BASELINE configs: text-only causal LMs (demo_qwen, demo_tinyllama) and ViT-B/16 (demo_vit)
+# ---------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class CausalLMConfig:
+    """Shape subset of QWenConfig (configuration_qwen.hpp:78-245) / TinyLLaMAConfig (configuration_tinyllama.hpp:10-50): decoder
+    blocks of MultiHeadAttention (HF rotary, fp16 KV cache, FlashAttention2) + gate/up/down SiLU MLP + RMSNorm."""
+    family: str = "qwen"            # "qwen": q/k/v bias, tied lm_head allowed; "tinyllama": no bias, Linear lm_head
+    hidden: int = 1024
+    inter: int = 2816
+    layers: int = 24
+    heads: int = 16
+    kv_heads: int = 16
+    vocab: int = 151936
+    rms_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    cache_limit: int = 400
+    tie_embedding: bool = True
+    target: int = mf.Q4_K           # storage dtype target of the .mllm (mf.F32 for the fp32 TinyLlama config)
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def qkv_bias(self) -> bool:
+        return self.family == "qwen"
+
+
+def qwen15_05b() -> CausalLMConfig:
+    return CausalLMConfig()
+
+
+def qwen15_tiny() -> CausalLMConfig:
+    return CausalLMConfig(hidden=256, inter=768, layers=2, heads=4, kv_heads=4, vocab=2048, cache_limit=96)
+
+
+def tinyllama_11b(target: int = mf.F32) -> CausalLMConfig:
+    return CausalLMConfig(family="tinyllama", hidden=2048, inter=5632, layers=22, heads=32, kv_heads=4, vocab=32000, rope_theta=10000.0,
+                          tie_embedding=False, target=target)
+
+
+def tinyllama_tiny(target: int = mf.F32) -> CausalLMConfig:
+    return CausalLMConfig(family="tinyllama", hidden=256, inter=512, layers=2, heads=4, kv_heads=2, vocab=1024, rope_theta=10000.0,
+                          cache_limit=96, tie_embedding=False, target=target)
+
+
+def causal_lm_tensors(c: CausalLMConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
+    """HFHUBROPE tensor names (configuration_qwen.hpp:30-46, configuration_llama.hpp:39-56)."""
+    H, I, D = c.hidden, c.inter, c.head_dim
+    yield "model.embed_tokens.weight", (c.vocab, H), "w"
+    for i in range(c.layers):
+        p = f"model.layers.{i}."
+        yield p + "input_layernorm.weight", (H,), "norm"
+        for nm, rows in (("q_proj", c.heads * D), ("k_proj", c.kv_heads * D), ("v_proj", c.kv_heads * D)):
+            yield p + f"self_attn.{nm}.weight", (rows, H), "w"
+            if c.qkv_bias:
+                yield p + f"self_attn.{nm}.bias", (rows,), "bias"
+        yield p + "self_attn.o_proj.weight", (H, c.heads * D), "w"
+        yield p + "post_attention_layernorm.weight", (H,), "norm"
+        yield p + "mlp.gate_proj.weight", (I, H), "w"
+        yield p + "mlp.up_proj.weight", (I, H), "w"
+        yield p + "mlp.down_proj.weight", (H, I), "w"
+    yield "model.norm.weight", (H,), "norm"
+    if not c.tie_embedding:
+        yield "lm_head.weight", (c.vocab, H), "w"
+
+
+def causal_lm_ids(c: CausalLMConfig, n: int) -> np.ndarray:
+    return np.random.default_rng(13).integers(0, c.vocab, size=n).astype(np.int32)
+
+
+@dataclass
+class ViTConfig:
+    """ViTConfig("base", 16, 224, classes) (configuration_vit.hpp:86-111)."""
+    hidden: int = 768
+    heads: int = 12
+    ffn: int = 3072
+    blocks: int = 12
+    patch: int = 16
+    img: int = 224
+    classes: int = 1000
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def tokens(self) -> int:
+        return (self.img // self.patch) ** 2 + 1
+
+
+def vit_b16() -> ViTConfig:
+    return ViTConfig()
+
+
+def vit_tiny() -> ViTConfig:
+    return ViTConfig(hidden=256, heads=4, ffn=512, blocks=2, patch=16, img=64, classes=16)
+
+
+def vit_tensors(c: ViTConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
+    """Names of ViTNameConfig::init("vit") (configuration_vit.hpp:27-45) as ViTModel composes them (modeling_vit.hpp:21-104)."""
+    H = c.hidden
+    e = "vit.embeddings."
+    yield e + "patch_embeddings.projection.weight", (H, 3, c.patch, c.patch), "w"
+    yield e + "patch_embeddings.projection.bias", (H,), "bias"
+    yield e + "cls_token", (H,), "w"
+    yield e + "position_embeddings", (c.tokens, H), "w"
+    for i in range(c.blocks):
+        p = f"vit.encoder.layer.{i}."
+        yield p + "layernorm_before.weight", (H,), "norm"
+        yield p + "layernorm_before.bias", (H,), "bias"
+        for nm in ("query", "key", "value"):
+            yield p + f"attention.attention.{nm}.weight", (H, H), "w"
+            yield p + f"attention.attention.{nm}.bias", (H,), "bias"
+        yield p + "attention.output.dense.weight", (H, H), "w"
+        yield p + "attention.output.dense.bias", (H,), "bias"
+        yield p + "layernorm_after.weight", (H,), "norm"
+        yield p + "layernorm_after.bias", (H,), "bias"
+        yield p + "intermediate.dense.weight", (c.ffn, H), "w"
+        yield p + "intermediate.dense.bias", (c.ffn,), "bias"
+        yield p + "output.dense.weight", (H, c.ffn), "w"
+        yield p + "output.dense.bias", (H,), "bias"
+    yield "vit.layernorm.weight", (H,), "norm"
+    yield "vit.layernorm.bias", (H,), "bias"
+    yield "classifier.weight", (c.classes, H), "w"
+
+
+def vit_images(c: ViTConfig, n: int) -> np.ndarray:
+    """n images fp32 [n][H][C][W] ~ N(0,1), seed 17 (the tensor layout ViTProcessor::img2Tensor builds)."""
+    return np.random.default_rng(17).standard_normal((n, c.img, 3, c.img), dtype=np.float32)

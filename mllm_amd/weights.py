@@ -53,3 +53,21 @@ def tensor_digests(path: str) -> dict:
     out = {n: hashlib.sha256(f.raw(n).tobytes()).hexdigest()[:16] for n in f.names()}
     f.close()
     return out
+
+
+def causal_lm_file(cfg: synth.CausalLMConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> str:
+    os.makedirs(cache_dir, exist_ok=True)
+    key = (f"{cfg.family}-h{cfg.hidden}-i{cfg.inter}-l{cfg.layers}-a{cfg.heads}k{cfg.kv_heads}-v{cfg.vocab}-t{int(cfg.tie_embedding)}"
+           f"-{'f32' if cfg.target == mf.F32 else 'q4k'}.mllm")
+    path = os.path.join(cache_dir, key)
+    if not os.path.exists(path):
+        build_q4k_file(path, synth.causal_lm_tensors(cfg), target=cfg.target)
+    return path
+
+
+def vit_file(cfg: synth.ViTConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> str:
+    os.makedirs(cache_dir, exist_ok=True)
+    path = os.path.join(cache_dir, f"vit-h{cfg.hidden}-f{cfg.ffn}-b{cfg.blocks}-p{cfg.patch}-i{cfg.img}-c{cfg.classes}-q4k.mllm")
+    if not os.path.exists(path):
+        build_q4k_file(path, synth.vit_tensors(cfg))
+    return path

@@ -223,7 +223,75 @@ def e2e_full(out_dir="/tmp/full/out", run_log="/tmp/full/run.log"):
     print("qwen2vl_2b_ref.npz", toks[:8], timing)
 
 
+def _ref_weights(specs, target):
+    """fp32 .mllm of the synthetic tensors -> the reference's own `quantize` (or the fp32 file itself for an F32 target)."""
+    td = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP"))
+    src, dst = os.path.join(td, "f32.mllm"), os.path.join(td, "q.mllm")
+    synth.write_fp32_mllm(src, specs)
+    if target == mf.F32:
+        return td, src
+    subprocess.run([os.path.join(REF, "quantize"), src, dst, "Q4_K"], check=True, capture_output=True)
+    os.remove(src)
+    return td, dst
+
+
+def run_ref_llm(c, n_prompt, steps, threads=4):
+    td, path = _ref_weights(synth.causal_lm_tensors(c), c.target)
+    ids = synth.causal_lm_ids(c, n_prompt)
+    ids.tofile(os.path.join(td, "ids.i32"))
+    cfg = f"{c.hidden},{c.inter},{c.layers},{c.heads},{c.kv_heads},{c.vocab},{c.cache_limit},{int(c.tie_embedding)}"
+    out = subprocess.run([os.path.join(REF, "ref_llm"), "--family", c.family, "--model", path, "--ids", os.path.join(td, "ids.i32"), "--steps", str(steps),
+                          "--threads", str(threads), "--out", td, "--cfg", cfg], check=True, capture_output=True, text=True)
+    toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
+    logits = np.stack([np.fromfile(os.path.join(td, f"logits_{s}.f32"), dtype=np.float32) for s in range(steps)])
+    os.remove(path)
+    return ids, toks, logits, out.stdout.strip().splitlines()[0]
+
+
+def run_ref_vit(c, n_img, threads=4):
+    td, path = _ref_weights(synth.vit_tensors(c), mf.Q4_K)
+    synth.vit_images(c, n_img).tofile(os.path.join(td, "img.f32"))
+    cfg = f"{c.hidden},{c.heads},{c.ffn},{c.blocks},{c.patch},{c.img},{c.classes}"
+    out = subprocess.run([os.path.join(REF, "ref_vit"), "--model", path, "--img", os.path.join(td, "img.f32"), "--n", str(n_img), "--threads", str(threads),
+                          "--out", td, "--cfg", cfg], check=True, capture_output=True, text=True)
+    os.remove(path)
+    return np.fromfile(os.path.join(td, "vit_logits.f32"), dtype=np.float32).reshape(n_img, c.classes), out.stdout.strip().splitlines()[0]
+
+
+def _sampled(logits):
+    idx = np.stack([np.argsort(-l, kind="stable")[:64] for l in logits]).astype(np.int32)
+    return idx, np.take_along_axis(logits, idx, axis=1), np.ascontiguousarray(logits[:, ::97])
+
+
+def configs_tiny():
+    """BASELINE configs 1-3 at toy shapes with the real head geometry (head_dim 64): every logit of the reference's run."""
+    q_ids, q_tok, q_log, _ = run_ref_llm(synth.qwen15_tiny(), 20, 8)
+    t_ids, t_tok, t_log, _ = run_ref_llm(synth.tinyllama_tiny(), 20, 8)
+    k_ids, k_tok, k_log, _ = run_ref_llm(synth.tinyllama_tiny(mf.Q4_K), 20, 8)
+    v_log, _ = run_ref_vit(synth.vit_tiny(), 3)
+    np.savez_compressed(os.path.join(GOLD, "configs_tiny.npz"), qwen_ids=q_ids, qwen_tokens=q_tok, qwen_logits=q_log, tl_ids=t_ids, tl_tokens=t_tok,
+                        tl_logits=t_log, tlq_ids=k_ids, tlq_tokens=k_tok, tlq_logits=k_log, vit_logits=v_log)
+    print("configs_tiny.npz", q_tok.tolist(), t_tok.tolist(), k_tok.tolist(), v_log[:, :3])
+
+
+def configs_full():
+    """Qwen1.5-0.5B (Q4_K, 32-token prompt + 16 steps) and ViT-B/16 (Q4_K, 2 images) at their real sizes: greedy ids, top-64 and
+    every 97th logit of each step for the LM; all 1000 class logits for the ViT."""
+    c = synth.qwen15_05b()
+    ids, tok, log, timing = run_ref_llm(c, 32, 16, threads=8)
+    ti, tv, st = _sampled(log)
+    v_log, v_timing = run_ref_vit(synth.vit_b16(), 2, threads=8)
+    np.savez_compressed(os.path.join(GOLD, "configs_full.npz"), qwen_ids=ids, qwen_tokens=tok, qwen_top_idx=ti, qwen_top_val=tv, qwen_strided=st,
+                        vit_logits=v_log, qwen_timing=np.frombuffer(timing.encode(), dtype=np.uint8), vit_timing=np.frombuffer(v_timing.encode(), dtype=np.uint8))
+    print("configs_full.npz", tok.tolist(), timing, v_timing)
+
+
 if __name__ == "__main__":
+    if "--configs" in sys.argv:
+        configs_tiny()
+        if "--full" in sys.argv:
+            configs_full()
+        sys.exit(0)
     os.makedirs(GOLD, exist_ok=True)
     ops_golden()
     e2e_tiny()

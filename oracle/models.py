@@ -145,3 +145,72 @@ class LLM:
     def decode(self, token):
         pos = np.full((3, 1), self.last_pos + 1.0, dtype=np.float32)
         return self.forward([token], pos)
+
+
+class CausalLM:
+    """QWenForCausalLM::Forward (models/qwen/modeling_qwen.hpp:151-164) and TinyLLaMAModel::Forward (models/tinyllama/
+    modeling_tinyllama.hpp:67-74) composed from oracle ops: MultiHeadAttention with HF rotary at positions [T, T+S)
+    (models/transformer/modeling_transformer.hpp:136-218, CPURoPE.cpp:100-128,510-513), fp16 KV slabs, FlashAttention2, SiLU MLP."""
+
+    def __init__(self, w: Weights, cfg):
+        self.w, self.cfg = w, cfg
+        self.k = [np.zeros((0, cfg.kv_heads * cfg.head_dim), dtype=np.uint16) for _ in range(cfg.layers)]
+        self.v = [np.zeros((0, cfg.kv_heads * cfg.head_dim), dtype=np.uint16) for _ in range(cfg.layers)]
+        self.T = 0
+
+    def forward(self, ids):
+        w, c = self.w, self.cfg
+        H, D, heads, kvh = c.hidden, c.head_dim, c.heads, c.kv_heads
+        ids = np.asarray(ids, dtype=np.int32).ravel()
+        S = ids.size
+        emb = "model.embed_tokens.weight"
+        x = orc.embedding(ids, w.f.raw(emb), w.f.dtype(emb), H)
+        s, co = orc.rope_table_hf(c.rope_theta, D, self.T + S)
+        s, co = np.ascontiguousarray(s[self.T:]), np.ascontiguousarray(co[self.T:])
+        for i in range(c.layers):
+            p = f"model.layers.{i}."
+            y = orc.rmsnorm(x, w.v(p + "input_layernorm.weight"), c.rms_eps)
+            q = w.lin(y, p + "self_attn.q_proj", heads * D, bias=c.qkv_bias)
+            k = w.lin(y, p + "self_attn.k_proj", kvh * D, bias=c.qkv_bias)
+            v = w.lin(y, p + "self_attn.v_proj", kvh * D, bias=c.qkv_bias, out_f16=True)
+            q = orc.rope_apply(q, S, heads, D, s, co)
+            k16 = orc.rope_apply(k, S, kvh, D, s, co, out_f16=True)
+            self.k[i] = np.concatenate([self.k[i], k16.reshape(S, kvh * D)])
+            self.v[i] = np.concatenate([self.v[i], v.reshape(S, kvh * D)])
+            o = orc.attention(q, self.k[i], self.v[i], S, self.k[i].shape[0], heads, kvh, D, True)
+            r = w.lin(o, p + "self_attn.o_proj", H, bias=False) + x
+            y = orc.rmsnorm(r, w.v(p + "post_attention_layernorm.weight"), c.rms_eps)
+            g = w.lin(y, p + "mlp.gate_proj", c.inter, bias=False)
+            u = w.lin(y, p + "mlp.up_proj", c.inter, bias=False)
+            x = w.lin(orc.silu(g) * u, p + "mlp.down_proj", H, bias=False) + r
+        self.T += S
+        x = orc.rmsnorm(x[-1:], w.v("model.norm.weight"), c.rms_eps)
+        if c.tie_embedding:
+            return orc.linear(x, w.f.raw(emb), w.f.dtype(emb), c.vocab)[0]
+        return w.lin(x, "lm_head", c.vocab, bias=False)[0]
+
+
+def vit_forward(w: Weights, cfg, img_hcw):
+    """ViTModel::Forward (models/vit/modeling_vit.hpp:21-104) on one image [H][C][W]: Conv2D patch embedding (+bias), cls token,
+    position embeddings, pre-LN blocks with non-causal FlashAttention2 on fp32 K/V and a GELU MLP, final LayerNorm of the cls row, head."""
+    H, heads, D, p = cfg.hidden, cfg.heads, cfg.head_dim, cfg.patch
+    e = "vit.embeddings."
+    pe = orc.conv2d_patch(img_hcw, cfg.img, 3, cfg.img, w.v(e + "patch_embeddings.projection.weight"), H, p, w.v(e + "patch_embeddings.projection.bias"))
+    g = cfg.img // p
+    tok = np.ascontiguousarray(pe.reshape(g, H, g).transpose(0, 2, 1).reshape(g * g, H))     # [oh][OC][ow] -> rows (oh, ow)
+    x = np.concatenate([w.v(e + "cls_token").reshape(1, H), tok])
+    x = w.v(e + "position_embeddings").reshape(-1, H) + x
+    N = x.shape[0]
+    for i in range(cfg.blocks):
+        b = f"vit.encoder.layer.{i}."
+        y = orc.layernorm(x, w.v(b + "layernorm_before.weight"), w.v(b + "layernorm_before.bias"), 1e-5)
+        q = w.lin(y, b + "attention.attention.query", H)
+        k = w.lin(y, b + "attention.attention.key", H)
+        v = w.lin(y, b + "attention.attention.value", H)
+        o = orc.attention(q, k, v, N, N, heads, heads, D, False)
+        r = w.lin(o, b + "attention.output.dense", H) + x
+        y = orc.layernorm(r, w.v(b + "layernorm_after.weight"), w.v(b + "layernorm_after.bias"), 1e-5)
+        a = orc.gelu(w.lin(y, b + "intermediate.dense", cfg.ffn))
+        x = w.lin(a, b + "output.dense", H) + r
+    y = orc.layernorm(x[:1], w.v("vit.layernorm.weight"), w.v("vit.layernorm.bias"), 1e-6)
+    return w.lin(y, "classifier", cfg.classes, bias=False)[0]
