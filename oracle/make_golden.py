@@ -280,7 +280,7 @@ def configs_full():
     c = synth.qwen15_05b()
     ids, tok, log, timing = run_ref_llm(c, 32, 16, threads=8)
     ti, tv, st = _sampled(log)
-    v_log, v_timing = run_ref_vit(synth.vit_b16(), 2, threads=8)
+    v_log, v_timing = run_ref_vit(synth.vit_b16(), 2, threads=4)      # FA2 asserts heads % threads == 0 (FlashAttention2.hpp:128)
     np.savez_compressed(os.path.join(GOLD, "configs_full.npz"), qwen_ids=ids, qwen_tokens=tok, qwen_top_idx=ti, qwen_top_val=tv, qwen_strided=st,
                         vit_logits=v_log, qwen_timing=np.frombuffer(timing.encode(), dtype=np.uint8), vit_timing=np.frombuffer(v_timing.encode(), dtype=np.uint8))
     print("configs_full.npz", tok.tolist(), timing, v_timing)

@@ -67,3 +67,49 @@ def test_gpu_vit_matches_reference(gold):
     m = graphs.ViT(cfg, weights.vit_file(cfg, CACHE))
     out = m.forward_batch(synth.vit_images(cfg, 3)).cpu().numpy()
     assert np.array_equal(out, gold["vit_logits"]), float(np.abs(out - gold["vit_logits"]).max())
+
+
+# ---- the real sizes: Qwen1.5-0.5B (Q4_K, tied Q4_0 head, 151,936-way logits) and ViT-B/16 ---------------------------------------------------
+
+@pytest.fixture(scope="module")
+def gold_full():
+    return np.load(os.path.join(GOLD, "configs_full.npz"))
+
+
+def _sample_err(g, s, lg):
+    return float(max(np.abs(lg[g["qwen_top_idx"][s]] - g["qwen_top_val"][s]).max(), np.abs(lg[::97] - g["qwen_strided"][s]).max()))
+
+
+def test_oracle_full_size_qwen15_and_vitb_match_reference(gold_full):
+    from oracle import models as om
+    g = gold_full
+    cfg = synth.qwen15_05b()
+    m = om.CausalLM(om.Weights(weights.causal_lm_file(cfg, CACHE)), cfg)
+    cur = g["qwen_ids"]
+    for s in range(3):
+        lg = m.forward(cur)
+        assert _sample_err(g, s, lg) == 0.0 and int(np.argmax(lg)) == int(g["qwen_tokens"][s])
+        cur = [int(np.argmax(lg))]
+    vc = synth.vit_b16()
+    out = om.vit_forward(om.Weights(weights.vit_file(vc, CACHE)), vc, synth.vit_images(vc, 2)[0])
+    assert np.array_equal(out, g["vit_logits"][0]), float(np.abs(out - g["vit_logits"][0]).max())
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_qwen15_matches_reference(gold_full):
+    from mllm_amd import graphs
+    g = gold_full
+    cfg = synth.qwen15_05b()
+    m = graphs.CausalLM(cfg, weights.causal_lm_file(cfg, CACHE))
+    toks, logits = m.greedy(g["qwen_ids"], len(g["qwen_tokens"]))
+    assert toks == g["qwen_tokens"].tolist()
+    assert max(_sample_err(g, s, lg) for s, lg in enumerate(logits)) == 0.0
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_vitb_matches_reference(gold_full):
+    from mllm_amd import graphs
+    cfg = synth.vit_b16()
+    m = graphs.ViT(cfg, weights.vit_file(cfg, CACHE))
+    out = m.forward_batch(synth.vit_images(cfg, 2)).cpu().numpy()
+    assert np.array_equal(out, gold_full["vit_logits"]), float(np.abs(out - gold_full["vit_logits"]).max())
