@@ -81,8 +81,10 @@ class CausalLM:
     def clear_kvcache(self):
         self.T = 0
 
+    PREFIX = ""
+
     def _embed(self, ids):
-        c, w, name = self.cfg, self.w, "model.embed_tokens.weight"
+        c, w, name = self.cfg, self.w, self.PREFIX + "model.embed_tokens.weight"
         if w.dtype(name) == mf.Q4_0:
             qs, d = w.q40_planes(name, c.vocab * c.hidden // 32)
             idf = torch.from_numpy(np.asarray(ids, dtype=np.float32)).cuda()
@@ -96,8 +98,8 @@ class CausalLM:
     def _head(self, x):
         c, w = self.cfg, self.w
         if not c.tie_embedding:
-            return linear(w, x, "lm_head", c.vocab, bias=False)
-        name = "model.embed_tokens.weight"      # Tensor::mm(x, embed^T) (modeling_qwen.hpp:158-159) = the same vec_dot per row
+            return linear(w, x, self.PREFIX + "lm_head", c.vocab, bias=False)
+        name = self.PREFIX + "model.embed_tokens.weight"      # Tensor::mm(x, embed^T) (modeling_qwen.hpp:158-159) = the same vec_dot per row
         if w.dtype(name) == mf.Q4_0:
             qs, d = w.q40_planes(name, c.vocab * c.hidden // 32)
             xqs, xd = ops.quantize_q80(x)
@@ -108,15 +110,16 @@ class CausalLM:
         return ops.linear_f32(w.f32(name), x)
 
     def forward(self, ids) -> np.ndarray:
-        c, w = self.cfg, self.w
-        ids = [int(v) for v in np.asarray(ids).ravel()]
-        S, T, D, heads, kvh = len(ids), self.T, c.head_dim, c.heads, c.kv_heads
+        return self._body(self._embed([int(v) for v in np.asarray(ids).ravel()]))
+
+    def _body(self, x) -> np.ndarray:
+        c, w, P = self.cfg, self.w, self.PREFIX
+        S, T, D, heads, kvh = x.shape[0], self.T, c.head_dim, c.heads, c.kv_heads
         if T + S > c.cache_limit:
             raise L.MllmHipError("KV cache overflow")       # CPUKVCache.cpp:121-126 exits the process; the library reports an error
-        x = self._embed(ids)
         sin, cos = self.sin[T:T + S], self.cos[T:T + S]
         for i in range(c.layers):
-            p = f"model.layers.{i}."
+            p = P + f"model.layers.{i}."
             y = ops.rmsnorm(x, w.f32(p + "input_layernorm.weight"), c.rms_eps)
             q = linear(w, y, p + "self_attn.q_proj", heads * D, bias=c.qkv_bias)
             k = linear(w, y, p + "self_attn.k_proj", kvh * D, bias=c.qkv_bias)
@@ -131,7 +134,7 @@ class CausalLM:
             u = linear(w, y, p + "mlp.up_proj", c.inter, bias=False)
             x = linear(w, ops.mul(ops.silu(g), u), p + "mlp.down_proj", c.hidden, bias=False, residual=r)
         self.T = T + S
-        x = ops.rmsnorm(x[S - 1:S].contiguous(), w.f32("model.norm.weight"), c.rms_eps)
+        x = ops.rmsnorm(x[S - 1:S].contiguous(), w.f32(P + "model.norm.weight"), c.rms_eps)
         return self._head(x)[0].cpu().numpy()
 
     def greedy(self, ids, steps):
@@ -181,3 +184,50 @@ class ViT:
 
     def forward_batch(self, imgs) -> torch.Tensor:
         return torch.stack([self.forward(im) for im in imgs])
+
+
+class LLaVA(CausalLM):
+    """LLaVAModel::Forward (models/llava/modeling_llava.hpp:101-137): text embedding; CLIP tower (LLaVAVisionModel, :62-98: Conv2D patch
+    embedding without bias, class_embedding row, position Embedding, pre_layrnorm, ViTBlocks with QuickGELU, cls row clipped) ->
+    multi_modal_projector (Linear, GELU, Linear); the <image> row replaced by the projected rows (index_put with accumulate,
+    CPUIndexPutFunc.hpp:84-110); LLaMA body (LLaMABodyModel, :13-37)."""
+
+    PREFIX = "language_model."
+
+    def __init__(self, cfg, path: str):
+        super().__init__(cfg.body(), path)
+        self.lcfg = cfg
+
+    def vision(self, img_hcw) -> torch.Tensor:
+        c, w = self.lcfg, self.w
+        V, heads, D = c.v_hidden, c.v_heads, c.v_head_dim
+        base = "vision_tower.vision_model."
+        e = base + "embeddings."
+        g = c.img // c.patch
+        pe = ops.conv2d_patch(img_hcw, c.img, 3, c.img, w.f32(e + "patch_embedding.weight"), V, c.patch)
+        tok = pe.permute(0, 2, 1).reshape(g * g, V)
+        x = torch.cat([w.f32(e + "class_embedding").view(1, V), tok]).contiguous()
+        x = ops.add(w.f32(e + "position_embedding.weight").view(-1, V), x)       # Embedding over Tensor::range(0, N): rows 0..N-1 in order
+        x = ops.layernorm(x, w.f32(base + "pre_layrnorm.weight"), w.f32(base + "pre_layrnorm.bias"), 1e-6)
+        N = x.shape[0]
+        for i in range(c.v_blocks):
+            b = base + f"encoder.layers.{i}."
+            y = ops.layernorm(x, w.f32(b + "layer_norm1.weight"), w.f32(b + "layer_norm1.bias"), 1e-5)
+            q, k, v = (linear(w, y, b + f"self_attn.{nm}", V) for nm in ("q_proj", "k_proj", "v_proj"))
+            o = ops.flash_attention2(q, k, v, N, N, heads, heads, D, False)
+            r = linear(w, o, b + "self_attn.out_proj", V, residual=x)
+            y = ops.layernorm(r, w.f32(b + "layer_norm2.weight"), w.f32(b + "layer_norm2.bias"), 1e-5)
+            x = linear(w, ops.quickgelu(linear(w, y, b + "mlp.fc1", c.v_ffn)), b + "mlp.fc2", V, residual=r)
+        y = ops.gelu(linear(w, x[1:].contiguous(), "multi_modal_projector.linear_1", c.v_ffn))
+        return linear(w, y, "multi_modal_projector.linear_2", c.v_ffn)
+
+    def forward(self, ids, img=None, vis=None) -> np.ndarray:
+        """`vis`: visual rows already computed (e.g. gathered from the ranks of the image shard); otherwise `img` runs the tower here."""
+        ids = [int(v) for v in np.asarray(ids).ravel()]
+        x = self._embed(ids)
+        if img is not None or vis is not None:
+            if vis is None:
+                vis = self.vision(img)
+            at = ids.index(self.lcfg.image_token_id)
+            x = torch.cat([x[:at], vis, x[at + 1:]]).contiguous()
+        return self._body(x)

@@ -304,3 +304,98 @@ def vit_tensors(c: ViTConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
 def vit_images(c: ViTConfig, n: int) -> np.ndarray:
     """n images fp32 [n][H][C][W] ~ N(0,1), seed 17 (the tensor layout ViTProcessor::img2Tensor builds)."""
     return np.random.default_rng(17).standard_normal((n, c.img, 3, c.img), dtype=np.float32)
+
+
+@dataclass
+class LLaVAConfig:
+    """LLaVAConfig(token_limit, "7B", 32064) (configuration_llava.hpp:14-40): LLaMA-7B body + CLIP-ViT-L/14-336 tower, 23 of its blocks."""
+    hidden: int = 4096
+    heads: int = 32
+    inter: int = 11008
+    layers: int = 32
+    vocab: int = 32064
+    cache_limit: int = 700
+    rope_theta: float = 10000.0
+    rms_eps: float = 1e-6
+    v_hidden: int = 1024
+    v_heads: int = 16
+    v_ffn: int = 4096            # also the projector width; linear_2 is v_ffn x v_ffn, so it must equal `hidden`
+    v_blocks: int = 23
+    patch: int = 14
+    img: int = 336
+    image_token_id: int = 32000  # Tensor::where(32000, SEQUENCE) (modeling_llava.hpp:130)
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def v_head_dim(self) -> int:
+        return self.v_hidden // self.v_heads
+
+    @property
+    def v_tokens(self) -> int:
+        return (self.img // self.patch) ** 2          # rows kept after the cls row is clipped
+
+    # the text body seen as a CausalLMConfig (LLaMABodyModel: kv heads == heads, no qkv bias, Linear lm_head)
+    def body(self) -> CausalLMConfig:
+        return CausalLMConfig(family="tinyllama", hidden=self.hidden, inter=self.inter, layers=self.layers, heads=self.heads, kv_heads=self.heads,
+                              vocab=self.vocab, rms_eps=self.rms_eps, rope_theta=self.rope_theta, cache_limit=self.cache_limit, tie_embedding=False)
+
+
+def llava_7b() -> LLaVAConfig:
+    return LLaVAConfig()
+
+
+def llava_tiny() -> LLaVAConfig:
+    return LLaVAConfig(hidden=256, heads=2, inter=512, layers=2, cache_limit=96, v_hidden=256, v_heads=4, v_ffn=256, v_blocks=2, img=56)
+
+
+def llava_tensors(c: LLaVAConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
+    """language_model.* (configuration_llava.hpp:25-29) + vision_tower.vision_model.* with the "clip" names (configuration_vit.hpp:46-64)
+    + multi_modal_projector.* (modeling_llava.hpp:81-83)."""
+    H, I, D = c.hidden, c.inter, c.head_dim
+    yield "language_model.model.embed_tokens.weight", (c.vocab, H), "w"
+    for i in range(c.layers):
+        p = f"language_model.model.layers.{i}."
+        yield p + "input_layernorm.weight", (H,), "norm"
+        for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            yield p + f"self_attn.{nm}.weight", (H, H), "w"
+        yield p + "post_attention_layernorm.weight", (H,), "norm"
+        yield p + "mlp.gate_proj.weight", (I, H), "w"
+        yield p + "mlp.up_proj.weight", (I, H), "w"
+        yield p + "mlp.down_proj.weight", (H, I), "w"
+    yield "language_model.model.norm.weight", (H,), "norm"
+    yield "language_model.lm_head.weight", (c.vocab, H), "w"
+    V, F = c.v_hidden, c.v_ffn
+    e = "vision_tower.vision_model.embeddings."
+    yield e + "patch_embedding.weight", (V, 3, c.patch, c.patch), "w"
+    yield e + "class_embedding", (V,), "w"
+    yield e + "position_embedding.weight", (c.v_tokens + 1, V), "w"
+    yield "vision_tower.vision_model.pre_layrnorm.weight", (V,), "norm"
+    yield "vision_tower.vision_model.pre_layrnorm.bias", (V,), "bias"
+    for i in range(c.v_blocks):
+        p = f"vision_tower.vision_model.encoder.layers.{i}."
+        yield p + "layer_norm1.weight", (V,), "norm"
+        yield p + "layer_norm1.bias", (V,), "bias"
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            yield p + f"self_attn.{nm}.weight", (V, V), "w"
+            yield p + f"self_attn.{nm}.bias", (V,), "bias"
+        yield p + "layer_norm2.weight", (V,), "norm"
+        yield p + "layer_norm2.bias", (V,), "bias"
+        yield p + "mlp.fc1.weight", (F, V), "w"
+        yield p + "mlp.fc1.bias", (F,), "bias"
+        yield p + "mlp.fc2.weight", (V, F), "w"
+        yield p + "mlp.fc2.bias", (V,), "bias"
+    yield "multi_modal_projector.linear_1.weight", (F, V), "w"
+    yield "multi_modal_projector.linear_1.bias", (F,), "bias"
+    yield "multi_modal_projector.linear_2.weight", (F, F), "w"
+    yield "multi_modal_projector.linear_2.bias", (F,), "bias"
+
+
+def llava_inputs(c: LLaVAConfig, n_text: int = 10):
+    """ids = 3 text ids + [<image> 32000] + n_text text ids (seed 19); image fp32 [H][C][W] ~ N(0,1) seed 23."""
+    text = np.random.default_rng(19).integers(0, c.image_token_id, size=3 + n_text)
+    ids = np.concatenate([text[:3], [c.image_token_id], text[3:]]).astype(np.int32)
+    img = np.random.default_rng(23).standard_normal((c.img, 3, c.img), dtype=np.float32)
+    return ids, img

@@ -71,3 +71,11 @@ def vit_file(cfg: synth.ViTConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> st
     if not os.path.exists(path):
         build_q4k_file(path, synth.vit_tensors(cfg))
     return path
+
+
+def llava_file(cfg: synth.LLaVAConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> str:
+    os.makedirs(cache_dir, exist_ok=True)
+    path = os.path.join(cache_dir, f"llava-h{cfg.hidden}-i{cfg.inter}-l{cfg.layers}-v{cfg.vocab}-vh{cfg.v_hidden}-vb{cfg.v_blocks}-img{cfg.img}-q4k.mllm")
+    if not os.path.exists(path):
+        build_q4k_file(path, synth.llava_tensors(cfg))
+    return path

@@ -258,6 +258,29 @@ def run_ref_vit(c, n_img, threads=4):
     return np.fromfile(os.path.join(td, "vit_logits.f32"), dtype=np.float32).reshape(n_img, c.classes), out.stdout.strip().splitlines()[0]
 
 
+def run_ref_llava(c, steps, threads=4):
+    td, path = _ref_weights(synth.llava_tensors(c), mf.Q4_K)
+    ids, img = synth.llava_inputs(c)
+    ids.tofile(os.path.join(td, "ids.i32"))
+    img.tofile(os.path.join(td, "img.f32"))
+    cfg = f"{c.hidden},{c.heads},{c.inter},{c.layers},{c.vocab},{c.cache_limit},{c.v_hidden},{c.v_heads},{c.v_ffn},{c.v_blocks},{c.patch},{c.img}"
+    subprocess.run([os.path.join(REF, "ref_llava"), "--model", path, "--ids", os.path.join(td, "ids.i32"), "--img", os.path.join(td, "img.f32"), "--steps",
+                    str(steps), "--threads", str(threads), "--out", td, "--cfg", cfg], check=True, capture_output=True, text=True)
+    toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
+    logits = np.stack([np.fromfile(os.path.join(td, f"logits_{s}.f32"), dtype=np.float32) for s in range(steps)])
+    os.remove(path)
+    return ids, toks, logits
+
+
+def llava_tiny():
+    """BASELINE config 5 (demo_llava) at a toy shape with the real head geometry (CLIP head_dim 64, LLaMA head_dim 128, vocab 32064).
+    Not runnable at the 2025-10-31 reference snapshot: LLaVAModel segfaults inside Tensor::range (see oracle/ref_drivers/ref_llava.cpp)."""
+    ids, tok, log = run_ref_llava(synth.llava_tiny(), 6)
+    ti, tv, st = _sampled(log)
+    np.savez_compressed(os.path.join(GOLD, "llava_tiny.npz"), ids=ids, tokens=tok, top_idx=ti, top_val=tv, strided=st, row0=log[0])
+    print("llava_tiny.npz", tok.tolist())
+
+
 def _sampled(logits):
     idx = np.stack([np.argsort(-l, kind="stable")[:64] for l in logits]).astype(np.int32)
     return idx, np.take_along_axis(logits, idx, axis=1), np.ascontiguousarray(logits[:, ::97])
@@ -287,6 +310,9 @@ def configs_full():
 
 
 if __name__ == "__main__":
+    if "--llava" in sys.argv:
+        llava_tiny()
+        sys.exit(0)
     if "--configs" in sys.argv:
         configs_tiny()
         if "--full" in sys.argv:

@@ -164,11 +164,19 @@ class CausalLM:
         ids = np.asarray(ids, dtype=np.int32).ravel()
         S = ids.size
         emb = "model.embed_tokens.weight"
-        x = orc.embedding(ids, w.f.raw(emb), w.f.dtype(emb), H)
+        return self.body_forward(orc.embedding(ids, w.f.raw(emb), w.f.dtype(emb), H))
+
+    PREFIX = ""
+
+    def body_forward(self, x):
+        w, c, P = self.w, self.cfg, self.PREFIX
+        H, D, heads, kvh = c.hidden, c.head_dim, c.heads, c.kv_heads
+        S = x.shape[0]
+        emb = P + "model.embed_tokens.weight"
         s, co = orc.rope_table_hf(c.rope_theta, D, self.T + S)
         s, co = np.ascontiguousarray(s[self.T:]), np.ascontiguousarray(co[self.T:])
         for i in range(c.layers):
-            p = f"model.layers.{i}."
+            p = P + f"model.layers.{i}."
             y = orc.rmsnorm(x, w.v(p + "input_layernorm.weight"), c.rms_eps)
             q = w.lin(y, p + "self_attn.q_proj", heads * D, bias=c.qkv_bias)
             k = w.lin(y, p + "self_attn.k_proj", kvh * D, bias=c.qkv_bias)
@@ -184,10 +192,10 @@ class CausalLM:
             u = w.lin(y, p + "mlp.up_proj", c.inter, bias=False)
             x = w.lin(orc.silu(g) * u, p + "mlp.down_proj", H, bias=False) + r
         self.T += S
-        x = orc.rmsnorm(x[-1:], w.v("model.norm.weight"), c.rms_eps)
+        x = orc.rmsnorm(x[-1:], w.v(P + "model.norm.weight"), c.rms_eps)
         if c.tie_embedding:
             return orc.linear(x, w.f.raw(emb), w.f.dtype(emb), c.vocab)[0]
-        return w.lin(x, "lm_head", c.vocab, bias=False)[0]
+        return w.lin(x, P + "lm_head", c.vocab, bias=False)[0]
 
 
 def vit_forward(w: Weights, cfg, img_hcw):
@@ -214,3 +222,50 @@ def vit_forward(w: Weights, cfg, img_hcw):
         x = w.lin(a, b + "output.dense", H) + r
     y = orc.layernorm(x[:1], w.v("vit.layernorm.weight"), w.v("vit.layernorm.bias"), 1e-6)
     return w.lin(y, "classifier", cfg.classes, bias=False)[0]
+
+
+def llava_vision(w: Weights, cfg, img_hcw):
+    """LLaVAVisionModel::Forward (models/llava/modeling_llava.hpp:39-98): CLIP embeddings (Conv2D without bias, class_embedding row, position
+    Embedding over range ids), pre_layrnorm, ViTBlocks with QuickGELU, the cls row clipped away, linear_1 -> GELU -> linear_2."""
+    V, heads, D, p = cfg.v_hidden, cfg.v_heads, cfg.v_head_dim, cfg.patch
+    base = "vision_tower.vision_model."
+    e = base + "embeddings."
+    g = cfg.img // p
+    pe = orc.conv2d_patch(img_hcw, cfg.img, 3, cfg.img, w.v(e + "patch_embedding.weight"), V, p)
+    tok = np.ascontiguousarray(pe.reshape(g, V, g).transpose(0, 2, 1).reshape(g * g, V))
+    x = np.concatenate([w.v(e + "class_embedding").reshape(1, V), tok])
+    x = w.v(e + "position_embedding.weight").reshape(-1, V) + x
+    x = orc.layernorm(x, w.v(base + "pre_layrnorm.weight"), w.v(base + "pre_layrnorm.bias"), 1e-6)
+    N = x.shape[0]
+    for i in range(cfg.v_blocks):
+        b = base + f"encoder.layers.{i}."
+        y = orc.layernorm(x, w.v(b + "layer_norm1.weight"), w.v(b + "layer_norm1.bias"), 1e-5)
+        q, k, v = (w.lin(y, b + f"self_attn.{nm}", V) for nm in ("q_proj", "k_proj", "v_proj"))
+        o = orc.attention(q, k, v, N, N, heads, heads, D, False)
+        r = w.lin(o, b + "self_attn.out_proj", V) + x
+        y = orc.layernorm(r, w.v(b + "layer_norm2.weight"), w.v(b + "layer_norm2.bias"), 1e-5)
+        x = w.lin(orc.quickgelu(w.lin(y, b + "mlp.fc1", cfg.v_ffn)), b + "mlp.fc2", V) + r
+    y = orc.gelu(w.lin(np.ascontiguousarray(x[1:]), "multi_modal_projector.linear_1", cfg.v_ffn))
+    return w.lin(y, "multi_modal_projector.linear_2", cfg.v_ffn)
+
+
+class LLaVA(CausalLM):
+    """LLaVAModel::Forward (modeling_llava.hpp:126-136): text embedding, the <image> row expanded into the projected visual rows
+    (index_put with accumulate, CPUIndexPutFunc.hpp:84-110), LLaMA body, last row."""
+
+    def __init__(self, w: Weights, cfg):
+        super().__init__(w, cfg.body())
+        self.lcfg = cfg
+
+    PREFIX = "language_model."
+
+    def forward(self, ids, img=None):
+        ids = np.asarray(ids, dtype=np.int32).ravel()
+        w, c = self.w, self.lcfg
+        emb = self.PREFIX + "model.embed_tokens.weight"
+        x = orc.embedding(ids, w.f.raw(emb), w.f.dtype(emb), c.hidden)
+        if img is not None:
+            vis = llava_vision(w, c, img)
+            at = int(np.nonzero(ids == c.image_token_id)[0][0])
+            x = np.concatenate([x[:at], vis, x[at + 1:]])
+        return self.body_forward(x)

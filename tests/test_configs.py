@@ -113,3 +113,26 @@ def test_gpu_full_size_vitb_matches_reference(gold_full):
     m = graphs.ViT(cfg, weights.vit_file(cfg, CACHE))
     out = m.forward_batch(synth.vit_images(cfg, 2)).cpu().numpy()
     assert np.array_equal(out, gold_full["vit_logits"]), float(np.abs(out - gold_full["vit_logits"]).max())
+
+
+# ---- config 5 (demo_llava): the reference's LLaVAModel segfaults at this snapshot (Tensor::range, see oracle/ref_drivers/ref_llava.cpp), so
+# ---- there is no whole-graph golden; the GPU graph is held to the oracle's composition, whose every op is pinned by the goldens above ----------
+
+@pytest.mark.gpu
+def test_gpu_llava_tiny_matches_oracle_composition():
+    from mllm_amd import graphs
+    from oracle import models as om
+    cfg = synth.llava_tiny()
+    path = weights.llava_file(cfg, CACHE)
+    ids, img = synth.llava_inputs(cfg)
+    ref = om.LLaVA(om.Weights(path), cfg)
+    m = graphs.LLaVA(cfg, path)
+    want, got = ref.forward(ids, img), m.forward(ids, img)
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+    for _ in range(4):
+        tok = int(np.argmax(want))
+        want, got = ref.forward([tok]), m.forward([tok])
+        assert np.array_equal(got, want), float(np.abs(got - want).max())
+    # the tower's rows handed in (the form the image shard uses) give the same logits as running it in place
+    m.clear_kvcache()
+    assert np.array_equal(m.forward(ids, vis=m.vision(img)), om.LLaVA(om.Weights(path), cfg).forward(ids, img))
