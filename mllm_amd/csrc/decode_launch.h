@@ -16,7 +16,8 @@ struct DecodeState {
 struct DecodeLayer {
     const float *in_norm, *post_norm;
     const uint8_t *Wqkv; const float *bqkv; int qkv_N;
-    const uint8_t *Wo, *Wgu, *Wdown;
+    const uint8_t *Wo, *Wgu, *Wdown;          // all four in decode order (decode_order_q4k)
+    const uint8_t *Wgu_raw;                   // gate|up rows as stored on disk (dec_gateup_blk keeps one lane per super-block)
 };
 
 struct DecodeCtx {
@@ -33,6 +34,8 @@ struct DecodeCtx {
     int vt_ld;
 };
 
+// raw Q4_K rows -> decode order: the nibble dwords of every super-block transposed so that a lane's 16 bytes are one column class (q4k_dot.h)
+int decode_order_q4k(const void *src, void *dst, int64_t n_blocks, hipStream_t st);
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st);
 int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st);
 

@@ -73,6 +73,7 @@ struct MllmFile {
 struct LinearW {          // one (possibly row-concatenated) Linear
     void *w = nullptr;    // Q4_K blocks [N][K/256] or fp32 [N][K]
     void *wp = nullptr;   // the same rows packed for the M >= 16 GEMM (mllm_hip_q4k_prepack): prefill / vision read these
+    void *wd = nullptr;   // LLM decode Linears only: the rows in decode order (decode_order_q4k) for the fused decode kernels
     float *bias = nullptr;
     int N = 0, K = 0, dtype = MLLM_HIP_Q4_K;
 };
@@ -311,9 +312,17 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
         d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos; d.cur_sin = m->cur_sin; d.cur_cos = m->cur_cos;
         d.kslab = m->kslab; d.vslab = m->vslab; d.vt_ld = m->vt_ld; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
         for (auto &L : m->layers) {
+            for (LinearW *lw : {&L.qkv, &L.o, &L.gu, &L.down}) {
+                const int64_t nblk = (int64_t)lw->N * (lw->K / 256);
+                uint8_t *wd = nullptr;
+                CK(m->dalloc(&wd, (size_t)nblk * 144));
+                CK(decode_order_q4k(lw->w, wd, nblk, m->st));
+                lw->wd = wd;
+            }
             DecodeLayer dl;
-            dl.in_norm = L.in_norm; dl.post_norm = L.post_norm; dl.Wqkv = (const uint8_t *)L.qkv.w; dl.bqkv = L.qkv.bias; dl.qkv_N = L.qkv.N;
-            dl.Wo = (const uint8_t *)L.o.w; dl.Wgu = (const uint8_t *)L.gu.w; dl.Wdown = (const uint8_t *)L.down.w;
+            dl.in_norm = L.in_norm; dl.post_norm = L.post_norm; dl.Wqkv = (const uint8_t *)L.qkv.wd; dl.bqkv = L.qkv.bias; dl.qkv_N = L.qkv.N;
+            dl.Wo = (const uint8_t *)L.o.wd; dl.Wgu = (const uint8_t *)L.gu.wd; dl.Wdown = (const uint8_t *)L.down.wd;
+            dl.Wgu_raw = (const uint8_t *)L.gu.w;
             m->dlayers.push_back(dl);
         }
         m->use_graph = getenv("MLLM_HIP_NO_GRAPH") == nullptr;
@@ -339,7 +348,7 @@ extern "C" int64_t mllm_hip_qwen2vl_decode_weight_bytes(const mllm_hip_qwen2vl *
 extern "C" void *mllm_hip_qwen2vl_stream(mllm_hip_qwen2vl *m) { return (void *)m->st; }
 // bring-up aid (not part of include/mllm_hip.h): device pointers of the prefill activations, 0 h0, 1 h1, 2 qkv, 3 attn, 4 gate|up, 5 act
 extern "C" void *mllm_hip_qwen2vl_debug_ptr(mllm_hip_qwen2vl *m, int which) {
-    switch (which) { case 0: return m->h0; case 1: return m->h1; case 2: return m->qkv; case 3: return m->attn; case 4: return m->gu; case 5: return m->act; case 6: return m->kslab; case 7: return m->vslab; }
+    switch (which) { case 0: return m->h0; case 1: return m->h1; case 2: return m->qkv; case 3: return m->attn; case 4: return m->gu; case 5: return m->act; case 6: return m->kslab; case 7: return m->vslab; case 8: return m->logits; }
     return nullptr;
 }
 
@@ -656,7 +665,8 @@ extern "C" int mllm_hip_qwen2vl_time_gemv(mllm_hip_qwen2vl *m, int which, int it
     // gate|up, down.  Launch i uses layer i % layers, so consecutive launches stream different weights (28 x 15.5 MB does not
     // fit the 256 MiB Infinity Cache): the time is that of a cold HBM stream, like inside the decode step.
     if (!m || iters <= 0) return MLLM_HIP_ERR_ARG;
-    const int nl = (int)m->layers.size();
+    int nl = (int)m->layers.size();
+    if (const char *e = getenv("MLLM_HIP_TIME_LAYERS")) nl = std::max(1, std::min(nl, atoi(e)));   // fewer layers: an Infinity-Cache-warm stream
     auto launch = [&](int i) -> int {
         auto &L = m->layers[i % nl];
         if (which >= 10) return decode_kernel_launch(m->dctx, m->dlayers.data(), i % nl == 0 && which == 10 ? 1 % nl : i % nl, which - 10, m->st);

@@ -29,6 +29,12 @@ namespace mllm_hip {
 #ifndef MLLM_HIP_NT
 #define MLLM_HIP_NT 0
 #endif
+#ifndef MLLM_HIP_GUB
+#define MLLM_HIP_GUB 1
+#endif
+#ifndef MLLM_HIP_GUB_DMA_FIRST
+#define MLLM_HIP_GUB_DMA_FIRST 1
+#endif
 #ifndef MLLM_HIP_PRE_ROWS
 #define MLLM_HIP_PRE_ROWS 0
 #endif
@@ -96,6 +102,7 @@ struct ActLds {
     float *d;
     int *q8s;
     float *xf;
+    int qstride;    // bytes between the q8 bytes of consecutive 256-blocks (256, or 272 for the bank-staggered image of dec_gateup_blk)
 };
 __device__ __forceinline__ ActLds carve_act(char *smem, int K) {
     ActLds a;
@@ -103,6 +110,7 @@ __device__ __forceinline__ ActLds carve_act(char *smem, int K) {
     a.d = reinterpret_cast<float *>(smem + K);
     a.q8s = reinterpret_cast<int *>(smem + K + ((K / 256 * 4 + 15) & ~15));
     a.xf = reinterpret_cast<float *>(smem + K + ((K / 256 * 4 + 15) & ~15) + ((K / 32 * 4 + 15) & ~15));
+    a.qstride = 256;
     return a;
 }
 __host__ __device__ static inline size_t act_lds_bytes(int K, bool with_xf) {
@@ -143,7 +151,7 @@ __device__ __forceinline__ void wave_quant_blocks(const float4 (&v)[NB], int lan
     for (int i = 0; i < NB; ++i) {
         const int blk = wid + WPB * i;
         if (blk < nblk) {
-            reinterpret_cast<uint32_t *>(a.qs + blk * 256)[lane] = packed[i];
+            reinterpret_cast<uint32_t *>(a.qs + blk * a.qstride)[lane] = packed[i];
             if ((lane & 7) == 0) a.q8s[blk * 8 + (lane >> 3)] = qsum[i];
             if (lane == 0) a.d[blk] = dd[i];
         }
@@ -161,7 +169,10 @@ __device__ __forceinline__ void load_row(float4 (&xv)[NV], const float *__restri
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int d = threadIdx.x * 4 + i * WPB * 256;
-        xv[i] = d < dim ? *reinterpret_cast<const float4 *>(x + d) : make_float4(0, 0, 0, 0);
+        // unconditional load of a clamped address + select: a predicated load makes the compiler wait for it inside the branch, which
+        // serialises the row's and the norm weights' round trips
+        const float4 v = *reinterpret_cast<const float4 *>(x + (d < dim ? d : 0));
+        xv[i] = d < dim ? v : make_float4(0, 0, 0, 0);
     }
 }
 // thread (wid, lane) holds values [(wid + WPB*i)*256 + 4*lane, +4): exactly the 4 values of lane `lane` of quant block wid + WPB*i
@@ -204,7 +215,7 @@ struct RowLoads { uint4 hdr[ROWS][NSTEPS], q[ROWS][NSTEPS]; };
 
 template <int NSTEPS, int ROWS, int R0 = 0, int R1 = ROWS>
 __device__ __forceinline__ void issue_rows(RowLoads<NSTEPS, ROWS> &L, const uint8_t *__restrict__ W, int nb, const int *rows, int lane) {
-    const int g = lane >> 3, qoff = q4k_lane_qoff(lane);
+    const int g = lane >> 3, qoff = 16 * (lane & 7);          // decode-order rows: the lane's 16 bytes = column class lane & 7
 #pragma unroll
     for (int rr = R0; rr < R1; ++rr)
 #pragma unroll
@@ -220,9 +231,9 @@ __device__ __forceinline__ void issue_rows(RowLoads<NSTEPS, ROWS> &L, const uint
 // out[rr] is wave-uniform.  tab: this wave's chain table (q4k_dot.h) inside the workgroup's dynamic LDS, after the activation image
 template <int NSTEPS, int ROWS>
 __device__ __forceinline__ void dot_rows(const RowLoads<NSTEPS, ROWS> &L, const ActLds &a, int nb, int lane, float2 *tab, float (&out)[ROWS]) {
-    Q4KAct<NSTEPS> A;
-    q4k_load_act<NSTEPS>(A, a.qs, a.d, a.q8s, nb, lane);
-    q4k_dot_rows<NSTEPS, ROWS>(L.hdr, L.q, A, nb, lane, tab, out);
+    Q4KActC<NSTEPS> A;
+    q4kc_load_act<NSTEPS>(A, a.qs, a.d, a.q8s, nb, lane);
+    q4kc_dot_rows<NSTEPS, ROWS>(L.hdr, L.q, A, nb, lane, tab, out);
 }
 template <int NSTEPS, int ROWS>
 __device__ __forceinline__ float2 *wave_tab(char *smem, int K, bool with_xf, int wid) {
@@ -341,6 +352,144 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_kernel(const float *__res
                 act[n] = (g / (1.0f + v_expf_dec(0.0f - g))) * u;   // mllm_v_silu then F_TTMUL
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dec_gateup_blk: the same step with ONE LANE PER SUPER-BLOCK.  The kernels above are VALU-bound (weights resident in L2 run no
+// faster than cold ones): with 8 lanes per super-block every lane repeats the header unpack and the table bookkeeping for 32 weights.
+// Here a wave takes PAIRS gate rows and PAIRS up rows (2 * PAIRS * K/256 <= 64 super-blocks), streams them -- contiguous in memory --
+// into LDS by LDS-DMA, and lane l keeps super-block l whole: one header unpack and one (scale, value) table row per 256 weights,
+// 7 VALU operations per nibble dword (and, shift, and, 2 dot4, 2 24-bit mads).  The chain walk and the table layout are q4k_dot.h's.
+// The activation image is staggered (272-byte block stride) so that the 6 distinct blocks read by one ds_read_b128 hit distinct banks.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int GUB_QSTRIDE = 272;
+__host__ __device__ static inline size_t gub_act_bytes(int K) {
+    return (size_t)(K / 256) * GUB_QSTRIDE + ((K / 256 * 4 + 15) & ~15) + ((K / 32 * 4 + 15) & ~15) + 64;
+}
+__host__ __device__ static inline size_t gub_half_bytes(int pairs, int nb) { return ((size_t)pairs * nb * 144 + 1023) & ~(size_t)1023; }
+__host__ __device__ static inline size_t gub_wave_bytes(int pairs, int nb) { return 2 * gub_half_bytes(pairs, nb) + (size_t)2 * pairs * nb * Q4K_SLOTS * 8 + 64; }
+static inline size_t gub_lds_bytes(int K, int pairs, int wpb) { return ((gub_act_bytes(K) + 15) & ~(size_t)15) + (size_t)wpb * gub_wave_bytes(pairs, K / 256); }
+
+__device__ __forceinline__ void glds16_dec(const void *gsrc, unsigned lds_dst_in) {
+    unsigned keep;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int PAIRS, int NV, int WPB>
+__global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *__restrict__ x, const float *__restrict__ norm_w, float eps,
+                                                                  const uint8_t *__restrict__ W, float *__restrict__ act, int I, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[(WPB + 1) & ~1];      // a multiple of 16 bytes: statics precede the dynamic region unpadded
+    const int nb = K >> 8;
+    ActLds a;
+    a.qs = reinterpret_cast<int8_t *>(smem);
+    a.d = reinterpret_cast<float *>(smem + (size_t)nb * GUB_QSTRIDE);
+    a.q8s = reinterpret_cast<int *>(smem + (size_t)nb * GUB_QSTRIDE + ((nb * 4 + 15) & ~15));
+    a.xf = nullptr;
+    a.qstride = GUB_QSTRIDE;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = blockIdx.x * WPB + wid;
+    const int p0 = wave * PAIRS;                                  // first pair of this wave (the launcher guarantees I % PAIRS == 0)
+    const bool live = p0 < I;
+    const size_t half = gub_half_bytes(PAIRS, nb);
+    char *stage = smem + ((gub_act_bytes(K) + 15) & ~(size_t)15) + (size_t)wid * gub_wave_bytes(PAIRS, nb);
+    float2 *tab = reinterpret_cast<float2 *>(stage + 2 * half);
+    float *outv = reinterpret_cast<float *>(stage + 2 * half + (size_t)2 * PAIRS * nb * Q4K_SLOTS * 8);
+    float4 xv[NV], wv[NV];
+    load_row<NV, WPB>(xv, x, K);
+    load_row<NV, WPB>(wv, norm_w, K);
+    __builtin_amdgcn_sched_barrier(0);
+#if MLLM_HIP_GUB_DMA_FIRST
+    // ---- the wave's rows: two contiguous runs of PAIRS * nb super-blocks -> LDS (global_load_lds_dwordx4, 1 KiB per instruction) ----------------
+    const int run = PAIRS * nb * 144;
+    if (live) {
+        const unsigned st0 = (unsigned)(size_t)stage;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint8_t *src = W + ((int64_t)(r ? I + p0 : p0) * nb) * 144;
+            for (int o = 0; o < run; o += 1024) {
+                const int off = o + lane * 16;
+                glds16_dec(src + (off < run ? off : 0), st0 + (unsigned)(r * half) + (unsigned)o);   // past the run: a dummy 16 bytes into the pad
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
+#if !MLLM_HIP_GUB_DMA_FIRST
+    // ---- the wave's rows: two contiguous runs of PAIRS * nb super-blocks -> LDS (global_load_lds_dwordx4, 1 KiB per instruction) ----------------
+    const int run = PAIRS * nb * 144;
+    if (live) {
+        const unsigned st0 = (unsigned)(size_t)stage;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint8_t *src = W + ((int64_t)(r ? I + p0 : p0) * nb) * 144;
+            for (int o = 0; o < run; o += 1024) {
+                const int off = o + lane * 16;
+                glds16_dec(src + (off < run ? off : 0), st0 + (unsigned)(r * half) + (unsigned)o);   // past the run: a dummy 16 bytes into the pad
+            }
+        }
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- lane l: super-block (region = gate / up, pair, b) ------------------------------------------------------------------------------------
+    const int region = lane >= PAIRS * nb, within = lane - (region ? PAIRS * nb : 0), pair = within / nb, b = within - pair * nb;
+    if (live && lane < 2 * PAIRS * nb) {
+        const char *blk = stage + (size_t)region * half + (size_t)within * 144;
+        const uint4 hdr = *reinterpret_cast<const uint4 *>(blk);
+        const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
+        uint32_t sc8[2], mn8[2];
+        unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
+        const int8_t *xb = a.qs + b * GUB_QSTRIDE;
+        int cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sl = byte_of(sc8, 2 * j), sh = byte_of(sc8, 2 * j + 1);
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 q0 = *reinterpret_cast<const u32x4 *>(blk + 16 + 32 * j), q1 = *reinterpret_cast<const u32x4 *>(blk + 32 + 32 * j);
+            const i32x4 xl0 = *reinterpret_cast<const i32x4 *>(xb + 64 * j), xl1 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 16);
+            const i32x4 xh0 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 32), xh1 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 48);
+            int lo[8], hi[8], xl[8], xh[8], dl[8], dh[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const unsigned q = t < 4 ? q0[t & 3] : q1[t & 3];
+                lo[t] = (int)(q & 0x0f0f0f0fu); hi[t] = (int)((q >> 4) & 0x0f0f0f0fu);
+                xl[t] = t < 4 ? xl0[t & 3] : xl1[t & 3]; xh[t] = t < 4 ? xh0[t & 3] : xh1[t & 3];
+            }
+            dot4z_x8(dl, lo, xl);
+            dot4z_x8(dh, hi, xh);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) cls[t] = __mul24(sh, dh[t]) + (__mul24(sl, dl[t]) + cls[t]);
+        }
+        const int4 s0 = *reinterpret_cast<const int4 *>(a.q8s + b * 8), s1 = *reinterpret_cast<const int4 *>(a.q8s + b * 8 + 4);
+        const int prod0 = __mul24(byte_of(mn8, 0), s0.x) + __mul24(byte_of(mn8, 1), s0.y), prod1 = __mul24(byte_of(mn8, 2), s0.z) + __mul24(byte_of(mn8, 3), s0.w);
+        const int prod2 = __mul24(byte_of(mn8, 4), s1.x) + __mul24(byte_of(mn8, 5), s1.y), prod3 = __mul24(byte_of(mn8, 6), s1.z) + __mul24(byte_of(mn8, 7), s1.w);
+        const float xd = a.d[b];
+        const float dy = xd * d, dm = (-xd) * dmin;      // VecDotQ4.cpp:228-229
+        // table row [2 * pair + region][b][12]: slots 0..7 = classes [0,4,2,6,1,5,3,7], 8..11 = mins [0,2,1,3]   (q4k_dot.h)
+        // (float2 stores, the type q4k_chain reads: a float4 store would be a different TBAA base and may be moved across the fence)
+        float2 *e = tab + ((size_t)(2 * pair + region) * nb + b) * Q4K_SLOTS;
+        e[0] = make_float2(dy, (float)cls[0]); e[1] = make_float2(dy, (float)cls[4]);
+        e[2] = make_float2(dy, (float)cls[2]); e[3] = make_float2(dy, (float)cls[6]);
+        e[4] = make_float2(dy, (float)cls[1]); e[5] = make_float2(dy, (float)cls[5]);
+        e[6] = make_float2(dy, (float)cls[3]); e[7] = make_float2(dy, (float)cls[7]);
+        e[8] = make_float2(dm, (float)prod0); e[9] = make_float2(dm, (float)prod2);
+        e[10] = make_float2(dm, (float)prod1); e[11] = make_float2(dm, (float)prod3);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int p = 0; p < 2 * PAIRS; p += 4) {
+        const int nr = 2 * PAIRS - p < 4 ? 2 * PAIRS - p : 4;
+        const float res = q4k_chain(tab + (size_t)p * nb * Q4K_SLOTS, nb, nb, nr, lane);
+        if ((lane & 15) == 8 && (lane >> 4) < nr) outv[p + (lane >> 4)] = res;
+    }
+    wave_lds_fence();
+    if (live && lane < PAIRS) {
+        const float g = outv[2 * lane], u = outv[2 * lane + 1];
+        act[p0 + lane] = (g / (1.0f + v_expf_dec(0.0f - g))) * u;   // mllm_v_silu then F_TTMUL
     }
 }
 
@@ -641,6 +790,23 @@ static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *
 #ifndef GU_WPB
 #define GU_WPB 8
 #endif
+#ifndef GUB_PAIRS
+#define GUB_PAIRS 5
+#endif
+#ifndef GUB_WPB
+#define GUB_WPB 7
+#endif
+    static const bool gub_off = getenv("MLLM_HIP_NO_GUB") != nullptr;      // bring-up switch: the 8-lanes-per-block kernel instead
+    if (MLLM_HIP_GUB && !gub_off && NS == 1 && 2 * GUB_PAIRS * (c.H >> 8) <= 64 && c.I % GUB_PAIRS == 0 && (c.H >> 8) <= GUB_WPB) {
+        constexpr int BP = GUB_PAIRS, BW = GUB_WPB, BNV = 1;      // one quant block per wave in the prologue: K/256 <= waves
+        const int bw = c.I / BP;
+        const size_t blds = gub_lds_bytes(c.H, BP, BW);
+        auto bk = dec_gateup_blk_kernel<BP, BNV, BW>;
+        int brc = allow_lds(bk, blds);
+        if (brc) return brc;
+        hipLaunchKernelGGL(bk, dim3((bw + BW - 1) / BW), dim3(64 * BW), blds, st, x, L.post_norm, c.eps, L.Wgu_raw, c.act, c.I, c.H);
+        return MH_LAUNCH_OK("dec_gateup_blk");
+    }
     constexpr int PAIRS = NS == 1 ? GU_PAIRS : 1, WPB = GU_WPB;
     const int waves = (c.I + PAIRS - 1) / PAIRS;
     const size_t lds = fused_lds_bytes<NS, 2 * PAIRS>(c.H, false, WPB);
@@ -686,6 +852,23 @@ static int launch_proj(const uint8_t *W, const float *xin, const float *residual
     }
 
 // one fused kernel of layer `li`: 0 qkv, 1 attn, 2 o-proj, 3 gate|up, 4 down. x = layer input / output, t = post-attention residual
+// raw Q4_K rows -> decode order (one thread per dword of the nibble area; headers copied)
+__global__ void q4k_decode_order_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t n_blocks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // dword index over n_blocks * 36
+    if (i >= n_blocks * 36) return;
+    const int64_t blk = i / 36;
+    const int w = (int)(i - blk * 36);
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(src + blk * 144);
+    uint32_t *o = reinterpret_cast<uint32_t *>(dst + blk * 144);
+    if (w < 4) o[w] = s[w];
+    else { const int n = w - 4, t = n >> 2, j = n & 3; o[w] = s[4 + 8 * j + t]; }
+}
+int decode_order_q4k(const void *src, void *dst, int64_t n_blocks, hipStream_t st) {
+    const int64_t n = n_blocks * 36;
+    hipLaunchKernelGGL(q4k_decode_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)src, (uint8_t *)dst, n_blocks);
+    return MH_LAUNCH_OK("q4k_decode_order");
+}
+
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st) {
     if (c.D != 128 || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
     float *x = c.x0, *t = c.x1;

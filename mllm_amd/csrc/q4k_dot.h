@@ -140,6 +140,91 @@ __device__ __forceinline__ void q4k_dot_rows(const uint4 (&hdr)[ROWS][NSTEPS], c
             out[rr] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res), 16 * (rr - p) + 8));
     }
 }
+// ---- decode-order weights (engine only) ------------------------------------------------------------------------------------------------
+// The resident engine keeps a second copy of every decode Linear with the 128 nibble bytes of each super-block transposed
+// (q4k_decode_order_kernel): new dword 4 t + j = old dword 8 j + t, i.e. the 16 bytes a lane loads are column class t of all four
+// 64-weight chunks.  Lane (g = lane >> 3, t = lane & 7) then owns class t of super-block 8 st + g whole: the class sum needs no
+// cross-lane step and no select, and the integer work is 8 v_dot4 + 8 24-bit mads per lane and row (the GEMV kernels are VALU-bound:
+// 735 VALU instructions per wave for 4 rows before this layout, L2-resident weights ran no faster than cold ones).
+__device__ __forceinline__ int bitrev3(int v) { return ((v & 1) << 2) | (v & 2) | (v >> 2); }
+// Eight independent v_dot4_i32_i8 with a zero accumulator (the builtin picks the tied VOP2 form v_dot4c + one v_mov per dot).
+// DOT results have a 3-wait-state hazard against a different VALU instruction that reads or overwrites them (LLVM's
+// GCNHazardRecognizer: DotWriteDifferentVALURead / ...Write = 3 on gfx90a+); the compiler does not see through inline asm, so the
+// block ends with s_nop 2 -- inside the block the eight results are independent, and the earlier ones are >= 3 instructions old.
+__device__ __forceinline__ void dot4z_x8(int (&r)[8], const int (&a)[8], const int (&b)[8]) {
+    asm("v_dot4_i32_i8 %0, %8, %16, 0\n\tv_dot4_i32_i8 %1, %9, %17, 0\n\tv_dot4_i32_i8 %2, %10, %18, 0\n\tv_dot4_i32_i8 %3, %11, %19, 0\n\t"
+        "v_dot4_i32_i8 %4, %12, %20, 0\n\tv_dot4_i32_i8 %5, %13, %21, 0\n\tv_dot4_i32_i8 %6, %14, %22, 0\n\tv_dot4_i32_i8 %7, %15, %23, 0\n\ts_nop 2"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]),
+          "v"(b[5]), "v"(b[6]), "v"(b[7]));
+}
+template <int NSTEPS>
+struct Q4KActC {
+    int xa[NSTEPS][4], xb[NSTEPS][4];   // q8 dwords of class t: low-nibble weights 64 j + 4 t .., high-nibble weights 64 j + 32 + 4 t ..
+    float xd[NSTEPS];
+    int mq0[NSTEPS], mq1[NSTEPS];
+    bool valid[NSTEPS];
+};
+template <int NSTEPS>
+__device__ __forceinline__ void q4kc_load_act(Q4KActC<NSTEPS> &A, const int8_t *qs, const float *d, const int *q8s32, int nb, int lane) {
+    const int g = lane >> 3, t = lane & 7, u = lane & 3;
+#pragma unroll
+    for (int st = 0; st < NSTEPS; ++st) {
+        const int blk = st * 8 + g;
+        A.valid[st] = blk < nb;
+        const int b = A.valid[st] ? blk : 0;
+        const int *x = reinterpret_cast<const int *>(qs + b * 256) + t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { A.xa[st][j] = x[16 * j]; A.xb[st][j] = x[16 * j + 8]; }
+        A.xd[st] = d[b];
+        A.mq0[st] = q8s32[b * 8 + 2 * u];
+        A.mq1[st] = q8s32[b * 8 + 2 * u + 1];
+    }
+}
+template <int NSTEPS>
+__device__ __forceinline__ void q4kc_emit(const uint4 hdr, const uint4 q, const Q4KActC<NSTEPS> &A, int st, int lane, float2 *row_tab) {
+    const int g = lane >> 3, t = lane & 7, u = lane & 3;
+    const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
+    uint32_t sc8[2], mn8[2];
+    unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
+    const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+    int nib[8], xv[8], dd[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        nib[2 * j] = (int)(qw[j] & 0x0f0f0f0fu); nib[2 * j + 1] = (int)((qw[j] >> 4) & 0x0f0f0f0fu);
+        xv[2 * j] = A.xa[st][j]; xv[2 * j + 1] = A.xb[st][j];
+    }
+    dot4z_x8(dd, nib, xv);
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = __mul24(byte_of(sc8, k), dd[k]) + s;
+    const int prod = __mul24(byte_of(mn8, 2 * u), A.mq0[st]) + __mul24(byte_of(mn8, 2 * u + 1), A.mq1[st]);
+    const float dy = A.xd[st] * d;              // y.d * fp16(x.d)        (VecDotQ4.cpp:228)
+    const float dm = (-A.xd[st]) * dmin;      // -y.d * fp16(x.dmin)    (:229)
+    if (A.valid[st]) {
+        float2 *e = row_tab + (st * 8 + g) * Q4K_SLOTS;
+        e[bitrev3(t)] = make_float2(dy, (float)s);
+        if (t < 4) e[8 + bitrev2(u)] = make_float2(dm, (float)prod);
+    }
+}
+template <int NSTEPS, int ROWS>
+__device__ __forceinline__ void q4kc_dot_rows(const uint4 (&hdr)[ROWS][NSTEPS], const uint4 (&q)[ROWS][NSTEPS], const Q4KActC<NSTEPS> &A, int nb, int lane,
+                                              float2 *tab, float (&out)[ROWS]) {
+    constexpr int NBP = NSTEPS * 8;
+#pragma unroll
+    for (int p = 0; p < ROWS; p += 4) {
+        if (p) wave_lds_fence();
+#pragma unroll
+        for (int rr = p; rr < (p + 4 < ROWS ? p + 4 : ROWS); ++rr)
+#pragma unroll
+            for (int st = 0; st < NSTEPS; ++st) q4kc_emit<NSTEPS>(hdr[rr][st], q[rr][st], A, st, lane, tab + (size_t)(rr - p) * NBP * Q4K_SLOTS);
+        wave_lds_fence();
+        const float res = q4k_chain(tab, NBP, nb, ROWS - p < 4 ? ROWS - p : 4, lane);
+#pragma unroll
+        for (int rr = p; rr < (p + 4 < ROWS ? p + 4 : ROWS); ++rr)
+            out[rr] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res), 16 * (rr - p) + 8));
+    }
+}
 constexpr size_t q4k_tab_bytes(int nsteps, int rows) { return (size_t)(rows < 4 ? rows : 4) * nsteps * 8 * Q4K_SLOTS * sizeof(float2); }
 
 }  // namespace mllm_hip

@@ -1,7 +1,7 @@
 import sys, os, ctypes as C, numpy as np
 sys.path.insert(0, '.')
 from mllm_amd import lib
-lib.SO_PATH = os.path.abspath('scratch/libmllm_hip_stamps.so')
+lib.SO_PATH = os.path.abspath(os.environ.get('STAMPSO', 'scratch/libmllm_hip_stamps.so'))
 from mllm_amd import synth, weights
 cfg = synth.qwen2vl_2b(); path = weights.qwen2vl_file(cfg)
 ids = (np.arange(int(os.environ.get('NTOK','8'))) * 7919 % 150000).astype(np.int32)
