@@ -129,7 +129,7 @@ def main():
         traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["dec_gateup_kernel"]["fetch_bytes_per_launch"]
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": "dec_gateup_kernel<1,2,1,8> (fused RMSNorm+Q8_K+gate|up GEMV+SiLU*mul, 17920 x 1536 Q4_K rows, launches cycle over the 28 layers so every launch streams cold HBM)", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "dec_gateup_blk_kernel<5,1,7> (fused RMSNorm+Q8_K+gate|up GEMV+SiLU*mul, 17920 x 1536 Q4_K rows, one lane per super-block, LDS-DMA weight stream; launches cycle over the 28 layers so every launch streams cold HBM)", "achieved": round(achieved, 1),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "us_per_launch": round(ms_launch * 1e3, 3), "algorithmic_bytes_per_launch": int(bytes_launch)}
     wbytes = m.decode_weight_bytes()
