@@ -644,22 +644,23 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__
     float best = -INFINITY;
     int besti = 0x7fffffff;
     for (int base = row0; base < row1; base += 8) {
+        // this pass's rows are in q0 / d0 (loaded one pass ago); the next pass's rows are requested before the dot so that the HBM
+        // round trip runs underneath the emit and the chain walk instead of in front of them
         uint4 q[2][BPL];
         uint16_t dw[2][BPL];
-        if (base == row0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int b = 0; b < BPL; ++b) { q[u][b] = q0[u][b]; dw[u][b] = d0[u][b]; }
-        } else {
+            for (int b = 0; b < BPL; ++b) { q[u][b] = q0[u][b]; dw[u][b] = d0[u][b]; }
+        if (base + 8 < row1) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int rw = min(base + 4 * u + rsel, row1 - 1);
+                const int rw = min(base + 8 + 4 * u + rsel, row1 - 1);
 #pragma unroll
                 for (int b = 0; b < BPL; ++b) {
                     const int64_t bidx = (int64_t)rw * nblk + sub + 16 * b;
-                    q[u][b] = *reinterpret_cast<const uint4 *>(Wqs + bidx * 16);
-                    dw[u][b] = Wd[bidx];
+                    q0[u][b] = *reinterpret_cast<const uint4 *>(Wqs + bidx * 16);
+                    d0[u][b] = Wd[bidx];
                 }
             }
         }
