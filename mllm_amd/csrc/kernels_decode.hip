@@ -921,7 +921,8 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
         hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, st, c.state, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos, c.D / 2, c.cache_limit);
         return MH_LAUNCH_OK("dec_advance");
     }
-    const int target_waves = 256 * 12;
+    static const int head_wpc = getenv("MLLM_HIP_HEAD_WPC") ? atoi(getenv("MLLM_HIP_HEAD_WPC")) : 8;   // waves per CU the row split aims at
+    const int target_waves = 256 * head_wpc;
     int rpw = (c.vocab + target_waves - 1) / target_waves;
     rpw = ((rpw + 7) / 8) * 8;
     const int waves = (c.vocab + rpw - 1) / rpw, blocks = (waves + 3) / 4;
