@@ -77,32 +77,52 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
     v16f_t oacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[i] = 0.0f;
-    // staging registers (the next chunk is requested while the current one is consumed)
-    float kst[KE], vst[KE];
+    // staging registers (the next chunk is requested while the current one is consumed): four consecutive values per request --
+    // four dims of a key row, or four keys of a dim row of the transposed V slab
+    constexpr int KG = (FA_KCH * D / 4 + 255) / 256;     // 4-element groups per thread and operand
+    float4 kst[KG], vst[KG];
+    auto load4 = [&](const void *base, int64_t off) -> float4 {
+        if (F16) {
+            const uint2 w = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(base) + off);
+            return make_float4(h2f((uint16_t)(w.x & 0xffff)), h2f((uint16_t)(w.x >> 16)), h2f((uint16_t)(w.y & 0xffff)), h2f((uint16_t)(w.y >> 16)));
+        }
+        return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + off);
+    };
     auto fetch = [&](int chunk0) {
 #pragma unroll
-        for (int i = 0; i < KE; ++i) {
-            const int e = tid + 256 * i;
+        for (int i = 0; i < KG; ++i) {
+            const int e4 = min(tid + 256 * i, FA_KCH * D / 4 - 1);
             {
-                const int key = e / D, dd = e - key * D;
-                kst[i] = kv_at<F16>(K, (int64_t)min(chunk0 + key, Sk - 1) * ldk + kvh * D + dd);
+                const int key = e4 / (D / 4), d4 = e4 - key * (D / 4);
+                kst[i] = load4(K, (int64_t)min(chunk0 + key, Sk - 1) * ldk + kvh * D + 4 * d4);
             }
             if (VT) {
-                const int dd = e / FA_KCH, key = e - dd * FA_KCH;
-                vst[i] = h2f(reinterpret_cast<const uint16_t *>(V)[(int64_t)(kvh * D + dd) * ldv + chunk0 + key]);
+                const int dd = e4 / (FA_KCH / 4), k4 = e4 - dd * (FA_KCH / 4);
+                vst[i] = load4(V, (int64_t)(kvh * D + dd) * ldv + chunk0 + 4 * k4);
             } else {
-                const int key = e / D, dd = e - key * D;
-                vst[i] = kv_at<F16>(V, (int64_t)min(chunk0 + key, Sk - 1) * ldv + kvh * D + dd);
+                const int key = e4 / (D / 4), d4 = e4 - key * (D / 4);
+                vst[i] = load4(V, (int64_t)min(chunk0 + key, Sk - 1) * ldv + kvh * D + 4 * d4);
             }
         }
     };
     auto park = [&]() {
 #pragma unroll
-        for (int i = 0; i < KE; ++i) {
-            const int e = tid + 256 * i;
-            { const int key = e / D, dd = e - key * D; Ks[key * KP + dd] = kst[i]; }
-            if (VT) { const int dd = e / FA_KCH, key = e - dd * FA_KCH; Vs[dd * 33 + key] = vst[i]; }
-            else Vs[e] = vst[i];
+        for (int i = 0; i < KG; ++i) {
+            const int e4 = tid + 256 * i;
+            if (e4 < FA_KCH * D / 4) {
+                {
+                    const int key = e4 / (D / 4), d4 = e4 - key * (D / 4);
+                    float *kd = Ks + key * KP + 4 * d4;      // odd pitch: four scalar stores
+                    kd[0] = kst[i].x; kd[1] = kst[i].y; kd[2] = kst[i].z; kd[3] = kst[i].w;
+                }
+                if (VT) {
+                    const int dd = e4 / (FA_KCH / 4), k4 = e4 - dd * (FA_KCH / 4);
+                    float *vd = Vs + dd * 33 + 4 * k4;
+                    vd[0] = vst[i].x; vd[1] = vst[i].y; vd[2] = vst[i].z; vd[3] = vst[i].w;
+                } else {
+                    *reinterpret_cast<float4 *>(Vs + 4 * e4) = vst[i];
+                }
+            }
         }
     };
     fetch(0);
