@@ -175,6 +175,20 @@ __device__ __forceinline__ void load_row(float4 (&xv)[NV], const float *__restri
         xv[i] = d < dim ? v : make_float4(0, 0, 0, 0);
     }
 }
+// the activation row and the norm weights together: both loads are issued before either is waited for.  (Written as a select of an
+// unconditional load the compiler sinks each load back under its predicate and waits for it there, one round trip after the other;
+// the empty asm makes both values live at one point outside any predicate.)
+template <int NV, int WPB>
+__device__ __forceinline__ void load_rows2(float4 (&xv)[NV], float4 (&wv)[NV], const float *__restrict__ x, const float *__restrict__ w, int dim) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int d = threadIdx.x * 4 + i * WPB * 256, dc = d < dim ? d : 0;
+        float4 a = *reinterpret_cast<const float4 *>(x + dc), b = *reinterpret_cast<const float4 *>(w + dc);
+        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+        xv[i] = d < dim ? a : make_float4(0, 0, 0, 0);
+        wv[i] = d < dim ? b : make_float4(0, 0, 0, 0);
+    }
+}
 // thread (wid, lane) holds values [(wid + WPB*i)*256 + 4*lane, +4): exactly the 4 values of lane `lane` of quant block wid + WPB*i
 template <int NV, int WPB>
 __device__ __forceinline__ void wg_rmsnorm_quant(const float4 (&xv)[NV], const float4 (&wv)[NV], int dim, float eps, const ActLds &a, double *red) {
@@ -285,11 +299,10 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
             }
             xv[i] = v;
         }
-    } else {
-        load_row<NV, WPB>(xv, x, K);
     }
     float4 wv[NV];
-    load_row<NV, WPB>(wv, norm_w, K);
+    if (EMBED) load_row<NV, WPB>(wv, norm_w, K);
+    else load_rows2<NV, WPB>(xv, wv, x, norm_w, K);
     __builtin_amdgcn_sched_barrier(0);
     wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
     issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);   // after the prologue: see dec_gateup_kernel
@@ -325,8 +338,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_kernel(const float *__res
     RowLoads<NSTEPS, 2 * PAIRS> L;
     float4 xv[NV], wv[NV];
     STAMP(0);
-    load_row<NV, WPB>(xv, x, K);
-    load_row<NV, WPB>(wv, norm_w, K);
+    load_rows2<NV, WPB>(xv, wv, x, norm_w, K);
     // The activation row is tiny and L2-resident; the weight rows saturate the CU's memory queue for ~2 us.  Issuing them
     // first makes every wave of the workgroup sit in load issue while the prologue's barriers wait for it, so only PRE rows
     // go out before the prologue and the rest right after it (measured with the stamp build: 5.3 -> see DESIGN.md).
@@ -397,8 +409,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
     float2 *tab = reinterpret_cast<float2 *>(stage + 2 * half);
     float *outv = reinterpret_cast<float *>(stage + 2 * half + (size_t)2 * PAIRS * nb * Q4K_SLOTS * 8);
     float4 xv[NV], wv[NV];
-    load_row<NV, WPB>(xv, x, K);
-    load_row<NV, WPB>(wv, norm_w, K);
+    load_rows2<NV, WPB>(xv, wv, x, norm_w, K);
     __builtin_amdgcn_sched_barrier(0);
 #if MLLM_HIP_GUB_DMA_FIRST
     // ---- the wave's rows: two contiguous runs of PAIRS * nb super-blocks -> LDS (global_load_lds_dwordx4, 1 KiB per instruction) ----------------
