@@ -149,6 +149,7 @@ struct DecodePrefetch {
     uint4 v[4][DecodeGeom<D, F16, NT, VT>::VPT];
     uint2 k[F16 ? D / 8 : 1];     // direct form: this lane's half of its key row (strided 8-byte pieces)
     uint4 kc[VT ? D / 16 : 1];    // staged form: coalesced 16-byte pieces of the pass-0 key rows, parked in the (not yet used) V ring
+    uint64_t etab;                // this lane's entry of glibc_expf's table (requested with the other early loads, stored to LDS later)
 };
 // pass-0 keys staged through LDS: rows [NT/2][D fp16] at pitch D*2+16 bytes in the ring area; needs the full 4-slot ring
 template <int D>
@@ -171,6 +172,7 @@ __device__ __forceinline__ void fa2_decode_fetch_v(uint4 *dst, const void *V, in
 template <int D, bool F16, int NT, bool VT>
 __device__ __forceinline__ void fa2_decode_prefetch(DecodePrefetch<D, F16, NT, VT> &P, const void *K, int64_t ldk, const void *V, int64_t ldv, int kvoff,
                                                     int cap, int nslots) {
+    P.etab = expf_tab_fetch();
     if (VT && nslots == 4 && fa_kstage_fits<D, NT>()) {
         // coalesced: one wave instruction = 1 KiB of consecutive key rows (the strided per-lane form below costs one cache line per lane)
         constexpr int ROWK = D * 2 / 16;
@@ -213,7 +215,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
         }
     };
     STAMP(0);
-    const uint64_t etab_v = expf_tab_fetch();
+    const uint64_t etab_v = P.etab;
     const bool kstaged = VT && L.nslots == 4 && fa_kstage_fits<D, NT>();
     if (kstaged) {
         constexpr int ROWK = D * 2 / 16;

@@ -108,3 +108,25 @@ def test_long_context_crosses_the_score_pass_and_ring_boundaries(tmp_path):
             assert tok == int(np.argmax(want))
     finally:
         m.close()
+
+
+def test_mid_shape_engine_matches_oracle_composition(tmp_path):
+    """hidden 512 / inter 1280: two super-blocks per row and an intermediate size divisible by 5, i.e. the one-lane-per-super-block
+    gate|up kernel (dec_gateup_blk) on a shape other than the 2B model's (the tiny golden config falls back to the 8-lane kernel)."""
+    from oracle import models as omodels
+    cfg = synth.Qwen2VLConfig(hidden=512, inter=1280, layers=2, heads=4, kv_heads=2, vocab=2048, cache_limit=64, v_dim=256, image_token_id=2040,
+                              vision_start_token_id=2041, vision_end_token_id=2042, video_token_id=2043)
+    path = weights.qwen2vl_file(cfg, cache_dir=str(tmp_path), vision=False, tag="-mid")
+    m = lib.Qwen2VL(cfg, path)
+    try:
+        ids = (np.arange(20, dtype=np.int64) * 7919 % 2000).astype(np.int32)
+        ref = omodels.LLM(omodels.Weights(path), cfg)
+        want = ref.prefill(ids)
+        tok, logits, _ = m.prefill(ids)
+        assert np.array_equal(logits, want), float(np.abs(logits - want).max())
+        for _ in range(6):
+            want = ref.decode(tok)
+            tok, logits, _ = m.decode(tok)
+            assert np.array_equal(logits, want), float(np.abs(logits - want).max())
+    finally:
+        m.close()
