@@ -132,6 +132,13 @@ int mllm_hip_softmax(const float *x, float *y, int rows, int n, const int *valid
 int mllm_hip_index_put_rows(float *dst, const float *value, const int *idx, int n_rows, int dim, void *stream);
 /* host argmax of the logits row (processing_qwen2_vl.hpp:284-289), moved to device */
 int mllm_hip_argmax(const float *x, int n, int *out_index, void *stream);
+/* SURVEY N2, top-k sampling (mllm/Generate.cpp:45-90, _LlmTextGenerateTopkSamplingMethod::generate): the k largest logits in descending
+ * order with their indices (std::partial_sort of :60-61; equal logits by ascending index) selected on the device -- k values cross PCIe
+ * instead of the vocabulary row -- and the method's temperature softmax + renormalisation (:69-87) over those k on the host with the
+ * host's libm exp, as the reference computes it.  The draw itself (std::discrete_distribution seeded from std::random_device, Generate.hpp:38-44)
+ * is not reproducible in the reference and stays with the caller.  k <= 64. */
+int mllm_hip_topk(const float *x, int n, int k, float *out_val, int *out_idx, void *stream);
+int mllm_hip_topk_probs_host(const float *top_val, int k, float temperature, float *probs);
 
 /* ---- A10/A11/A19: rotary embeddings. Tables are built on the host with the reference's libm formulas
  *      (CPURoPE.cpp:22-31,100-128; CPUMultimodalRoPE.cpp:26-36,84-118,37-82; CPUVisionRoPE.cpp:19-55) and uploaded;

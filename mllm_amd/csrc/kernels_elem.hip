@@ -381,6 +381,44 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float *__restrict__ 
     }
 }
 
+// N2: the candidate set of _LlmTextGenerateTopkSamplingMethod::generate (mllm/Generate.cpp:56-67: std::partial_sort of the (logit, index)
+// pairs by descending logit, first k kept), on device so that k values travel instead of the whole logits row.  k rounds of a first-
+// maximum argmax over the entries not yet taken: descending values, equal values by ascending index (the reference's order among equal
+// logits is whatever its heap leaves -- not specified).  Single workgroup; k <= 64.
+__global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ x, int n, int k, float *__restrict__ out_val, int *__restrict__ out_idx) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int taken[64];
+    for (int r = 0; r < k; ++r) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const float v = x[i];
+            if (v > best || (bi == 0x7fffffff && !(v != v))) {      // first candidate of this thread, or strictly larger (NaNs never win)
+                bool free = true;
+                for (int t = 0; t < r; ++t) free = free && taken[t] != i;
+                if (free) { best = v; bi = i; }
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(best, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 16; ++w)
+                if (si[w] != 0x7fffffff && (bi == 0x7fffffff || sv[w] > best || (sv[w] == best && si[w] < bi))) { best = sv[w]; bi = si[w]; }
+            taken[r] = bi;
+            out_val[r] = best;
+            out_idx[r] = bi;
+        }
+        __syncthreads();
+    }
+}
+
 // A8: dequantize_row_q4_0 (ggml QuantizeQ4.cpp:74-93) of row ids[s] from the nibble/scale planes: y = (nib-8)*d
 __global__ __launch_bounds__(256) void embedding_q40_kernel(const float *__restrict__ ids, const uint8_t *__restrict__ Wqs, const uint16_t *__restrict__ Wd,
                                                             float *__restrict__ out, int hidden, int vocab) {
@@ -598,6 +636,30 @@ extern "C" int mllm_hip_argmax(const float *x, int n, int *out_index, void *stre
     if (n <= 0) return MLLM_HIP_ERR_SHAPE;
     hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n, out_index);
     return MH_LAUNCH_OK("argmax");
+}
+extern "C" int mllm_hip_topk(const float *x, int n, int k, float *out_val, int *out_idx, void *stream) {
+    if (n <= 0 || k <= 0 || k > 64 || k > n) return MLLM_HIP_ERR_SHAPE;
+    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n, k, out_val, out_idx);
+    return MH_LAUNCH_OK("topk");
+}
+// Host part of the same method (Generate.cpp:69-87): softmax with temperature over the k candidates, in the reference's mixed float /
+// double arithmetic with the host's libm exp (the reference runs it on the host too), then the renormalisation by the float sum.
+extern "C" int mllm_hip_topk_probs_host(const float *top_val, int k, float temperature, float *probs) {
+    if (k <= 0 || !top_val || !probs) return MLLM_HIP_ERR_ARG;
+    int am = 0;
+    for (int i = 1; i < k; ++i) if (top_val[i] > top_val[am]) am = i;      // std::max_element: first maximum
+    const double max_logit = top_val[am];
+    double sum_exp = 0.f;
+    for (int i = 0; i < k; ++i) {
+        probs[i] = exp((top_val[i] - max_logit) / temperature);
+        sum_exp += probs[i];
+    }
+    for (int i = 0; i < k; ++i) probs[i] /= sum_exp;
+    double acc = 0.0;
+    for (int i = 0; i < k; ++i) acc += probs[i];
+    const float fsum = acc;
+    for (int i = 0; i < k; ++i) probs[i] /= fsum;
+    return MLLM_HIP_OK;
 }
 extern "C" int mllm_hip_embedding_q40(const float *ids, const uint8_t *Wqs, const uint16_t *Wd, float *out, int S, int hidden, int vocab, void *stream) {
     if (hidden % 32 != 0) return MLLM_HIP_ERR_SHAPE;

@@ -279,3 +279,20 @@ def conv2d_patch(img_hcw, H, Cc, Wd, Wt, OC, p, bias=None):
     check(L.load().mllm_hip_im2patch_hcw(vp(img), vp(patches), C.c_int(H), C.c_int(Cc), C.c_int(Wd), C.c_int(p), _stream()), "im2patch")
     out = patch_gemm(patches, Wt, bias)  # [oh*ow][OC]
     return out.reshape(H // p, Wd // p, OC).permute(0, 2, 1).contiguous()
+
+
+def topk(logits, k):
+    """Top-k candidate set of _LlmTextGenerateTopkSamplingMethod (mllm/Generate.cpp:56-67) on device: (values desc, indices)."""
+    x = _dev(logits, torch.float32).reshape(-1)
+    val = torch.empty(k, dtype=torch.float32, device="cuda")
+    idx = torch.empty(k, dtype=torch.int32, device="cuda")
+    check(L.load().mllm_hip_topk(vp(x), C.c_int(x.numel()), C.c_int(k), vp(val), vp(idx), _stream()), "topk")
+    return val.cpu().numpy(), idx.cpu().numpy()
+
+
+def topk_probs(top_val, temperature):
+    """Temperature softmax + renormalisation over the k candidates (Generate.cpp:69-87), host arithmetic with the host's libm."""
+    v = np.ascontiguousarray(top_val, dtype=np.float32)
+    p = np.empty_like(v)
+    check(L.load().mllm_hip_topk_probs_host(vp(v), C.c_int(v.size), C.c_float(temperature), vp(p)), "topk_probs_host")
+    return p

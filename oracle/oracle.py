@@ -223,3 +223,24 @@ def f16_to_f32(a):
 
 def f32_to_f16(a):
     return _f32(a).astype(np.float16).view(np.uint16)
+
+
+def topk_sampling_probs(logits, k, temperature):
+    """N2 restatement (pure Python/numpy; parity unpinned -- the reference's generate() ends in a random_device-seeded draw and exposes no
+    intermediate): _LlmTextGenerateTopkSamplingMethod::generate, mllm/Generate.cpp:56-87.  Returns (indices, values, probabilities)."""
+    import math
+    x = np.asarray(logits, dtype=np.float32).ravel()
+    order = np.argsort(-x.astype(np.float64), kind="stable")[:k]          # partial_sort by descending logit; equal logits by index
+    top = x[order]
+    max_logit = float(top[int(np.argmax(top))])                            # double max_logit = top[argmax(top)]
+    soft = np.empty(k, dtype=np.float32)
+    sum_exp = 0.0
+    for i in range(k):
+        soft[i] = np.float32(math.exp((float(top[i]) - max_logit) / float(np.float32(temperature))))
+        sum_exp += float(soft[i])
+    for i in range(k):
+        soft[i] = np.float32(float(soft[i]) / sum_exp)
+    fsum = np.float32(sum(float(v) for v in soft))                         # float _sum = std::accumulate(..., 0.0)
+    for i in range(k):
+        soft[i] = np.float32(soft[i] / fsum)
+    return order.astype(np.int32), top, soft
