@@ -91,6 +91,10 @@ int mllm_hip_rmsnorm_packed(const float *x, const float *w, float *y, void *xpac
                             void *stream);
 int mllm_hip_layernorm_packed(const float *x, const float *w, const float *b, float *y, void *xpack, int M, int dim, float eps,
                               void *stream);
+/* the quantiser with the preceding activation folded in (prefill): lut = the fp16 LUT of mllm_hip_act_lut (A18), or silu(gate)*up on a fused
+ * [M][2 I] gate|up buffer (A14 + F_TTMUL); the values quantised are bit for bit those the separate launches would have stored */
+int mllm_hip_quantize_q8k_packed_act(const float *x, const uint16_t *lut, void *xpack, int M, int K, void *stream);
+int mllm_hip_quantize_q8k_packed_silu_mul(const float *gu, void *xpack, int M, int I, void *stream);
 int mllm_hip_linear_q4kp_packed(const void *Wpacked, const float *bias, const void *xpack, void *y, int y_dtype, int64_t ldy,
                                 const float *residual, int M, int N, int K, void *stream);
 int mllm_hip_linear_f32(const float *W, const float *bias, const float *x, float *y, int64_t ldy, int M, int N, int K, void *stream);

@@ -413,6 +413,17 @@ static int q_quant(M *m, const float *x, const Q8Planes &p, int rows, int K) {
     if (rows >= 16) { EH(ensure_xpack(m, rows, K)); return mllm_hip_quantize_q8k_packed(x, m->xpack, rows, K, m->st); }
     return mllm_hip_quantize_q8k(x, p.qs, p.d, p.bs, rows, K, m->st);
 }
+// activation + quantiser in one launch for the GEMM path; the separate launches otherwise
+static int q_act_quant(M *m, const float *x, float *scratch, const uint16_t *lut, const Q8Planes &p, int rows, int K) {
+    if (rows >= 16) { EH(ensure_xpack(m, rows, K)); return mllm_hip_quantize_q8k_packed_act(x, lut, m->xpack, rows, K, m->st); }
+    EH(mllm_hip_act_lut(x, scratch, (int64_t)rows * K, lut, m->st));
+    return q_quant(m, scratch, p, rows, K);
+}
+static int q_silu_mul_quant(M *m, const float *gu, float *scratch, const Q8Planes &p, int rows, int I) {
+    if (rows >= 16) { EH(ensure_xpack(m, rows, I)); return mllm_hip_quantize_q8k_packed_silu_mul(gu, m->xpack, rows, I, m->st); }
+    EH(mllm_hip_silu_mul(gu, scratch, rows, I, m->st));
+    return q_quant(m, scratch, p, rows, I);
+}
 static int q_rmsnorm(M *m, const float *x, const float *w, const Q8Planes &p, int rows, int dim, float eps) {
     if (rows >= 16) { EH(ensure_xpack(m, rows, dim)); return mllm_hip_rmsnorm_packed(x, w, nullptr, m->xpack, rows, dim, eps, 0, m->st); }
     return mllm_hip_rmsnorm(x, w, nullptr, p.qs, p.d, p.bs, rows, dim, eps, 0, m->st);
@@ -453,16 +464,14 @@ static int forward_vision(M *m, const int32_t *grid, float *out) {
         EH(lin(m, B.proj, m->xq, r, MLLM_HIP_F32, V, x, N));                       // residual = proj(attn) + x
         EH(q_layernorm(m, r, B.n2w, B.n2b, m->xq, N, V, 1e-6f));
         EH(lin(m, B.fc1, m->xq, m->vfc, MLLM_HIP_F32, VM, nullptr, N));
-        EH(mllm_hip_act_lut(m->vfc, m->vact, (int64_t)N * VM, m->lut_qgelu, st));
-        EH(q_quant(m, m->vact, m->xq2, N, VM));
+        EH(q_act_quant(m, m->vfc, m->vact, m->lut_qgelu, m->xq2, N, VM));
         EH(lin(m, B.fc2, m->xq2, x, MLLM_HIP_F32, V, r, N));                        // x = fc2(act) + residual
     }
     // PatchMerger: ln_q -> view [NT][MM] -> mlp.0 -> GELU -> mlp.2
     EH(mllm_hip_layernorm(x, m->lnq_w, m->lnq_b, r, nullptr, nullptr, nullptr, N, V, 1e-6f, st));
     EH(q_quant(m, r, m->xq2, NT, MM));
     EH(lin(m, m->m0, m->xq2, m->vm0, MLLM_HIP_F32, MM, nullptr, NT));
-    EH(mllm_hip_act_lut(m->vm0, m->vfc, (int64_t)NT * MM, m->lut_gelu, st));
-    EH(q_quant(m, m->vfc, m->xq2, NT, MM));
+    EH(q_act_quant(m, m->vm0, m->vfc, m->lut_gelu, m->xq2, NT, MM));
     EH(lin(m, m->m2, m->xq2, out, MLLM_HIP_F32, c.hidden, nullptr, NT));
     return 0;
 }
@@ -516,8 +525,7 @@ static int forward_llm(M *m, int S, const float *pos3) {
         EH(lin(m, L.o, m->xq, h2, MLLM_HIP_F32, H, h, S));                          // tmp = o_proj(attn) + x
         EH(q_rmsnorm(m, h2, L.post_norm, m->xq, S, H, c.rms_eps));
         EH(lin(m, L.gu, m->xq, m->gu, MLLM_HIP_F32, 2 * I, nullptr, S));
-        EH(mllm_hip_silu_mul(m->gu, m->act, S, I, st));
-        EH(q_quant(m, m->act, m->xq2, S, I));
+        EH(q_silu_mul_quant(m, m->gu, m->act, m->xq2, S, I));
         EH(lin(m, L.down, m->xq2, h, MLLM_HIP_F32, H, h2, S));                      // x = down(...) + tmp
     }
     // final norm on the last token only (norm then clip({-1}) == clip then norm), tied lm_head through Q8_0 activations

@@ -318,6 +318,33 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const float *__restrict__
         *reinterpret_cast<float4 *>(y + e) = o;
     }
 }
+// The same packing producer with the activation folded in (prefill only): the fp32 value that act_lut / silu_mul would have stored is
+// computed in registers and quantised at once -- one launch and one fp32 round trip through HBM less per MLP.
+//   ACT 1: v = lut[f16(x)] (GELU / QuickGELU LUT, A18);  ACT 2: v = silu(gate) * up on a fused [M][2 K] gate|up row (A14 + F_TTMUL)
+template <int ACT>
+__global__ __launch_bounds__(256) void quantize_q8k_pack_act_kernel(const float *__restrict__ x, const uint16_t *__restrict__ lut, uint8_t *__restrict__ pack,
+                                                                    int M, int nb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int Mp = (M + 31) & ~31;
+    if (blk >= (int64_t)Mp * nb) return;
+    const int m = (int)(blk / nb), i = (int)(blk % nb);
+    const bool live = m < M;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (live) {
+        if (ACT == 1) {
+            const float4 a = reinterpret_cast<const float4 *>(x + ((int64_t)m * nb + i) * 256)[lane];
+            v = make_float4(h2f(lut[f2h(a.x)]), h2f(lut[f2h(a.y)]), h2f(lut[f2h(a.z)]), h2f(lut[f2h(a.w)]));
+        } else {
+            const int64_t K = (int64_t)nb * 256;
+            const float4 g = reinterpret_cast<const float4 *>(x + (int64_t)m * 2 * K + i * 256)[lane];
+            const float4 u = reinterpret_cast<const float4 *>(x + (int64_t)m * 2 * K + K + i * 256)[lane];
+            v = make_float4(__fmul_rn(silu_ref(g.x), u.x), __fmul_rn(silu_ref(g.y), u.y), __fmul_rn(silu_ref(g.z), u.z), __fmul_rn(silu_ref(g.w), u.w));
+        }
+    }
+    wave_quant_pack(v, lane, live, pack, q4kp_tile_blocks(M, nb), nb, m, i);
+}
+
 // A18: y = f16->f32(lut[f32->f16(x)])  (mllm_vec_gelu_f32 / mllm_vec_gelu_quick_f32, ggml Quantize.hpp:92-131)
 __global__ __launch_bounds__(256) void act_lut_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n, const uint16_t *__restrict__ lut) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = h2f(lut[f2h(x[i])]);
@@ -574,6 +601,22 @@ extern "C" int mllm_hip_quantize_q8k_packed(const float *x, void *xpack, int M, 
     const int64_t blocks = (int64_t)((M + 31) & ~31) * nb;
     hipLaunchKernelGGL(quantize_q8k_pack_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, as_stream(stream), x, (uint8_t *)xpack, M, nb);
     return MH_LAUNCH_OK("quantize_q8k_packed");
+}
+extern "C" int mllm_hip_quantize_q8k_packed_act(const float *x, const uint16_t *lut, void *xpack, int M, int K, void *stream) {
+    if (K % 256 != 0 || M < 0 || !xpack || !lut) return MLLM_HIP_ERR_SHAPE;
+    if (M == 0) return MLLM_HIP_OK;
+    const int nb = K / 256;
+    const int64_t blocks = (int64_t)((M + 31) & ~31) * nb;
+    hipLaunchKernelGGL(quantize_q8k_pack_act_kernel<1>, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, as_stream(stream), x, lut, (uint8_t *)xpack, M, nb);
+    return MH_LAUNCH_OK("quantize_q8k_packed_act");
+}
+extern "C" int mllm_hip_quantize_q8k_packed_silu_mul(const float *gu, void *xpack, int M, int I, void *stream) {
+    if (I % 256 != 0 || M < 0 || !xpack) return MLLM_HIP_ERR_SHAPE;
+    if (M == 0) return MLLM_HIP_OK;
+    const int nb = I / 256;
+    const int64_t blocks = (int64_t)((M + 31) & ~31) * nb;
+    hipLaunchKernelGGL(quantize_q8k_pack_act_kernel<2>, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, as_stream(stream), gu, (const uint16_t *)nullptr, (uint8_t *)xpack, M, nb);
+    return MH_LAUNCH_OK("quantize_q8k_packed_silu_mul");
 }
 extern "C" int mllm_hip_debug_ln_stats(const float *x, float *stats, int M, int dim, float eps, void *stream) {
     hipLaunchKernelGGL(ln_stats_kernel, dim3((M + LN_ROWS - 1) / LN_ROWS), dim3(256), 0, as_stream(stream), x, stats, M, dim, eps);

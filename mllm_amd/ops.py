@@ -235,13 +235,21 @@ def linear_q4k_packed_producers(Wq, x, N, mode="quant", w=None, b=None, eps=1e-6
     Wd = _dev(np.asarray(Wq).view(np.uint8))
     lib_ = L.load()
     lib_.mllm_hip_q4k_prepack_bytes.restype = C.c_size_t
-    wp = torch.empty(lib_.mllm_hip_q4k_prepack_bytes(C.c_int(N), C.c_int(K)), dtype=torch.uint8, device="cuda")
-    xp = torch.empty(lib_.mllm_hip_q4k_prepack_bytes(C.c_int(M), C.c_int(K)), dtype=torch.uint8, device="cuda")
-    check(lib_.mllm_hip_q4k_prepack(vp(Wd), C.c_int(N), C.c_int(K), vp(wp), _stream()), "q4k_prepack")
+    Kw = K // 2 if mode == "silu_mul" else K
+    wp = torch.empty(lib_.mllm_hip_q4k_prepack_bytes(C.c_int(N), C.c_int(Kw)), dtype=torch.uint8, device="cuda")
+    xp = torch.empty(lib_.mllm_hip_q4k_prepack_bytes(C.c_int(M), C.c_int(Kw)), dtype=torch.uint8, device="cuda")
+    check(lib_.mllm_hip_q4k_prepack(vp(Wd), C.c_int(N), C.c_int(Kw), vp(wp), _stream()), "q4k_prepack")
     if mode == "quant":
         check(lib_.mllm_hip_quantize_q8k_packed(vp(x), vp(xp), C.c_int(M), C.c_int(K), _stream()), "quantize_q8k_packed")
     elif mode == "rms":
         check(lib_.mllm_hip_rmsnorm_packed(vp(x), vp(_dev(w, torch.float32)), None, vp(xp), C.c_int(M), C.c_int(K), C.c_float(eps), C.c_int(0), _stream()), "rmsnorm_packed")
+    elif mode in ("gelu", "quickgelu"):
+        lut = _act_luts()[0 if mode == "gelu" else 1]
+        check(lib_.mllm_hip_quantize_q8k_packed_act(vp(x), vp(lut), vp(xp), C.c_int(M), C.c_int(K), _stream()), "quantize_q8k_packed_act")
+    elif mode == "silu_mul":     # x is the fused [M][2 K] gate|up buffer
+        K = K // 2
+        xp = torch.empty(lib_.mllm_hip_q4k_prepack_bytes(C.c_int(M), C.c_int(K)), dtype=torch.uint8, device="cuda")
+        check(lib_.mllm_hip_quantize_q8k_packed_silu_mul(vp(x), vp(xp), C.c_int(M), C.c_int(K), _stream()), "quantize_q8k_packed_silu_mul")
     else:
         wb = _dev(b, torch.float32) if b is not None else None
         check(lib_.mllm_hip_layernorm_packed(vp(x), vp(_dev(w, torch.float32)), vp(wb), None, vp(xp), C.c_int(M), C.c_int(K), C.c_float(eps), _stream()), "layernorm_packed")

@@ -110,6 +110,18 @@ def test_linear_on_packed_producers(M, K, N):
     assert eq(ops.linear_q4k_packed_producers(Wq, x, N, "ln", w=w, b=b), orc.linear(orc.layernorm(x, w, b, 1e-6), Wq, orc.Q4_K, N))
 
 
+@pytest.mark.parametrize("M,K,N", [(64, 512, 96), (282, 1536, 128), (17, 256, 64)])
+def test_linear_on_activation_fused_producers(M, K, N):
+    """The quantiser with GELU / QuickGELU (LUT) or silu(gate)*up folded in feeds the GEMM the same bits as the separate ops."""
+    Wq, x, _ = _q4k_case(M, K, N, 5 * M + K + N, bias=False)
+    x = x * 3
+    assert eq(ops.linear_q4k_packed_producers(Wq, x, N, "gelu"), orc.linear(orc.gelu(x), Wq, orc.Q4_K, N))
+    assert eq(ops.linear_q4k_packed_producers(Wq, x, N, "quickgelu"), orc.linear(orc.quickgelu(x), Wq, orc.Q4_K, N))
+    u = rng(M * K).standard_normal((M, K)).astype(np.float32)
+    gu = np.concatenate([x, u], axis=1)
+    assert eq(ops.linear_q4k_packed_producers(Wq, gu, N, "silu_mul"), orc.linear(orc.silu(x) * u, Wq, orc.Q4_K, N))
+
+
 def test_linear_golden_reference(ops_gold):
     g = ops_gold
     for x, yref in ((g["lin_x5"], g["lin_y5"]), (g["lin_x1"], g["lin_y1"])):
