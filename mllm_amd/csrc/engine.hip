@@ -456,8 +456,8 @@ static int forward_vision(M *m, const int32_t *grid, float *out) {
     for (auto &B : m->vblocks) {
         EH(q_layernorm(m, x, B.n1w, B.n1b, m->xq, N, V, 1e-6f));
         EH(lin(m, B.qkv, m->xq, m->vqkv, MLLM_HIP_F32, 3 * V, nullptr, N));
-        EH(mllm_hip_rope_apply(m->vqkv, 3 * V, m->vsin, m->vcos, VD / 2, m->vqkv, MLLM_HIP_F32, 3 * V, N, c.v_heads, VD, st));
-        EH(mllm_hip_rope_apply(m->vqkv + V, 3 * V, m->vsin, m->vcos, VD / 2, m->vqkv + V, MLLM_HIP_F32, 3 * V, N, c.v_heads, VD, st));
+        // q and k are columns [0, 2V) of the same rows: one launch over 2 * heads heads rotates both in place
+        EH(mllm_hip_rope_apply(m->vqkv, 3 * V, m->vsin, m->vcos, VD / 2, m->vqkv, MLLM_HIP_F32, 3 * V, N, 2 * c.v_heads, VD, st));
         EH(mllm_hip_fa2(m->vqkv, 3 * V, m->vqkv + V, 3 * V, m->vqkv + 2 * V, 3 * V, MLLM_HIP_F32, m->vattn, V, N, N, c.v_heads, c.v_heads, VD, 0,
                         nullptr, nullptr, st));
         EH(q_quant(m, m->vattn, m->xq, N, V));
