@@ -389,6 +389,49 @@ __device__ __forceinline__ void glds16_dec(const void *gsrc, unsigned lds_dst_in
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// One super-block (144 bytes in LDS, disk layout) against block b of the staggered activation image: the 12 (scale, value) table entries of
+// q4k_dot.h -- slots 0..7 = classes [0,4,2,6,1,5,3,7], 8..11 = mins [0,2,1,3] -- written as float2, the type q4k_chain reads (a float4 store
+// would be a different TBAA base and may be moved across the fence).
+__device__ __forceinline__ void blk_emit(const char *blk, const ActLds &a, int b, float2 *e) {
+    const uint4 hdr = *reinterpret_cast<const uint4 *>(blk);
+    const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
+    uint32_t sc8[2], mn8[2];
+    unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
+    const int8_t *xb = a.qs + b * a.qstride;
+    int cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sl = byte_of(sc8, 2 * j), sh = byte_of(sc8, 2 * j + 1);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q0 = *reinterpret_cast<const u32x4 *>(blk + 16 + 32 * j), q1 = *reinterpret_cast<const u32x4 *>(blk + 32 + 32 * j);
+        const i32x4 xl0 = *reinterpret_cast<const i32x4 *>(xb + 64 * j), xl1 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 16);
+        const i32x4 xh0 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 32), xh1 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 48);
+        int lo[8], hi[8], xl[8], xh[8], dl[8], dh[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const unsigned q = t < 4 ? q0[t & 3] : q1[t & 3];
+            lo[t] = (int)(q & 0x0f0f0f0fu); hi[t] = (int)((q >> 4) & 0x0f0f0f0fu);
+            xl[t] = t < 4 ? xl0[t & 3] : xl1[t & 3]; xh[t] = t < 4 ? xh0[t & 3] : xh1[t & 3];
+        }
+        dot4z_x8(dl, lo, xl);
+        dot4z_x8(dh, hi, xh);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cls[t] = __mul24(sh, dh[t]) + (__mul24(sl, dl[t]) + cls[t]);
+    }
+    const int4 s0 = *reinterpret_cast<const int4 *>(a.q8s + b * 8), s1 = *reinterpret_cast<const int4 *>(a.q8s + b * 8 + 4);
+    const int prod0 = __mul24(byte_of(mn8, 0), s0.x) + __mul24(byte_of(mn8, 1), s0.y), prod1 = __mul24(byte_of(mn8, 2), s0.z) + __mul24(byte_of(mn8, 3), s0.w);
+    const int prod2 = __mul24(byte_of(mn8, 4), s1.x) + __mul24(byte_of(mn8, 5), s1.y), prod3 = __mul24(byte_of(mn8, 6), s1.z) + __mul24(byte_of(mn8, 7), s1.w);
+    const float xd = a.d[b];
+    const float dy = xd * d, dm = (-xd) * dmin;      // VecDotQ4.cpp:228-229
+    e[0] = make_float2(dy, (float)cls[0]); e[1] = make_float2(dy, (float)cls[4]);
+    e[2] = make_float2(dy, (float)cls[2]); e[3] = make_float2(dy, (float)cls[6]);
+    e[4] = make_float2(dy, (float)cls[1]); e[5] = make_float2(dy, (float)cls[5]);
+    e[6] = make_float2(dy, (float)cls[3]); e[7] = make_float2(dy, (float)cls[7]);
+    e[8] = make_float2(dm, (float)prod0); e[9] = make_float2(dm, (float)prod2);
+    e[10] = make_float2(dm, (float)prod1); e[11] = make_float2(dm, (float)prod3);
+}
+
 template <int PAIRS, int NV, int WPB>
 __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *__restrict__ x, const float *__restrict__ norm_w, float eps,
                                                                   const uint8_t *__restrict__ W, float *__restrict__ act, int I, int K) {
@@ -448,47 +491,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
     // ---- lane l: super-block (region = gate / up, pair, b) ------------------------------------------------------------------------------------
     const int region = lane >= PAIRS * nb, within = lane - (region ? PAIRS * nb : 0), pair = within / nb, b = within - pair * nb;
     if (live && lane < 2 * PAIRS * nb) {
-        const char *blk = stage + (size_t)region * half + (size_t)within * 144;
-        const uint4 hdr = *reinterpret_cast<const uint4 *>(blk);
-        const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
-        uint32_t sc8[2], mn8[2];
-        unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
-        const int8_t *xb = a.qs + b * GUB_QSTRIDE;
-        int cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int sl = byte_of(sc8, 2 * j), sh = byte_of(sc8, 2 * j + 1);
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 q0 = *reinterpret_cast<const u32x4 *>(blk + 16 + 32 * j), q1 = *reinterpret_cast<const u32x4 *>(blk + 32 + 32 * j);
-            const i32x4 xl0 = *reinterpret_cast<const i32x4 *>(xb + 64 * j), xl1 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 16);
-            const i32x4 xh0 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 32), xh1 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 48);
-            int lo[8], hi[8], xl[8], xh[8], dl[8], dh[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const unsigned q = t < 4 ? q0[t & 3] : q1[t & 3];
-                lo[t] = (int)(q & 0x0f0f0f0fu); hi[t] = (int)((q >> 4) & 0x0f0f0f0fu);
-                xl[t] = t < 4 ? xl0[t & 3] : xl1[t & 3]; xh[t] = t < 4 ? xh0[t & 3] : xh1[t & 3];
-            }
-            dot4z_x8(dl, lo, xl);
-            dot4z_x8(dh, hi, xh);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) cls[t] = __mul24(sh, dh[t]) + (__mul24(sl, dl[t]) + cls[t]);
-        }
-        const int4 s0 = *reinterpret_cast<const int4 *>(a.q8s + b * 8), s1 = *reinterpret_cast<const int4 *>(a.q8s + b * 8 + 4);
-        const int prod0 = __mul24(byte_of(mn8, 0), s0.x) + __mul24(byte_of(mn8, 1), s0.y), prod1 = __mul24(byte_of(mn8, 2), s0.z) + __mul24(byte_of(mn8, 3), s0.w);
-        const int prod2 = __mul24(byte_of(mn8, 4), s1.x) + __mul24(byte_of(mn8, 5), s1.y), prod3 = __mul24(byte_of(mn8, 6), s1.z) + __mul24(byte_of(mn8, 7), s1.w);
-        const float xd = a.d[b];
-        const float dy = xd * d, dm = (-xd) * dmin;      // VecDotQ4.cpp:228-229
-        // table row [2 * pair + region][b][12]: slots 0..7 = classes [0,4,2,6,1,5,3,7], 8..11 = mins [0,2,1,3]   (q4k_dot.h)
-        // (float2 stores, the type q4k_chain reads: a float4 store would be a different TBAA base and may be moved across the fence)
-        float2 *e = tab + ((size_t)(2 * pair + region) * nb + b) * Q4K_SLOTS;
-        e[0] = make_float2(dy, (float)cls[0]); e[1] = make_float2(dy, (float)cls[4]);
-        e[2] = make_float2(dy, (float)cls[2]); e[3] = make_float2(dy, (float)cls[6]);
-        e[4] = make_float2(dy, (float)cls[1]); e[5] = make_float2(dy, (float)cls[5]);
-        e[6] = make_float2(dy, (float)cls[3]); e[7] = make_float2(dy, (float)cls[7]);
-        e[8] = make_float2(dm, (float)prod0); e[9] = make_float2(dm, (float)prod2);
-        e[10] = make_float2(dm, (float)prod1); e[11] = make_float2(dm, (float)prod3);
+        blk_emit(stage + (size_t)region * half + (size_t)within * 144, a, b, tab + ((size_t)(2 * pair + region) * nb + b) * Q4K_SLOTS);
     }
     wave_lds_fence();
 #pragma unroll
@@ -539,6 +542,65 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const float *__restr
             const int rw = wave * ROWS + rr;
             if (rw < N) y[rw] = residual ? out[rr] + residual[rw] : out[rr];
         }
+    }
+}
+
+// dec_proj_blk: the down projection with one lane per super-block (blk_emit), a workgroup per RPW consecutive rows.  The rows (one
+// contiguous run of RPW * K/256 super-blocks, disk layout) go to LDS by LDS-DMA, issued once the activation row has arrived and
+// running underneath its quantisation; lane g of the workgroup owns super-block g of the run; RPW / 4 waves walk the chains.
+__host__ __device__ static inline size_t pjb_stage_bytes(int rpw, int nb) { return ((size_t)rpw * nb * 144 + 1023) & ~(size_t)1023; }
+static inline size_t pjb_lds_bytes(int K, int rpw) {
+    return ((gub_act_bytes(K) + 15) & ~(size_t)15) + pjb_stage_bytes(rpw, K / 256) + (size_t)rpw * (K / 256) * Q4K_SLOTS * 8;
+}
+template <int RPW, int WPB, int NQ>
+__global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__restrict__ xin, const uint8_t *__restrict__ W, const float *__restrict__ residual,
+                                                                float *__restrict__ y, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nb = K >> 8;
+    ActLds a;
+    a.qs = reinterpret_cast<int8_t *>(smem);
+    a.d = reinterpret_cast<float *>(smem + (size_t)nb * GUB_QSTRIDE);
+    a.q8s = reinterpret_cast<int *>(smem + (size_t)nb * GUB_QSTRIDE + ((nb * 4 + 15) & ~15));
+    a.xf = nullptr;
+    a.qstride = GUB_QSTRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = min((int)blockIdx.x * RPW, N - RPW);     // the last workgroup re-does rows of its neighbour (same values)
+    char *stage = smem + ((gub_act_bytes(K) + 15) & ~(size_t)15);
+    float2 *tab = reinterpret_cast<float2 *>(stage + pjb_stage_bytes(RPW, nb));
+    float4 v[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int blk = wid + WPB * i;
+        v[i] = *reinterpret_cast<const float4 *>(xin + (blk < nb ? blk : 0) * 256 + lane * 4);
+    }
+    // all NQ loads in flight together, then (the activation row being the dependent fetch) the weight stream behind it
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+    {
+        const int run = RPW * nb * 144;
+        const uint8_t *src = W + (int64_t)row0 * nb * 144;
+        const unsigned st0 = (unsigned)(size_t)stage;
+        for (int o = wid * 1024; o < run; o += WPB * 1024) {
+            const int off = o + lane * 16;
+            glds16_dec(src + (off < run ? off : 0), st0 + (unsigned)o);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) if (wid + WPB * i >= nb) v[i] = make_float4(0, 0, 0, 0);
+    wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < RPW * nb) {
+        const int row = tid / nb, b = tid - row * nb;
+        blk_emit(stage + (size_t)tid * 144, a, b, tab + (size_t)tid * Q4K_SLOTS);
+    }
+    __syncthreads();
+    if (4 * wid < RPW) {
+        const int nr = RPW - 4 * wid < 4 ? RPW - 4 * wid : 4;
+        const float res = q4k_chain(tab + (size_t)4 * wid * nb * Q4K_SLOTS, nb, nb, nr, lane);
+        const int rw = row0 + 4 * wid + (lane >> 4);
+        if ((lane & 15) == 8 && (lane >> 4) < nr) y[rw] = residual ? res + residual[rw] : res;
     }
 }
 
@@ -829,7 +891,7 @@ static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *
     return MH_LAUNCH_OK("dec_gateup");
 }
 template <int NS>
-static int launch_proj(const uint8_t *W, const float *xin, const float *residual, float *y, int N, int K, hipStream_t st) {
+static int launch_proj(const uint8_t *W, const uint8_t *Wraw, const float *xin, const float *residual, float *y, int N, int K, hipStream_t st) {
 #ifndef PJ_ROWS1
 #define PJ_ROWS1 2
 #endif
@@ -842,6 +904,19 @@ static int launch_proj(const uint8_t *W, const float *xin, const float *residual
 #ifndef PJ_WPB1
 #define PJ_WPB1 8
 #endif
+#ifndef PJB_RPW
+#define PJB_RPW 6
+#endif
+    static const bool pjb_off = getenv("MLLM_HIP_NO_PJB") != nullptr;
+    if (NS == 5 && Wraw && !pjb_off && N >= PJB_RPW && PJB_RPW * (K >> 8) <= 512) {
+        constexpr int RPW = PJB_RPW, BW = 8, NQ = 5;
+        const size_t blds = pjb_lds_bytes(K, RPW);
+        auto bk = dec_proj_blk_kernel<RPW, BW, NQ>;
+        int brc = allow_lds(bk, blds);
+        if (brc) return brc;
+        hipLaunchKernelGGL(bk, dim3((N + RPW - 1) / RPW), dim3(64 * BW), blds, st, xin, Wraw, residual, y, N, K);
+        return MH_LAUNCH_OK("dec_proj_blk");
+    }
     constexpr int ROWS = NS == 1 ? PJ_ROWS1 : PJ_ROWS5, WPB = NS >= 3 ? PJ_WPB5 : PJ_WPB1;   // long rows: 1024-thread workgroups share the row quantisation
     const int waves = (N + ROWS - 1) / ROWS;
     const size_t lds = fused_lds_bytes<NS, ROWS>(K, false, WPB);
@@ -901,13 +976,13 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         return MH_LAUNCH_OK("dec_attn");
     }
     case 2:
-        NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS>(L.Wo, c.fa_ws, x, t, c.H, c.heads * c.D, st)));
+        NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS>(L.Wo, nullptr, c.fa_ws, x, t, c.H, c.heads * c.D, st)));
         return rc;
     case 3:
         NS_DISPATCH(c.H, rc = launch_gateup<NS>(L, c, t, st));
         return rc;
     case 4:
-        NS_DISPATCH(c.I, rc = (launch_proj<NS>(L.Wdown, c.act, t, x, c.H, c.I, st)));
+        NS_DISPATCH(c.I, rc = (launch_proj<NS>(L.Wdown, L.Wdown_raw, c.act, t, x, c.H, c.I, st)));
         return rc;
     }
     return MLLM_HIP_ERR_ARG;
