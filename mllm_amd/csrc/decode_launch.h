@@ -17,7 +17,7 @@ struct DecodeLayer {
     const float *in_norm, *post_norm;
     const uint8_t *Wqkv; const float *bqkv; int qkv_N;
     const uint8_t *Wo, *Wgu, *Wdown;          // all four in decode order (decode_order_q4k)
-    const uint8_t *Wgu_raw, *Wdown_raw;       // the rows as stored on disk (the one-lane-per-super-block kernels dec_gateup_blk / dec_proj_blk)
+    const uint8_t *Wgu_raw, *Wdown_raw, *Wo_raw;       // the rows as stored on disk (the one-lane-per-super-block kernels dec_gateup_blk / dec_proj_blk)
 };
 
 struct DecodeCtx {

@@ -322,7 +322,7 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
             DecodeLayer dl;
             dl.in_norm = L.in_norm; dl.post_norm = L.post_norm; dl.Wqkv = (const uint8_t *)L.qkv.wd; dl.bqkv = L.qkv.bias; dl.qkv_N = L.qkv.N;
             dl.Wo = (const uint8_t *)L.o.wd; dl.Wgu = (const uint8_t *)L.gu.wd; dl.Wdown = (const uint8_t *)L.down.wd;
-            dl.Wgu_raw = (const uint8_t *)L.gu.w; dl.Wdown_raw = (const uint8_t *)L.down.w;
+            dl.Wgu_raw = (const uint8_t *)L.gu.w; dl.Wdown_raw = (const uint8_t *)L.down.w; dl.Wo_raw = (const uint8_t *)L.o.w;
             m->dlayers.push_back(dl);
         }
         m->use_graph = getenv("MLLM_HIP_NO_GRAPH") == nullptr;

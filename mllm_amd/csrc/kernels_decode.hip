@@ -18,6 +18,7 @@
 // hipGraph replays every step.  Weight loads are issued BEFORE the prologue so the HBM latency of the first rows overlaps
 // the prologue's arithmetic (vmcnt counts in issue order: the prologue's own small loads are issued first).
 #include <cmath>
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -552,9 +553,9 @@ __host__ __device__ static inline size_t pjb_stage_bytes(int rpw, int nb) { retu
 static inline size_t pjb_lds_bytes(int K, int rpw) {
     return ((gub_act_bytes(K) + 15) & ~(size_t)15) + pjb_stage_bytes(rpw, K / 256) + (size_t)rpw * (K / 256) * Q4K_SLOTS * 8;
 }
-template <int RPW, int WPB, int NQ>
+template <int WPB, int NQ>
 __global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__restrict__ xin, const uint8_t *__restrict__ W, const float *__restrict__ residual,
-                                                                float *__restrict__ y, int N, int K) {
+                                                                float *__restrict__ y, int N, int K, int RPW) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nb = K >> 8;
     ActLds a;
@@ -904,18 +905,21 @@ static int launch_proj(const uint8_t *W, const uint8_t *Wraw, const float *xin, 
 #ifndef PJ_WPB1
 #define PJ_WPB1 8
 #endif
-#ifndef PJB_RPW
-#define PJB_RPW 6
-#endif
+    // one lane per super-block: rows per workgroup chosen for one workgroup per CU (256) within the 512 lanes of a workgroup
     static const bool pjb_off = getenv("MLLM_HIP_NO_PJB") != nullptr;
-    if (NS == 5 && Wraw && !pjb_off && N >= PJB_RPW && PJB_RPW * (K >> 8) <= 512) {
-        constexpr int RPW = PJB_RPW, BW = 8, NQ = 5;
-        const size_t blds = pjb_lds_bytes(K, RPW);
-        auto bk = dec_proj_blk_kernel<RPW, BW, NQ>;
-        int brc = allow_lds(bk, blds);
-        if (brc) return brc;
-        hipLaunchKernelGGL(bk, dim3((N + RPW - 1) / RPW), dim3(64 * BW), blds, st, xin, Wraw, residual, y, N, K);
-        return MH_LAUNCH_OK("dec_proj_blk");
+    static const int pjb_min_ns = getenv("MLLM_HIP_PJB_MIN_NS") ? atoi(getenv("MLLM_HIP_PJB_MIN_NS")) : 3;   // short rows: the 8-lane kernel is faster
+    {
+        const int nb = K >> 8;
+        const int rpw = std::max(1, std::min(512 / nb, (N + 255) / 256));
+        if (NS >= pjb_min_ns && NS <= 5 && Wraw && !pjb_off && N >= rpw) {
+            constexpr int BW = 8, NQ = NS;
+            const size_t blds = pjb_lds_bytes(K, rpw);
+            auto bk = dec_proj_blk_kernel<BW, NQ>;
+            int brc = allow_lds(bk, blds);
+            if (brc) return brc;
+            hipLaunchKernelGGL(bk, dim3((N + rpw - 1) / rpw), dim3(64 * BW), blds, st, xin, Wraw, residual, y, N, K, rpw);
+            return MH_LAUNCH_OK("dec_proj_blk");
+        }
     }
     constexpr int ROWS = NS == 1 ? PJ_ROWS1 : PJ_ROWS5, WPB = NS >= 3 ? PJ_WPB5 : PJ_WPB1;   // long rows: 1024-thread workgroups share the row quantisation
     const int waves = (N + ROWS - 1) / ROWS;
@@ -976,7 +980,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         return MH_LAUNCH_OK("dec_attn");
     }
     case 2:
-        NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS>(L.Wo, nullptr, c.fa_ws, x, t, c.H, c.heads * c.D, st)));
+        NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS>(L.Wo, L.Wo_raw, c.fa_ws, x, t, c.H, c.heads * c.D, st)));
         return rc;
     case 3:
         NS_DISPATCH(c.H, rc = launch_gateup<NS>(L, c, t, st));
