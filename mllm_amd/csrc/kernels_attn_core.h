@@ -190,6 +190,9 @@ __device__ __forceinline__ void fa2_decode_prefetch(DecodePrefetch<D, F16, NT, V
     (void)V; (void)ldv;   // the V chunks are requested once Sk is known (fa2_decode_head): they are not needed before phase C
 }
 
+// ring slot of chunk ch: the usual 4-slot ring needs no division
+__device__ __forceinline__ int fa_slot(int ch, int nslots) { return nslots == 4 ? (ch & 3) : ch % nslots; }
+
 template <int D, bool F16, int NT, bool VT = false>
 __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefetch<D, F16, NT, VT> &P, const void *K, int64_t ldk, const void *V,
                                                 int64_t ldv, int kvoff, int Sk, int cap, const uint16_t *knew, const uint16_t *vnew, int tnew) {
@@ -203,7 +206,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
     const int nch = (nkv + FA_VCH - 1) / FA_VCH;
     const int npre = min(nch, L.nslots);
     auto park_chunk = [&](int ch, const uint4 (&src)[VPT]) {
-        char *slot = L.vring + (size_t)(ch % L.nslots) * SLOT;
+        char *slot = L.vring + (size_t)fa_slot(ch, L.nslots) * SLOT;
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int vi = tid + NT * i, row = vi / ROWV, part = vi % ROWV;
@@ -337,7 +340,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
         if (walker && VT) {
             // transposed ring, 16 keys per step, LDS reads issued TWO steps ahead of the fma chain that consumes them (a three-stage register
             // ring: raw fp16 pairs + the 16 p's + the mask), so the dependent chain never waits on LDS latency
-            const char *row = L.vring + (size_t)(ch % L.nslots) * SLOT + (size_t)tid * FA_VPITCH;
+            const char *row = L.vring + (size_t)fa_slot(ch, L.nslots) * SLOT + (size_t)tid * FA_VPITCH;
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             struct Stage { u32x4 v0, v1; f32x4 p[4]; };
@@ -389,7 +392,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
             }
         } else if (walker) {
             // 16 keys per step, the next step's LDS reads issued before this step's fma chain
-            const char *slot = L.vring + (size_t)(ch % L.nslots) * SLOT;
+            const char *slot = L.vring + (size_t)fa_slot(ch, L.nslots) * SLOT;
             float va[16], vb[16];
             float4 pa[4], pb[4];
             int ma, mb;

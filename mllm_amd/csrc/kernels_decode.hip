@@ -45,26 +45,26 @@ constexpr bool g_nt = MLLM_HIP_NT != 0;
 __device__ unsigned long long g_stamps[8192 * 8];
 #define STAMP(i)                                                                                         \
     do {                                                                                                 \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                     \
+        if (threadIdx.x == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) {                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
+            g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
 #define STAMPCLK(i)                                                                                      \
     do {                                                                                                 \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                     \
+        if (threadIdx.x == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) {                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();                               \
+            g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memtime();                               \
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
-#define STAMPV(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = (v); } while (0)
+#define STAMPV(i, v) do { if (threadIdx.x == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = (v); } while (0)
 #define STAMPT(i, t)                                                                                     \
     do {                                                                                                 \
-        if (threadIdx.x == (t) && blockIdx.x < 8192) {                                                   \
+        if (threadIdx.x == (t) && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) {                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
+            g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
@@ -622,7 +622,8 @@ __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState
     __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
     const DecodeLds L = carve_decode(smem, cache_limit, D, DEC_ATTN_NT, nslots);
     const int tid = threadIdx.x;
-    const int head = blockIdx.x, gsize = Hq / Hkv, kvh = head / gsize;
+    // grid = (Hq / Hkv, Hkv): no run-time division on the way to the first loads
+    const int gsize = gridDim.x, kvh = blockIdx.y, head = kvh * gsize + blockIdx.x;
     const int HD = Hq * D, KVD = Hkv * D;
     // the step's own small operands first (vmcnt retires in issue order), then -- speculatively, T only masks them afterwards -- the
     // slab rows of the first pass
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState
         vnew[tid - D] = f2h(qa);
     }
     __syncthreads();
-    if (head % gsize == 0 && tid < D) {
+    if (blockIdx.x == 0 && tid < D) {
         kslab[(int64_t)T * KVD + kvh * D + tid] = knew[tid];
         vslab[(int64_t)(kvh * D + tid) * vt_ld + T] = vnew[tid];
     }
@@ -975,7 +976,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
         rc = allow_lds(dec_attn_kernel<128>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((dec_attn_kernel<128>), dim3(c.heads), dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads,
+        hipLaunchKernelGGL((dec_attn_kernel<128>), dim3(c.heads / c.kv_heads, c.kv_heads), dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads,
                            c.kv_heads, c.cache_limit, c.vt_ld, nslots);
         return MH_LAUNCH_OK("dec_attn");
     }
