@@ -233,12 +233,18 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst_in) {
     const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);   // wave-uniform by construction; M0 wants an SGPR
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the same with a wave-uniform source base (SGPR pair) and a 32-bit per-lane offset: no 64-bit vector address arithmetic
+__device__ __forceinline__ void glds16s(const void *sbase, unsigned voff, unsigned lds_dst_in) {
+    unsigned keep;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 template <int MTW>
 __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__restrict__ Wp, const uint8_t *__restrict__ Xp, const float *__restrict__ bias,
                                                          void *__restrict__ y, int y_f16, int64_t ldy, const float *__restrict__ residual, int M, int N,
                                                          int nb) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the DMA bookkeeping below stays scalar
     const int col = lane & 31, h = lane >> 5;
     const int MT = (M + 31) / 32, NT = (N + 31) / 32;
     constexpr int NW = 4 * MTW, FPW = (8 * MTW + 16) / NW;    // waves; operand fragments copied per wave and half-step
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
             else if (c < 8 * MTW) { base = Xp; off = (size_t)mts1 * nb; }
             else if (c < 8 * MTW + 8) off = (size_t)nts0 * nb;
             else off = (size_t)nts1 * nb;
-            glds16(base + (off + i) * Q4KP_W_PER_BLK + (size_t)(8 * hb + f) * 1024 + lane * 16, slot + (unsigned)c * 1024u);
+            glds16s(base + (off + i) * Q4KP_W_PER_BLK + (size_t)(8 * hb + f) * 1024, (unsigned)lane * 16u, slot + (unsigned)c * 1024u);
         }
         const uint8_t *src = Xp + lane * 16;
         unsigned dst = ring0 + (unsigned)GQ_LDS;   // scratch tail
