@@ -33,6 +33,9 @@ namespace mllm_hip {
 #ifndef MLLM_HIP_GUB
 #define MLLM_HIP_GUB 1
 #endif
+#ifndef MLLM_HIP_EARLY_ROWS
+#define MLLM_HIP_EARLY_ROWS 1
+#endif
 #ifndef MLLM_HIP_GUB_DMA_FIRST
 #define MLLM_HIP_GUB_DMA_FIRST 1
 #endif
@@ -305,8 +308,11 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
     if (EMBED) load_row<NV, WPB>(wv, norm_w, K);
     else load_rows2<NV, WPB>(xv, wv, x, norm_w, K);
     __builtin_amdgcn_sched_barrier(0);
+#if MLLM_HIP_EARLY_ROWS
+    if (NSTEPS == 1) { issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane); __builtin_amdgcn_sched_barrier(0); }
+#endif
     wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
-    issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);   // after the prologue: see dec_gateup_kernel
+    if (!(MLLM_HIP_EARLY_ROWS && NSTEPS == 1)) issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);   // long rows after the prologue: see dec_gateup_kernel
     __builtin_amdgcn_sched_barrier(0);
     float out[ROWS];
     dot_rows<NSTEPS, ROWS>(L, a, nb, lane, wave_tab<NSTEPS, ROWS>(smem, K, false, threadIdx.x >> 6), out);
@@ -530,8 +536,13 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const float *__restr
         v[i] = blk < nb ? *reinterpret_cast<const float4 *>(xin + blk * 256 + lane * 4) : make_float4(0, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+#if MLLM_HIP_EARLY_ROWS
+    // short rows (o-proj: 1.3 MB of weights in all): the rows go out right behind the activation loads and fly underneath the
+    // quantisation -- the burst is too small to hold the activation row up, unlike the 15 MB of gate|up
+    if (NSTEPS == 1) { issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane); __builtin_amdgcn_sched_barrier(0); }
+#endif
     wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
-    issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+    if (!(MLLM_HIP_EARLY_ROWS && NSTEPS == 1)) issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
     __syncthreads();
     STAMP(5);
     float out[ROWS];
