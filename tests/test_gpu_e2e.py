@@ -110,6 +110,27 @@ def test_long_context_crosses_the_score_pass_and_ring_boundaries(tmp_path):
         m.close()
 
 
+def test_large_cache_limit_uses_a_three_slot_ring(tmp_path):
+    """cache_limit 4096: the score / mask arrays take 36 KB of LDS and the V ring drops to three slots (modulo slot index, refills from the
+    first chunk on) -- prefill + decode steps of the toy model against the oracle's composition."""
+    from oracle import models as omodels
+    cfg = synth.qwen2vl_tiny()
+    path = weights.qwen2vl_file(cfg, cache_dir=str(tmp_path))
+    m = lib.Qwen2VL(cfg, path, cache_limit=4096)
+    try:
+        ids = (np.arange(530, dtype=np.int64) * 104729 % 2000).astype(np.int32)
+        ref = omodels.LLM(omodels.Weights(path), cfg)
+        want = ref.prefill(ids)
+        tok, logits, _ = m.prefill(ids)
+        assert np.array_equal(logits, want), float(np.abs(logits - want).max())
+        for _ in range(3):
+            want = ref.decode(tok)
+            tok, logits, _ = m.decode(tok)
+            assert np.array_equal(logits, want), float(np.abs(logits - want).max())
+    finally:
+        m.close()
+
+
 def test_mid_shape_engine_matches_oracle_composition(tmp_path):
     """hidden 512 / inter 1280: two super-blocks per row and an intermediate size divisible by 5, i.e. the one-lane-per-super-block
     gate|up kernel (dec_gateup_blk) on a shape other than the 2B model's (the tiny golden config falls back to the 8-lane kernel)."""
