@@ -74,9 +74,15 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
     expf_tab_store(etab, expf_tab_fetch());
     int klim = sk_eff;
     if (causal) klim = min(sk_eff, r0 + FA_R + delta + 4);   // tiles beyond are skipped for every row of this workgroup
-    v16f_t oacc;
+    // P V on v_mfma_f32_16x16x4_f32 -- like the 32x32x2 form an exact fp32 fma chain in k order (scratch/mfma/test16.hip: 0 of 256 outputs differ
+    // from sequential fmaf), but four keys per instruction and 40 instead of 2 x 64 cycles of dependent latency per key tile.  The 32 x D
+    // output is 2 * D/16 tiles (row half rh, dim tile dt), tile id = rh + 2 dt, wave w owns ids w, w + 4, ...: independent chains that interleave.
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    constexpr int ND16 = D / 16, NT16 = 2 * ND16, TPW = (NT16 + 3) / 4;
+    const int c16 = lane & 15, q4 = lane >> 4;
+    v4f_t oacc[TPW];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) oacc[i] = 0.0f;
+    for (int j = 0; j < TPW; ++j) oacc[j] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
     // staging registers (the next chunk is requested while the current one is consumed): four consecutive values per request --
     // four dims of a key row, or four keys of a dim row of the transposed V slab
     constexpr int KG = (FA_KCH * D / 4 + 255) / 256;     // 4-element groups per thread and operand
@@ -203,30 +209,37 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
             for (int t = 0; t < 8; ++t) l = __fmaf_rn(l, Cc[lane * 8 + t], Sm[lane * 8 + t]);
             l_s[lane] = l;
         }
-        if (wid < NDT) {
-            const int dd = 32 * wid + col;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (moved_any[t]) {
+        for (int t = 0; t < 8; ++t) {
+            if (moved_any[t]) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) oacc[i] = oacc[i] * Cc[((i & 3) + 8 * (i >> 2) + 4 * h) * 8 + t];
+                for (int j = 0; j < TPW; ++j) {
+                    const int rh = min(wid + 4 * j, NT16 - 1) & 1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) oacc[j][i] = oacc[j][i] * Cc[(16 * rh + 4 * q4 + i) * 8 + t];
                 }
+            }
 #pragma unroll
-                for (int kp = 0; kp < 2; ++kp) {
-                    const int key = 4 * t + 2 * kp + h;
-                    const float vb = dd < D ? (VT ? Vs[dd * 33 + key] : Vs[key * D + dd]) : 0.0f;
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(P[col * 33 + key], vb, oacc, 0, 0, 0);
-                }
+            for (int j = 0; j < TPW; ++j) {
+                // a wave whose last tile id is past the end repeats the last tile (its result is not stored): no control flow around the MFMAs,
+                // which would make the compiler shuttle every accumulator through AGPR copies at each branch
+                const int tile = min(wid + 4 * j, NT16 - 1), rh = tile & 1, dt = tile >> 1;
+                const int key = 4 * t + q4, dd = 16 * dt + c16;
+                const float vb = VT ? Vs[dd * 33 + key] : Vs[key * D + dd];
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[(16 * rh + c16) * 33 + key], vb, oacc[j], 0, 0, 0);
             }
         }
     }
     __syncthreads();
-    if (wid < NDT) {
-        const int dd = 32 * wid + col;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (r0 + row < Sq && dd < D) O[(int64_t)(r0 + row) * ldo + head * D + dd] = oacc[i] * (1.0f / l_s[row]);
+    for (int j = 0; j < TPW; ++j) {
+        const int tile = wid + 4 * j, rh = tile & 1, dt = tile >> 1;
+        if (tile < NT16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * rh + 4 * q4 + i;
+                if (r0 + row < Sq) O[(int64_t)(r0 + row) * ldo + head * D + 16 * dt + c16] = oacc[j][i] * (1.0f / l_s[row]);
+            }
         }
     }
 }
