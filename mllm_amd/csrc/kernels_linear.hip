@@ -9,6 +9,7 @@
 //     sub-block scales can be applied to exact int32 partial sums; the `mins` term is a second MFMA whose B operand
 //     is the broadcast 6-bit min (sum_e q8[e]*min_{sb(e)} == sum_j bsums[j]*min_{j/2}, VecDotQ4.cpp:318).
 //   fp32 weights (patch-embed conv, fp32 models): f32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 fma chain).
+#include <type_traits>
 #include "common.h"
 #include "q4k_dot.h"
 #include "q40_dot.h"
@@ -254,41 +255,79 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
     const size_t tbw = q4kp_tile_blocks(N, nb), tbx = q4kp_tile_blocks(M, nb);
     // DMA sources (tiles clamped: a workgroup at the edge copies a valid tile twice and does not use the copy)
     const int mts0 = min((int)blockIdx.y * MTW, MT - 1), mts1 = min((int)blockIdx.y * MTW + MTW - 1, MT - 1);
+#if defined(GQ_DBG_SAME)   // diagnosis build: every workgroup streams tile 0 (operand traffic served by L2 hits only; results are wrong)
+    const int nts0 = 0, nts1 = 0;
+#else
     const int nts0 = min((int)blockIdx.x * 2, NT - 1), nts1 = min((int)blockIdx.x * 2 + 1, NT - 1);
+#endif
     const uint8_t *XpM = Xp + tbx * Q4KP_W_PER_BLK, *XpD = Xp + tbx * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK);
     const uint8_t *WpM = Wp + tbw * Q4KP_W_PER_BLK, *WpD = Wp + tbw * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK);
     const unsigned ring0 = (unsigned)(size_t)ring;   // LDS byte address of the ring
-    // FPW + 1 DMA instructions per wave and half-step: FPW of the operand fragments + 1 aux (or a dummy into the scratch tail, so the count is uniform)
-    auto issue = [&](int hstep) __attribute__((always_inline)) {
-        const int i = hstep >> 1, hb = hstep & 1;
-        const unsigned slot = ring0 + (unsigned)((hstep & (GQ_SLOTS - 1)) * GQ_SLOT);
+    // FPW + 1 DMA instructions per wave and half-step: FPW of the operand fragments + 1 aux (or a dummy into the scratch tail, so the count is
+    // uniform).  A lone wave issues about one instruction per 4-8 cycles whatever its kind, so everything about the stream is set up once:
+    // fragment q of this wave always comes from sb[q] + 8192 * hstep + 16 * lane and lands at slot + 1024 * (q NW + wid); the aux sources are
+    // per-lane pointers that advance by a per-lane stride per block.  One asm block per half-step (M0 saved and restored once).
+    const uint8_t *sb[FPW];
 #pragma unroll
-        for (int q = 0; q < FPW; ++q) {
-            const int c = q * NW + wid, f = c & 7;              // fragment c of the slot: [A tiles: 8 MTW][B tiles: 16]
-            size_t off;                                         // byte offset of the (tile, block) record inside its operand buffer
-            const uint8_t *base = Wp;
-            if (c < 8) { base = Xp; off = (size_t)mts0 * nb; }
-            else if (c < 8 * MTW) { base = Xp; off = (size_t)mts1 * nb; }
-            else if (c < 8 * MTW + 8) off = (size_t)nts0 * nb;
-            else off = (size_t)nts1 * nb;
-            glds16s(base + (off + i) * Q4KP_W_PER_BLK + (size_t)(8 * hb + f) * 1024, (unsigned)lane * 16u, slot + (unsigned)c * 1024u);
+    for (int q = 0; q < FPW; ++q) {
+        const int c = q * NW + wid, f = c & 7;                  // fragment c of the slot: [A tiles: 8 MTW][B tiles: 16]
+        size_t off;                                             // the (tile, block 0) record inside its operand buffer
+        const uint8_t *base = Wp;
+        if (c < 8) { base = Xp; off = (size_t)mts0 * nb; }
+        else if (c < 8 * MTW) { base = Xp; off = (size_t)mts1 * nb; }
+        else if (c < 8 * MTW + 8) off = (size_t)nts0 * nb;
+        else off = (size_t)nts1 * nb;
+        const uint8_t *ptr = base + off * Q4KP_W_PER_BLK + (size_t)f * 1024;
+        const uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)ptr), phi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)ptr >> 32));
+        sb[q] = reinterpret_cast<const uint8_t *>(((uint64_t)phi << 32) | (uint64_t)plo);   // (readfirstlane returns int: no sign extension into the high half)
+    }
+    // aux of an even half (scales): wave 0, lanes < 48; of an odd half (mins operands): waves 0..3.  Everyone else copies 16 dummy bytes.
+    const uint8_t *pe = Xp + lane * 16, *po = Xp + lane * 16;
+    unsigned se = 0, so = 0;
+    if (wid == 0 && lane < 48) {
+        pe = lane < 8    ? XpD + (size_t)mts0 * nb * 128 + lane * 16
+             : lane < 16 ? XpD + (size_t)mts1 * nb * 128 + (lane - 8) * 16
+             : lane < 32 ? WpD + (size_t)nts0 * nb * 256 + (lane - 16) * 16
+                         : WpD + (size_t)nts1 * nb * 256 + (lane - 32) * 16;
+        se = lane < 16 ? 128u : 256u;
+    }
+    if (wid < 4) {
+        const int tsel = wid == 0 ? mts0 : (wid == 1 ? mts1 : (wid == 2 ? nts0 : nts1));
+        po = (wid < 2 ? XpM : WpM) + (size_t)tsel * nb * 1024 + lane * 16;
+        so = 1024u;
+    }
+    const unsigned scratch = ring0 + (unsigned)GQ_LDS;
+    const unsigned dst_e = wid == 0 ? 32768u : 0xffffffffu, dst_o = wid < 4 ? 32768u + (unsigned)wid * 1024u : 0xffffffffu;   // relative to the slot; ~0 = scratch
+    unsigned voff = (unsigned)lane * 16u;     // + 8192 per half-step issued
+    unsigned islot = ring0;                   // LDS address of the slot the next issue fills
+    auto issue = [&](int hb) __attribute__((always_inline)) {
+        const unsigned d0 = __builtin_amdgcn_readfirstlane(islot + (unsigned)wid * 1024u);
+        const unsigned rel = hb == 0 ? dst_e : dst_o;
+        const unsigned da = __builtin_amdgcn_readfirstlane(rel == 0xffffffffu ? scratch : islot + rel);
+        const uint8_t *pa = hb == 0 ? pe : po;
+        unsigned keep;
+        if constexpr (FPW == 4) {
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
+                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(d0), "s"(sb[0]), "s"(sb[1]), "s"(sb[2]), "s"(sb[3]), "s"(da), "v"(pa) : "memory", "scc");
+        } else {
+            static_assert(FPW == 6 || FPW == 4, "");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
+                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
+                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %8\n\t"
+                         "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(d0), "s"(sb[0]), "s"(sb[1]), "s"(sb[2]), "s"(sb[3]), "s"(sb[FPW - 2]), "s"(sb[FPW - 1]), "s"(da), "v"(pa)
+                         : "memory", "scc");
         }
-        const uint8_t *src = Xp + lane * 16;
-        unsigned dst = ring0 + (unsigned)GQ_LDS;   // scratch tail
-        if (hb == 0) {
-            if (wid == 0 && lane < 48) {
-                src = lane < 8    ? XpD + ((size_t)mts0 * nb + i) * 128 + lane * 16
-                      : lane < 16 ? XpD + ((size_t)mts1 * nb + i) * 128 + (lane - 8) * 16
-                      : lane < 32 ? WpD + ((size_t)nts0 * nb + i) * 256 + (lane - 16) * 16
-                                  : WpD + ((size_t)nts1 * nb + i) * 256 + (lane - 32) * 16;
-            }
-            if (wid == 0) dst = slot + 32768u;
-        } else if (wid < 4) {
-            const int tsel = wid == 0 ? mts0 : (wid == 1 ? mts1 : (wid == 2 ? nts0 : nts1));
-            src = (wid < 2 ? XpM : WpM) + ((size_t)tsel * nb + i) * 1024 + lane * 16;
-            dst = slot + 32768u + (unsigned)wid * 1024u;
-        }
-        glds16(src, dst);   // (even half, wave 0: lanes >= 48 drop 16 dummy bytes into the unused part of the aux area)
+        voff += 8192u;
+        islot = islot + (unsigned)GQ_SLOT == ring0 + (unsigned)GQ_LDS ? ring0 : islot + (unsigned)GQ_SLOT;
+        if (hb == 0) pe += se; else po += so;
     };
     v16f acc[4], accm[2];
 #pragma unroll
@@ -307,92 +346,172 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int TS = 2 * nb;
     issue(0);
-    if (TS > 1) issue(1);
-    if (TS > 2) issue(2);
+    issue(1);                 // TS >= 2 always (nb >= 1)
+    if (TS > 2) issue(0);
+    // Software pipeline over the half-steps: a half-step requests its LDS operands, then *retires the previous half-step's class sums*
+    // (the VALU chain step acc = fma(dd, c, acc), which covers the LDS latency), then issues its own MFMAs, whose results are
+    // read one barrier later -- no wave waits on an MFMA it has just issued.  dd starts at 0 so the first retire is fma(0, 0, 0).
     float dd[16], dm[16];
-#pragma unroll 1
-    for (int i = 0; i < nb; ++i) {
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            const int hstep = 2 * i + hb;
-            // this wave's DMA of `hstep` has landed when at most the (up to two) younger half-steps are outstanding: FPW + 1 per half-step
-            if (hstep + 2 < TS) { if (MTW == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
-            else if (hstep + 1 < TS) { if (MTW == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();      // everyone's part of the slot has landed; everyone is done with slot hstep-1
-            asm volatile("" ::: "memory");
-            if (hstep + 3 < TS) issue(hstep + 3);
-            if (active) {
-                const char *slot = ring + (size_t)(hstep & (GQ_SLOTS - 1)) * GQ_SLOT;
-                // this wave's 4 + 4 fragments: classes 2ch, 2ch+1 of the half
-                const v8h *A = reinterpret_cast<const v8h *>(slot + mw * 8192 + ch * 4096) + lane, *B = reinterpret_cast<const v8h *>(slot + MTW * 8192 + nw * 8192 + ch * 4096) + lane;
-                const char *aux = slot + 32768;
-                if (hb == 0) {
-                    const f32x2 dwv = *reinterpret_cast<const f32x2 *>(aux + 256 + nw * 256 + col * 8);
+    for (int r = 0; r < 16; ++r) dd[r] = dm[r] = 0.0f;
+    v16f cp0 = zero, cp1 = zero;
+    // per-lane LDS read addresses inside slot 0; the compute slot's offset cycles through the ring
+    const unsigned lA = ring0 + (unsigned)(mw * 8192 + ch * 4096 + lane * 16), lB = ring0 + (unsigned)(MTW * 8192 + nw * 8192 + ch * 4096 + lane * 16);
+    const unsigned lW = ring0 + (unsigned)(32768 + 256 + nw * 256 + col * 8), lX = ring0 + (unsigned)(32768 + mw * 128 + 16 * h);
+    const unsigned lAm = ring0 + (unsigned)(32768 + mw * 1024 + col * 8 + 2 * ch * 256), lBm = ring0 + (unsigned)(32768 + 2048 + nw * 1024 + col * 8 + 2 * ch * 256);
+    unsigned cslot = 0;
+    // one half-step; HB = which half of the block, REM = half-steps still to come after this one, clipped to 3 (3 = steady state)
+    auto step = [&](auto HB, auto REM) __attribute__((always_inline)) {
+        constexpr int hb = decltype(HB)::value, rem = decltype(REM)::value;
+        // this wave's DMA of the half-step has landed when at most the (up to two) younger half-steps are outstanding: FPW + 1 per half-step
+        if (rem >= 2) { if (MTW == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+        else if (rem == 1) { if (MTW == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // everyone's part of the slot has landed; everyone is done with the previous slot
+        asm volatile("" ::: "memory");
+#if !defined(GQ_DBG_NODMA)   // diagnosis build: no operand stream after the first three half-steps (compute + barriers only; results are wrong)
+        if (rem >= 3) issue(1 - hb);
+#endif
+        if (active) {
+            typedef __attribute__((address_space(3))) const char *lds_cp;
+            const unsigned cs = __builtin_amdgcn_readfirstlane(cslot);
+            f32x2 dwv;
+            f32x4 dx[4];
+            if (hb == 0) {
+                dwv = *reinterpret_cast<__attribute__((address_space(3))) const f32x2 *>((lds_cp)(size_t)(lW + cs));
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const f32x4 dx = *reinterpret_cast<const f32x4 *>(aux + mw * 128 + (8 * g4 + 4 * h) * 4);   // rows 8 g4 + 4h + (0..3)
+                for (int g4 = 0; g4 < 4; ++g4) dx[g4] = *reinterpret_cast<__attribute__((address_space(3))) const f32x4 *>((lds_cp)(size_t)(lX + cs) + 32 * g4);   // rows 8 g4 + 4h + (0..3)
+            }
+            // this wave's 4 + 4 fragments: classes 2ch, 2ch+1 of the half
+            const __attribute__((address_space(3))) v8h *A = reinterpret_cast<__attribute__((address_space(3))) const v8h *>((lds_cp)(size_t)(lA + cs));
+            const __attribute__((address_space(3))) v8h *B = reinterpret_cast<__attribute__((address_space(3))) const v8h *>((lds_cp)(size_t)(lB + cs));
+            const v8h a0 = A[0], b0 = B[0], a2 = A[128], b2 = B[128], a1 = A[64], b1 = B[64], a3 = A[192], b3 = B[192];
+            v4h a4[2], b4[2];                                  // mins operands (k = 0..3 of the fragment; lanes 32..63 carry k = 8..15 = zeros)
+            if (hb == 1) {
+                const __attribute__((address_space(3))) v4h *Am = reinterpret_cast<__attribute__((address_space(3))) const v4h *>((lds_cp)(size_t)(lAm + cs));
+                const __attribute__((address_space(3))) v4h *Bm = reinterpret_cast<__attribute__((address_space(3))) const v4h *>((lds_cp)(size_t)(lBm + cs));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            dd[4 * g4 + e] = dx[e] * dwv[0];        // y.d * fp16(x.d)
-                            dm[4 * g4 + e] = (-dx[e]) * dwv[1];     // -y.d * fp16(x.dmin)
-                        }
+                for (int k = 0; k < 2; ++k) { a4[k] = Am[k * 32]; b4[k] = Bm[k * 32]; }   // all lanes read (no wait under a predicate)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // retire the previous half-step (hb == 0: the odd half of the previous block, still under that block's dd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[2 * (1 - hb)][r] = __fmaf_rn(dd[r], cp0[r], acc[2 * (1 - hb)][r]);
+                acc[2 * (1 - hb) + 1][r] = __fmaf_rn(dd[r], cp1[r], acc[2 * (1 - hb) + 1][r]);
+            }
+            if (hb == 0) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dd[4 * g4 + e] = dx[g4][e] * dwv[0];        // y.d * fp16(x.d)
+                        dm[4 * g4 + e] = (-dx[g4][e]) * dwv[1];     // -y.d * fp16(x.dmin)
                     }
-                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            v16f cm0, cm1;
+            if (hb == 1) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                v8h am[2], bm[2];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(2 * k) * 64], B[(2 * k) * 64], zero, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(2 * k + 1) * 64], B[(2 * k + 1) * 64], c, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[2 * hb + k][r] = __fmaf_rn(dd[r], c[r], acc[2 * hb + k][r]);
+                    const u32x2 ua = __builtin_bit_cast(u32x2, a4[k]), ub = __builtin_bit_cast(u32x2, b4[k]);
+                    const u32x4 wa = {h == 0 ? ua[0] : 0u, h == 0 ? ua[1] : 0u, 0u, 0u}, wb = {h == 0 ? ub[0] : 0u, h == 0 ? ub[1] : 0u, 0u, 0u};
+                    am[k] = __builtin_bit_cast(v8h, wa); bm[k] = __builtin_bit_cast(v8h, wb);
                 }
-                if (hb == 1) {
-                    const v4h *Am = reinterpret_cast<const v4h *>(aux + mw * 1024) + col, *Bm = reinterpret_cast<const v4h *>(aux + 2048 + nw * 1024) + col;
+                cm0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[0], bm[0], zero, 0, 0, 0);
+                cm1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[1], bm[1], zero, 0, 0, 0);
+            }
+            cp0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0);
+            cp1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b2, zero, 0, 0, 0);
+            cp0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, cp0, 0, 0, 0);
+            cp1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, b3, cp1, 0, 0, 0);
+            if (hb == 1) {
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int u = 2 * ch + k;
-                        v8h a = hz, b = hz;
-                        if (h == 0) {
-                            const v4h a4 = Am[u * 32], b4 = Bm[u * 32];
-                            a[0] = a4[0]; a[1] = a4[1]; a[2] = a4[2]; a[3] = a4[3];
-                            b[0] = b4[0]; b[1] = b4[1]; b[2] = b4[2]; b[3] = b4[3];
-                        }
-                        const v16f c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, zero, 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) accm[k][r] = __fmaf_rn(dm[r], c[r], accm[k][r]);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    accm[0][r] = __fmaf_rn(dm[r], cm0[r], accm[0][r]);
+                    accm[1][r] = __fmaf_rn(dm[r], cm1[r], accm[1][r]);
                 }
             }
         }
+        cslot = cslot + (unsigned)GQ_SLOT == (unsigned)GQ_LDS ? 0u : cslot + (unsigned)GQ_SLOT;
+    };
+    using std::integral_constant;
+#pragma unroll 1
+    for (int i = 0; i + 2 < nb; ++i) {                    // blocks 0 .. nb-3: both halves in the steady state
+        step(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+        step(integral_constant<int, 1>{}, integral_constant<int, 3>{});
     }
-    // the pair meets: wave ch = 1 hands (a2+a6, a3+a7, m2, m3) to wave ch = 0 through LDS (the ring is free now)
+    if (nb >= 2) {                                        // block nb-2: its odd half has nothing left to request
+        step(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+        step(integral_constant<int, 1>{}, integral_constant<int, 2>{});
+    }
+    step(integral_constant<int, 0>{}, integral_constant<int, 1>{});   // the last block
+    step(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[2][r] = __fmaf_rn(dd[r], cp0[r], acc[2][r]);
+            acc[3][r] = __fmaf_rn(dd[r], cp1[r], acc[3][r]);
+        }
+    }
+    // the pair meets through LDS (the ring is free now): wave ch finishes accumulator registers 8 ch .. 8 ch + 7 of the tile and hands the other
+    // eight of its partial sums (a0+a4 | a2+a6, a1+a5 | a3+a7, m0 | m2, m1 | m3) to its partner -- IEEE adds commute, so which of the two waves
+    // performs (a0+a4)+(a2+a6) does not matter.  Residual rows are requested together, ahead of the adds.
     float x[16], yv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { x[r] = acc[0][r] + acc[2][r]; yv[r] = acc[1][r] + acc[3][r]; }
     __syncthreads();
     float *xch = reinterpret_cast<float *>(ring) + (size_t)tile * 64 * 64 + lane;
-    if (ch == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { xch[(r) * 64] = x[r]; xch[(16 + r) * 64] = yv[r]; xch[(32 + r) * 64] = accm[0][r]; xch[(48 + r) * 64] = accm[1][r]; }
-    }
-    __syncthreads();
-    if (!active || ch == 1) return;
     const int n = nt * 32 + col;
-    if (n >= N) return;
-    const float bv = bias ? bias[n] : 0.0f;
+    auto finish = [&](auto R0) __attribute__((always_inline)) {
+        constexpr int r0 = decltype(R0)::value, p0 = 8 - r0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= M) continue;
-        const float hs = (x[r] + xch[r * 64]) + (yv[r] + xch[(16 + r) * 64]);
-        float v = hs + ((accm[0][r] + xch[(32 + r) * 64]) + (accm[1][r] + xch[(48 + r) * 64]));
-        if (bias) v = v + bv;
-        if (y_f16) reinterpret_cast<uint16_t *>(y)[(int64_t)m * ldy + n] = f2h(v);
-        else {
-            if (residual) v = v + residual[(int64_t)m * ldy + n];
-            reinterpret_cast<float *>(y)[(int64_t)m * ldy + n] = v;
+        for (int j = 0; j < 8; ++j) {
+            const int r = p0 + j;
+            xch[r * 64] = x[r]; xch[(16 + r) * 64] = yv[r]; xch[(32 + r) * 64] = accm[0][r]; xch[(48 + r) * 64] = accm[1][r];
         }
-    }
+        __syncthreads();
+        if (!active || n >= N) return;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + j;
+            const float hs = (x[r] + xch[r * 64]) + (yv[r] + xch[(16 + r) * 64]);
+            v[j] = hs + ((accm[0][r] + xch[(32 + r) * 64]) + (accm[1][r] + xch[(48 + r) * 64]));
+        }
+        if (bias) {
+            const float bv = bias[n];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] + bv;
+        }
+        const int mb = mt * 32 + 4 * h;
+        if (y_f16) {
+            uint16_t *yp = reinterpret_cast<uint16_t *>(y) + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = mb + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2);
+                if (m < M) yp[(int64_t)m * ldy] = f2h(v[j]);
+            }
+        } else {
+            float *yp = reinterpret_cast<float *>(y) + n;
+            if (residual) {
+                float res[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) res[j] = residual[(int64_t)min(mb + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2), M - 1) * ldy + n];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] + res[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = mb + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2);
+                if (m < M) yp[(int64_t)m * ldy] = v[j];
+            }
+        }
+    };
+    if (ch == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 8>{});
 }
 
 // ------------------------------------------------------------------------------------------------------------------
