@@ -367,7 +367,9 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
         if (rem >= 2) { if (MTW == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
         else if (rem == 1) { if (MTW == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !defined(GQ_DBG_NOBAR)   // diagnosis build: waves free-run (results are wrong)
         __builtin_amdgcn_s_barrier();      // everyone's part of the slot has landed; everyone is done with the previous slot
+#endif
         asm volatile("" ::: "memory");
 #if !defined(GQ_DBG_NODMA)   // diagnosis build: no operand stream after the first three half-steps (compute + barriers only; results are wrong)
         if (rem >= 3) issue(1 - hb);
