@@ -329,6 +329,11 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
         islot = islot + (unsigned)GQ_SLOT == ring0 + (unsigned)GQ_LDS ? ring0 : islot + (unsigned)GQ_SLOT;
         if (hb == 0) pe += se; else po += so;
     };
+    const int TS = 2 * nb;
+    issue(0);                 // the first three half-steps are on their way before the accumulators are even cleared
+    issue(1);                 // TS >= 2 always (nb >= 1)
+    if (TS > 2) issue(0);
+    __builtin_amdgcn_sched_barrier(0);
     v16f acc[4], accm[2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -344,10 +349,6 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
     const v8h hz = {0, 0, 0, 0, 0, 0, 0, 0};
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const int TS = 2 * nb;
-    issue(0);
-    issue(1);                 // TS >= 2 always (nb >= 1)
-    if (TS > 2) issue(0);
     // Software pipeline over the half-steps: a half-step requests its LDS operands, then *retires the previous half-step's class sums*
     // (the VALU chain step acc = fma(dd, c, acc), which covers the LDS latency), then issues its own MFMAs, whose results are
     // read one barrier later -- no wave waits on an MFMA it has just issued.  dd starts at 0 so the first retire is fma(0, 0, 0).
