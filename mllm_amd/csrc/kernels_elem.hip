@@ -150,7 +150,12 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float *__restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + 256 * i, r = idx >> 6, c4 = idx & 63;
-                *reinterpret_cast<float4 *>(&buf[b][r * LN_PITCH + 4 * c4]) = stage[i];
+                float4 v = stage[i];
+                if (pass == 1) {          // the centring c = x - mean is order-free: all 256 threads do it while parking, the walker keeps only its fma chain
+                    const float mr = mean_s[r];
+                    v.x = v.x - mr; v.y = v.y - mr; v.z = v.z - mr; v.w = v.w - mr;
+                }
+                *reinterpret_cast<float4 *>(&buf[b][r * LN_PITCH + 4 * c4]) = v;
             }
         };
         fetch(0);
@@ -177,12 +182,11 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float *__restrict__
                     for (; k + 16 <= n; k += 16) {
                         const float4 v0 = *reinterpret_cast<const float4 *>(rowp + k), v1 = *reinterpret_cast<const float4 *>(rowp + k + 4);
                         const float4 v2 = *reinterpret_cast<const float4 *>(rowp + k + 8), v3 = *reinterpret_cast<const float4 *>(rowp + k + 12);
-                        const float cc[16] = {v0.x - mean, v0.y - mean, v0.z - mean, v0.w - mean, v1.x - mean, v1.y - mean, v1.z - mean, v1.w - mean,
-                                              v2.x - mean, v2.y - mean, v2.z - mean, v2.w - mean, v3.x - mean, v3.y - mean, v3.z - mean, v3.w - mean};
+                        const float cc[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};   // already centred
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc = __fmaf_rn(cc[e], cc[e], acc);
                     }
-                    for (; k < n; ++k) { const float cc = rowp[k] - mean; acc = __fmaf_rn(cc, cc, acc); }
+                    for (; k < n; ++k) { const float cc = rowp[k]; acc = __fmaf_rn(cc, cc, acc); }
                 }
             }
             if (c + 1 < nch) park((c + 1) & 1);
