@@ -94,7 +94,28 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
         }
         return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + off);
     };
+    // element offsets of this thread's groups in chunk 0; a chunk that lies wholly inside the Sk rows is reached by adding chunk0 * ld (one 64-bit add per
+    // request instead of a clamp and 64-bit multiplies -- a lone wave pays for every instruction); only the ragged last chunk clamps its key rows
+    int64_t koff[KG], voff[KG];
+#pragma unroll
+    for (int i = 0; i < KG; ++i) {
+        const int e4 = min(tid + 256 * i, FA_KCH * D / 4 - 1);
+        const int key = e4 / (D / 4), d4 = e4 - key * (D / 4);
+        koff[i] = (int64_t)key * ldk + kvh * D + 4 * d4;
+        if (VT) {
+            const int dd = e4 / (FA_KCH / 4), k4 = e4 - dd * (FA_KCH / 4);
+            voff[i] = (int64_t)(kvh * D + dd) * ldv + 4 * k4;
+        } else {
+            voff[i] = (int64_t)key * ldv + kvh * D + 4 * d4;
+        }
+    }
     auto fetch = [&](int chunk0) {
+        if (chunk0 + FA_KCH <= Sk) {
+            const int64_t ck = (int64_t)chunk0 * ldk, cv = VT ? (int64_t)chunk0 : (int64_t)chunk0 * ldv;
+#pragma unroll
+            for (int i = 0; i < KG; ++i) { kst[i] = load4(K, koff[i] + ck); vst[i] = load4(V, voff[i] + cv); }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < KG; ++i) {
             const int e4 = min(tid + 256 * i, FA_KCH * D / 4 - 1);
