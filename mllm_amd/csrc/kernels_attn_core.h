@@ -487,7 +487,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
             }
         }
         if (ch == nch - 1) { STAMPT(5, 0); STAMPT(6, 64); STAMPT(7, (D + 63) & ~63); }
-        __syncthreads();
+        if (nch > L.nslots) __syncthreads();   // only a ring that gets refilled needs the walkers and the parking threads to meet per chunk (T <= nslots * 128 keys: never)
         if (refill) park_chunk(ch + L.nslots, vref);
     }
     if (walker && VT && vnew) {   // the appended token: rescale (always a multiply in the reference), then its value row
