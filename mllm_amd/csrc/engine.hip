@@ -233,9 +233,9 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
         CK(m->dalloc(&m->emb_qs, nblk * 16));
         CK(m->dalloc(&m->emb_d, nblk * 2));
         CK(mllm_hip_repack_q40(raw, m->emb_qs, m->emb_d, (int64_t)nblk, m->st));
-        hipStreamSynchronize(m->st);
-        hipFree(raw);
+        CK(hipStreamSynchronize(m->st) == hipSuccess ? 0 : MLLM_HIP_ERR_HIP);
         m->allocs.erase(std::find(m->allocs.begin(), m->allocs.end(), (void *)raw));
+        CK(hipFree(raw) == hipSuccess ? 0 : MLLM_HIP_ERR_HIP);
         if (!c.tie_embedding) { fprintf(stderr, "mllm_hip: untied lm_head not implemented in this engine\n"); mllm_hip_qwen2vl_destroy(m); return MLLM_HIP_ERR_ARG; }
     }
     m->layers.resize(c.layers);
@@ -293,7 +293,8 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
     // of zero padding (the decode walk over-reads whole 16-byte vectors; prefill reads 4 keys at a time)
     m->vt_ld = ((T + 63) & ~63) + 128;
     CK(m->dalloc(&m->kslab, ((size_t)c.layers * T + 64) * m->KVD * 2)); CK(m->dalloc(&m->vslab, (size_t)c.layers * m->KVD * m->vt_ld * 2));
-    hipMemset(m->kslab, 0, ((size_t)c.layers * T + 64) * m->KVD * 2); hipMemset(m->vslab, 0, (size_t)c.layers * m->KVD * m->vt_ld * 2);
+    CK(hipMemset(m->kslab, 0, ((size_t)c.layers * T + 64) * m->KVD * 2) == hipSuccess ? 0 : MLLM_HIP_ERR_HIP);
+    CK(hipMemset(m->vslab, 0, (size_t)c.layers * m->KVD * m->vt_ld * 2) == hipSuccess ? 0 : MLLM_HIP_ERR_HIP);
     m->nsplit = (T + 63) / 64;
     {
         size_t wsb = mllm_hip_fa2_workspace_bytes(1, c.heads, m->D, T), wsd = (size_t)c.heads * m->nsplit * 136 * 4;
@@ -334,13 +335,14 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
 
 extern "C" void mllm_hip_qwen2vl_destroy(mllm_hip_qwen2vl *m) {
     if (!m) return;
-    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) hipGraphDestroy(m->graph);
-    for (void *p : m->allocs) hipFree(p);
-    if (m->xpack) hipFree(m->xpack);
-    if (m->ev0) hipEventDestroy(m->ev0);
-    if (m->ev1) hipEventDestroy(m->ev1);
-    if (m->st) hipStreamDestroy(m->st);
+    // teardown: nothing useful can be done with a failing release, the codes are dropped on purpose
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
+    for (void *p : m->allocs) (void)hipFree(p);
+    if (m->xpack) (void)hipFree(m->xpack);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->st) (void)hipStreamDestroy(m->st);
     delete m;
 }
 extern "C" int mllm_hip_qwen2vl_clear_kvcache(mllm_hip_qwen2vl *m) { m->cache_len = 0; m->last_pos = -1.0f; return MLLM_HIP_OK; }
