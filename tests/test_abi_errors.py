@@ -1,0 +1,88 @@
+"""Error behaviour of the C-ABI boundary (include/mllm_hip.h:33-38): every entry point returns MLLM_HIP_OK or a negative MLLM_HIP_ERR_*, validates
+its arguments before anything is launched, and treats an empty batch as a no-op.  These calls return before the first HIP call, so they run
+without a GPU (no compute); the adapter of INTEGRATION.md relies on exactly these codes to refuse an Op at opCreate / reshape time."""
+import ctypes as C
+import os
+
+import pytest
+
+from mllm_amd import lib
+
+OK, ERR_HIP, ERR_SHAPE, ERR_DTYPE, ERR_IO, ERR_ARG = 0, -1, -2, -3, -4, -5
+F32, F16 = lib.F32, lib.F16
+NULL = C.c_void_p(0)
+P = C.c_void_p(0x1000)      # a non-null pointer that is never dereferenced on these paths
+
+
+@pytest.fixture(scope="module")
+def L():
+    return lib.load()
+
+
+def test_header_codes_match_the_bindings():
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mllm_hip.h")).read()
+    for name, val in (("MLLM_HIP_OK", "0"), ("MLLM_HIP_ERR_HIP", "(-1)"), ("MLLM_HIP_ERR_SHAPE", "(-2)"), ("MLLM_HIP_ERR_DTYPE", "(-3)"),
+                      ("MLLM_HIP_ERR_IO", "(-4)"), ("MLLM_HIP_ERR_ARG", "(-5)")):
+        assert f"#define {name} {val}" in hdr
+    assert lib.OK == OK
+
+
+def test_gemm_on_packed_operands_validates_before_launch(L):
+    f = L.mllm_hip_linear_q4kp_packed
+    args = lambda W, xp, ydt, M, N, K: (W, NULL, xp, P, C.c_int(ydt), C.c_int64(N), NULL, C.c_int(M), C.c_int(N), C.c_int(K), NULL)
+    assert f(*args(P, P, F32, 32, 64, 300)) == ERR_SHAPE          # K is not a whole number of super-blocks
+    assert f(*args(P, P, F32, 32, 0, 256)) == ERR_SHAPE
+    assert f(*args(P, P, 99, 32, 64, 256)) == ERR_DTYPE
+    assert f(*args(P, P, F32, 0, 64, 256)) == OK                  # empty batch: nothing to do, nothing touched
+    assert f(*args(NULL, P, F32, 32, 64, 256)) == ERR_ARG
+    assert f(*args(P, NULL, F32, 32, 64, 256)) == ERR_ARG
+
+
+def test_producers_validate_before_launch(L):
+    q = L.mllm_hip_quantize_q8k_packed
+    assert q(P, P, C.c_int(4), C.c_int(300), NULL) == ERR_SHAPE
+    assert q(P, NULL, C.c_int(4), C.c_int(256), NULL) == ERR_SHAPE
+    assert q(P, P, C.c_int(0), C.c_int(256), NULL) == OK
+    assert L.mllm_hip_quantize_q8k_packed_act(P, NULL, P, C.c_int(4), C.c_int(256), NULL) == ERR_SHAPE     # no LUT
+    assert L.mllm_hip_quantize_q8k_packed_silu_mul(P, P, C.c_int(4), C.c_int(100), NULL) == ERR_SHAPE
+    assert L.mllm_hip_quantize_q8k_packed_silu_mul(P, P, C.c_int(0), C.c_int(256), NULL) == OK
+    r = L.mllm_hip_rmsnorm_packed
+    assert r(P, P, NULL, P, C.c_int(0), C.c_int(256), C.c_float(1e-6), C.c_int(0), NULL) == OK
+    assert r(P, P, NULL, NULL, C.c_int(4), C.c_int(256), C.c_float(1e-6), C.c_int(0), NULL) == ERR_SHAPE
+    assert r(P, P, NULL, P, C.c_int(4), C.c_int(100), C.c_float(1e-6), C.c_int(0), NULL) == ERR_SHAPE
+    assert L.mllm_hip_layernorm_packed(P, P, P, NULL, NULL, C.c_int(4), C.c_int(256), C.c_float(1e-6), NULL) == ERR_ARG
+    ln = L.mllm_hip_layernorm
+    assert ln(P, P, P, P, NULL, NULL, NULL, C.c_int(0), C.c_int(256), C.c_float(1e-6), NULL) == OK
+    assert ln(P, P, P, NULL, P, P, P, C.c_int(4), C.c_int(100), C.c_float(1e-6), NULL) == ERR_SHAPE           # fused Q8_K output needs dim % 256 == 0
+    assert ln(P, P, P, NULL, P, NULL, NULL, C.c_int(4), C.c_int(256), C.c_float(1e-6), NULL) == ERR_SHAPE     # qs without d / bsums
+    assert ln(P, P, P, NULL, NULL, NULL, NULL, C.c_int(4), C.c_int(256), C.c_float(1e-6), NULL) == ERR_ARG    # no output at all
+
+
+def test_elementwise_and_attention_validate_before_launch(L):
+    assert L.mllm_hip_silu(P, P, C.c_int64(0), NULL) == OK
+    assert L.mllm_hip_add(P, P, P, C.c_int64(0), NULL) == OK
+    assert L.mllm_hip_silu_mul(P, P, C.c_int(4), C.c_int(6), NULL) == ERR_SHAPE
+    assert L.mllm_hip_silu_mul(P, P, C.c_int(0), C.c_int(8), NULL) == OK
+    assert L.mllm_hip_act_lut(P, P, C.c_int64(0), P, NULL) == OK
+    fa = L.mllm_hip_fa2
+    a = lambda kvdt, Sq, Sk, Hq, Hkv, D, ldk=256: (P, C.c_int64(256), P, C.c_int64(ldk), P, C.c_int64(ldk), C.c_int(kvdt), P, C.c_int64(256), C.c_int(Sq),
+                                                    C.c_int(Sk), C.c_int(Hq), C.c_int(Hkv), C.c_int(D), C.c_int(1), NULL, NULL, NULL)
+    assert fa(*a(F16, 0, 8, 2, 1, 128)) == ERR_SHAPE
+    assert fa(*a(F16, 8, 8, 3, 2, 128)) == ERR_SHAPE             # query heads must be a multiple of the K/V heads
+    assert fa(*a(7, 8, 8, 2, 1, 128)) == ERR_DTYPE
+    assert fa(*a(F16, 8, 8, 2, 1, 128, ldk=250)) == ERR_SHAPE    # rows must allow 16-byte loads
+    assert L.mllm_hip_linear(P, C.c_int(F32), NULL, P, P, C.c_int(F16), C.c_int64(8), C.c_int(1), C.c_int(8), C.c_int(8), NULL, NULL) == ERR_DTYPE
+    assert L.mllm_hip_linear(P, C.c_int(lib.Q4_K), NULL, P, P, C.c_int(F32), C.c_int64(8), C.c_int(1), C.c_int(8), C.c_int(256), NULL, NULL) == ERR_ARG   # no workspace
+
+
+def test_engine_create_reports_io_and_argument_errors(L, tmp_path):
+    out = C.c_void_p(0)
+    assert L.mllm_hip_qwen2vl_create(NULL, b"/nonexistent", C.byref(out)) == ERR_ARG
+    from mllm_amd import synth
+    cfg = lib.make_config(synth.qwen2vl_tiny()) if hasattr(lib, "make_config") else None
+    if cfg is not None:
+        assert L.mllm_hip_qwen2vl_create(C.byref(cfg), b"/nonexistent/model.mllm", C.byref(out)) == ERR_IO
+        bad = tmp_path / "bad.mllm"
+        bad.write_bytes(b"\x00" * 64)                               # wrong magic number
+        assert L.mllm_hip_qwen2vl_create(C.byref(cfg), str(bad).encode(), C.byref(out)) == ERR_IO
+    assert not out.value
