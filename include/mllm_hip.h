@@ -55,10 +55,6 @@ int mllm_hip_h2d(void *dst, const void *src, size_t nbytes, void *stream);
 int mllm_hip_d2h(void *dst, const void *src, size_t nbytes, void *stream);
 int mllm_hip_sync(void *stream);
 
-/* ---- host-side weight tooling (tools/quantizer/QuantWriter.cpp:288-300; ggml QuantizeQ4.cpp:31-64,187-293) -------- */
-int64_t mllm_hip_quantized_nbytes(int dtype, int64_t n_elem);
-int mllm_hip_quantize_host(int dtype, const float *x, void *y, int64_t n_elem);
-
 /* ---- A4: activation quantisation. quantize_row_q8_K_reference (ggml QuantizeQ8.cpp:216-251), quantize_row_q8_0_reference
  *      (:32-55), as called by mat_mul (compute/Matmul.cpp:77-120) ----------------------------------------------------- */
 int mllm_hip_quantize_q8k(const float *x, int8_t *qs, float *d, int16_t *bsums, int M, int K, void *stream);
@@ -143,6 +139,14 @@ int mllm_hip_argmax(const float *x, int n, int *out_index, void *stream);
  * is not reproducible in the reference and stays with the caller.  k <= 64. */
 int mllm_hip_topk(const float *x, int n, int k, float *out_val, int *out_idx, void *stream);
 int mllm_hip_topk_probs_host(const float *top_val, int k, float temperature, float *probs);
+/* SURVEY N2, top-p (nucleus) sampling (mllm/Generate.cpp:93-142, _LlmTextGenerateToppSamplingMethod::generate): the std::sort of the whole
+ * (score, index) row (:99) as one device radix sort, keys descending, equal keys by ascending index; the caller then reads only the prefix whose
+ * running float sum reaches p (:108-115).  workspace: mllm_hip_sort_desc_workspace_bytes(n) bytes of device memory. */
+size_t mllm_hip_sort_desc_workspace_bytes(int n);
+int mllm_hip_sort_desc(const float *x, int n, float *val_sorted, int *idx_sorted, void *workspace, size_t workspace_bytes, void *stream);
+/* the draw of both sampling methods, _sample_element (mllm/Generate.hpp:38-44: std::discrete_distribution over the float probabilities), as an
+ * inverse CDF on a caller-supplied uniform number u01 in [0,1): returns the index of the drawn candidate (host arithmetic). */
+int mllm_hip_sample_index_host(const float *probs, int k, float u01);
 
 /* ---- A10/A11/A19: rotary embeddings. Tables are built on the host with the reference's libm formulas
  *      (CPURoPE.cpp:22-31,100-128; CPUMultimodalRoPE.cpp:26-36,84-118,37-82; CPUVisionRoPE.cpp:19-55) and uploaded;
@@ -180,10 +184,97 @@ int mllm_hip_patch_gemm_f32(const float *patches, const float *W, const float *b
 int mllm_hip_im2patch_hcw(const float *img, float *patches, int H, int C, int W, int p, void *stream);
 
 /* ================================================================================================================
- * Engine: the reference's model graphs for the hot-path configs, reproduced on top of the launchers above.
- * Mirrors demo_qwen2_vl.cpp:32-66 (load -> get_position_ids -> model(input) -> argmax -> next token) and
- * Module::profiling()'s timing definition (mllm/Module.cpp:35-42).
+ * Engine: the reference's model graphs for the hot-path configs, resident on the device, on top of the
+ * launchers above.  One engine type serves the five BASELINE configs; `arch` picks the graph and the tensor names:
+ *   QWEN2VL  Qwen2VLModel (models/qwen2_vl/modeling_qwen2_vl.hpp:21-404): M-RoPE decoder + its vision tower + PatchMerger
+ *   QWEN     QWenForCausalLM (models/qwen/modeling_qwen.hpp:131-179): HF rotary, q/k/v bias, tied or Linear lm_head
+ *   LLAMA    TinyLLaMAModel / LLaMAModel (models/tinyllama/modeling_tinyllama.hpp:15-84, models/llama/modeling_llama.hpp:38-117):
+ *            HF rotary, no bias, Linear lm_head
+ *   LLAVA    LLaVAModel (models/llava/modeling_llava.hpp:39-137): LLaMA body under "language_model." + CLIP tower + projector
+ *   VIT      ViTModel (models/vit/modeling_vit.hpp:63-111): patch embedding, encoder, classifier (no language model)
+ * Mirrors the demos' loop (examples/demo_qwen2_vl.cpp:32-66, demo_qwen.cpp, demo_llava.cpp:39-57: load -> model(input) ->
+ * argmax -> next token) and Module::profiling()'s timing definition (mllm/Module.cpp:35-42).
+ * Weights: Q4_K Linears, Q4_0 embed_tokens, F32 norms / biases / patch-embedding convolutions -- what `quantize ... Q4_K` writes
+ * (tools/quantizer/QuantWriter.cpp:123-157).
  * ============================================================================================================== */
+#define MLLM_HIP_ARCH_QWEN2VL 0
+#define MLLM_HIP_ARCH_QWEN 1
+#define MLLM_HIP_ARCH_LLAMA 2
+#define MLLM_HIP_ARCH_LLAVA 3
+#define MLLM_HIP_ARCH_VIT 4
+
+typedef struct mllm_hip_model_config {
+    int arch;
+    int hidden, inter, layers, heads, kv_heads, vocab;
+    float rms_eps;         /* decoder blocks' RMSNorm epsilon */
+    float final_eps;       /* model.norm epsilon: 1e-6 hard-coded in Qwen2VLModel (:374), LLaMA/TinyLLaMA/LLaVA; config.rms_norm_eps in QWen (:105) */
+    float rope_theta;
+    int mrope_section[3];  /* QWEN2VL only */
+    int cache_limit;       /* KV slab length, `-l` of the demos */
+    int tie_embedding;     /* lm_head = embed_tokens^T (Tensor::mm, modeling_qwen.hpp:158-159) */
+    int qkv_bias;
+    /* vision tower (0 = none): QWEN2VL patch 14 / merge 2 / mlp 4*dim; LLAVA CLIP-L (v_ffn also the projector width); VIT */
+    int v_dim, v_heads, v_blocks, v_patch, v_merge, v_ffn, v_img, v_classes;
+    int image_token_id, vision_start_token_id, vision_end_token_id, video_token_id;
+} mllm_hip_model_config;
+
+typedef struct mllm_hip_model mllm_hip_model;
+
+/* Module::load (mllm/Module.hpp:215-225) + ParamLoader (mllm/ParamLoader.cpp:88-141,157-286): mmap the .mllm and stream it to HBM
+ * through two pinned staging buffers (hipMemcpyAsync on a copy stream) while the load-time repack kernels of the tensors already
+ * resident run on the compute stream (Backend::load_from_file hook, mllm/Backend.hpp:118). */
+int mllm_hip_model_create(const mllm_hip_model_config *cfg, const char *mllm_path, mllm_hip_model **out);
+void mllm_hip_model_destroy(mllm_hip_model *m);
+/* load-time report in the spirit of Module::profiling()'s load_time (mllm/Module.cpp:25-33): wall ms of create(), bytes read from
+ * the file, ms the copy stream was busy, ms of repack kernels.  Any pointer may be NULL. */
+int mllm_hip_model_load_stats(const mllm_hip_model *m, float *total_ms, int64_t *file_bytes, float *h2d_ms, float *repack_ms);
+/* Module::clear_kvcache: KVCache sequence counters and RoPE position counters back to 0 (CPUKVCache.hpp:26-29, CPURoPE.hpp:63-65) */
+int mllm_hip_model_clear_kvcache(mllm_hip_model *m);
+/* One prefill forward.  ids: n_ids host ints.  image (optional, host fp32): QWEN2VL pixel_values `[n_patch][3*2*14*14]` with
+ * image_meta = grid_thw (3 ints); LLAVA one image `[H][C][W]` (CLIP img2Tensor layout, models/clip/processing_clip.hpp:28-44),
+ * image_meta NULL.  visual_dev (optional, device fp32): the tower's output rows already computed (e.g. all-gathered from the ranks
+ * of the image shard) -- then `image` is not run.  QWEN2VL puts row i at the i-th image_token_id position (where + index_put,
+ * modeling_qwen2_vl.hpp:386-393); LLAVA replaces its single 32000 row by the N rows (modeling_llava.hpp:128-132), so the sequence
+ * grows to n_ids - 1 + N.  Outputs (each optional): logits_host `[vocab]` of the last token, next_token (greedy argmax, first maximum like
+ * std::max_element), elapsed_ms (device time, inputs resident in HBM when it starts). */
+int mllm_hip_model_prefill(mllm_hip_model *m, const int32_t *ids, int n_ids, const float *image, const int32_t *image_meta,
+                           const float *visual_dev, int n_visual_rows, float *logits_host, int32_t *next_token, float *elapsed_ms);
+/* One decode forward for `token` at the next position */
+int mllm_hip_model_decode(mllm_hip_model *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms);
+/* `steps` greedy decode forwards back to back on the device (argmax on device, no per-token D2H): SURVEY N2, the loop of
+ * Module::generate (mllm/Module.cpp:63-100) with the greedy method.  tokens_host receives the generated ids. */
+int mllm_hip_model_generate(mllm_hip_model *m, int32_t first_token, int steps, int32_t *tokens_host, float *elapsed_ms);
+/* Sampled generation (mllm/Generate.hpp:156-240; method 0 greedy, 1 top-k, 2 top-p = nucleus): the candidate set is selected on the
+ * device each step (k values or the nucleus prefix cross PCIe, never the vocabulary row); the temperature softmax over it and the draw run
+ * on the host as in the reference.  `u01` = steps uniform numbers in [0,1) that replace the reference's std::random_device-seeded
+ * std::discrete_distribution draw (Generate.hpp:38-44), so a run is reproducible; stops after `steps` or at `eos` (< 0: never).
+ * Returns the count generated in *n_out. */
+int mllm_hip_model_generate_sampled(mllm_hip_model *m, int32_t first_token, int steps, int method, int top_k, float top_p, float temperature,
+                                    const float *u01, int32_t eos, int32_t *tokens_host, int *n_out, float *elapsed_ms);
+/* Vision tower only on `n_img` images (the unit of the multi-GPU image shard; uploads of image i+1 overlap the tower on image i).
+ * QWEN2VL: images = pixel_values `[n_img][n_patch][1176]`, image_meta = grid_thw, out `[n_img][n_patch/4][hidden]`;
+ * LLAVA:   images `[n_img][H][C][W]`, out `[n_img][(H/p)^2][v_ffn]`;   VIT: images `[n_img][H][C][W]`, out `[n_img][v_classes]`.
+ * out_dev is device memory (so the shard can all-gather it without a host hop). */
+int mllm_hip_model_vision(mllm_hip_model *m, const float *images_host, const int32_t *image_meta, int n_img, float *out_dev, float *elapsed_ms);
+/* rows and columns of one image's tower output for this config (0 if the config has no tower) */
+int mllm_hip_model_vision_shape(const mllm_hip_model *m, const int32_t *image_meta, int *rows, int *cols);
+/* bytes of weights streamed per decode token (SURVEY §8d algorithmic bytes), for bench.py */
+int64_t mllm_hip_model_decode_weight_bytes(const mllm_hip_model *m);
+/* the stream the engine launches on (hipStream_t as void*), for event timing around it */
+void *mllm_hip_model_stream(mllm_hip_model *m);
+/* mean ms per launch (HIP events on the engine's stream) of one fused decode kernel on the live decode state, cycling over the layers so
+ * that every launch streams cold HBM; which: 10 qkv, 11 attention, 12 o-proj, 13 gate|up, 14 down (0..3: the stand-alone GEMV launcher on
+ * gate|up, down, qkv, o).  Returns its algorithmic bytes per launch too. */
+int mllm_hip_model_time_kernel(mllm_hip_model *m, int which, int iters, float *ms_per_launch, int64_t *bytes_per_launch);
+/* The visual-token exchange of the sharded vision prefill behind the C ABI: every rank contributes `rows_per_rank` rows of `cols`
+ * fp32 (its images' tower output, padded to the common count) and receives all ranks' rows in rank order -- one ncclAllGather (RCCL over
+ * xGMI) on the engine's stream.  `comm` is an ncclComm_t the host created (mllm_hip_comm_* below); no torch types. */
+int mllm_hip_comm_unique_id(void *id128);                                  /* ncclGetUniqueId: 128 bytes, rank 0 shares them */
+int mllm_hip_comm_create(const void *id128, int world, int rank, void **comm);
+int mllm_hip_comm_destroy(void *comm);
+int mllm_hip_all_gather_rows(void *comm, const float *local_dev, float *all_dev, int64_t rows_per_rank, int cols, void *stream);
+
+/* ---- the round-1 names of the Qwen2-VL engine, kept as thin forwards onto the generic engine ------------------------------------ */
 typedef struct mllm_hip_qwen2vl_config {
     int hidden, inter, layers, heads, kv_heads, vocab;
     float rms_eps, rope_theta;
@@ -193,35 +284,18 @@ typedef struct mllm_hip_qwen2vl_config {
     int v_dim, v_heads, v_blocks, v_patch, v_merge;
     int image_token_id, vision_start_token_id, vision_end_token_id, video_token_id;
 } mllm_hip_qwen2vl_config;
-
-typedef struct mllm_hip_qwen2vl mllm_hip_qwen2vl;
-
-/* Module::load (mllm/Module.hpp:215-225) + ParamLoader (mllm/ParamLoader.cpp:88-141,157-286): mmap the .mllm, upload */
+typedef struct mllm_hip_model mllm_hip_qwen2vl;
 int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const char *mllm_path, mllm_hip_qwen2vl **out);
 void mllm_hip_qwen2vl_destroy(mllm_hip_qwen2vl *m);
-/* Qwen2VLModel::clear_kvcache (modeling_qwen2_vl.hpp:405-412) */
 int mllm_hip_qwen2vl_clear_kvcache(mllm_hip_qwen2vl *m);
-/* One prefill forward (modeling_qwen2_vl.hpp:381-404). ids: n_ids host ints; pixel_values: host fp32 `[n_patch][3*2*14*14]`
- * or NULL; grid_thw: 3 host ints. Outputs (each optional): logits_host `[vocab]` of the last token, next_token (greedy
- * argmax, first maximum like std::max_element), elapsed_ms (wall, device-synchronised both sides). */
 int mllm_hip_qwen2vl_prefill(mllm_hip_qwen2vl *m, const int32_t *ids, int n_ids, const float *pixel_values,
                              const int32_t *grid_thw, float *logits_host, int32_t *next_token, float *elapsed_ms);
-/* One decode forward for `token` at the next position (get_position_ids' decode branch, modeling_qwen2_vl.hpp:423-432) */
 int mllm_hip_qwen2vl_decode(mllm_hip_qwen2vl *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms);
-/* `steps` greedy decode forwards back to back on the device (argmax on device, no per-token D2H): SURVEY N2.
- * tokens_host receives the `steps` generated ids. elapsed_ms covers all steps. */
 int mllm_hip_qwen2vl_generate(mllm_hip_qwen2vl *m, int32_t first_token, int steps, int32_t *tokens_host, float *elapsed_ms);
-/* Vision tower only (Qwen2VisionModel::Forward, modeling_qwen2_vl.hpp:177-190) on `n_img` images of the same grid,
- * pixel_values host `[n_img][n_patch][1176]`; embeds_dev receives `[n_img][n_patch/4][hidden]` fp32 ON DEVICE
- * (so the multi-GPU shard can all-gather it without a host hop). */
 int mllm_hip_qwen2vl_vision(mllm_hip_qwen2vl *m, const float *pixel_values_host, const int32_t *grid_thw, int n_img,
                             float *embeds_dev, float *elapsed_ms);
-/* bytes of weights streamed per decode token (SURVEY §8d algorithmic bytes) and ViT FLOPs per image, for bench.py */
 int64_t mllm_hip_qwen2vl_decode_weight_bytes(const mllm_hip_qwen2vl *m);
-/* the stream the engine launches on (hipStream_t as void*), for event timing around it */
 void *mllm_hip_qwen2vl_stream(mllm_hip_qwen2vl *m);
-/* time (ms) of the dominant kernel measured with HIP events on the engine's stream: runs `iters` launches of the
- * gate/up Q4_K GEMV of layer 0 on the live decode state; returns mean ms per launch and its algorithmic bytes. */
 int mllm_hip_qwen2vl_time_gemv(mllm_hip_qwen2vl *m, int which, int iters, float *ms_per_launch, int64_t *bytes_per_launch);
 
 #ifdef __cplusplus

@@ -23,8 +23,9 @@ struct DecodeLayer {
 struct DecodeCtx {
     DecodeState *state;
     int H, I, heads, kv_heads, D, vocab, cache_limit, nsplit, max_parts;
-    float eps;
+    float eps, final_eps;
     const uint8_t *emb_qs; const uint16_t *emb_d; const float *final_norm;
+    const uint8_t *Whead;               // Linear lm_head rows (Q4_K, decode order) when the head is not tied to embed_tokens, else nullptr
     float *x0, *x1, *qkv, *act, *logits, *fa_ws, *part_val, *normed;
     int8_t *x80_qs; uint16_t *x80_d;
     int *part_idx, *tok_dev, *history;

@@ -1,23 +1,29 @@
-// mllm_amd/csrc/engine.hip -- host side of the hot path: .mllm loader + the reference's Qwen2-VL model graph on the launchers.
+// mllm_amd/csrc/engine.hip -- host side of the hot path: the .mllm loader and the reference's model graphs on the launchers, resident on the device.
 //
 // What it mirrors (all host logic, the arithmetic lives in the kernels_*.hip launchers):
-//   ParamLoader            mllm/ParamLoader.cpp:157-286 (index parse, mmap), :88-141 (load)          -> MllmFile
-//   Qwen2VLModel::Forward  mllm/models/qwen2_vl/modeling_qwen2_vl.hpp:381-404                         -> forward_llm()
-//   QWen2Decoder/Attention/MLP  :193-335                                                              -> layer loop
-//   Qwen2VisionModel       :21-191 (patch embed, VisionBlock x32, PatchMerger)                        -> forward_vision()
-//   get_rope_index / get_position_ids  :413-595                                                       -> rope_index()
-//   demo loop + argmax     examples/demo_qwen2_vl.cpp:53-63, processing_qwen2_vl.hpp:284-289,438-452  -> prefill/decode/generate
+//   ParamLoader            mllm/ParamLoader.cpp:157-286 (index parse, mmap), :88-141 (load)           -> MllmFile + Loader (pinned double buffer)
+//   Qwen2VLModel::Forward  mllm/models/qwen2_vl/modeling_qwen2_vl.hpp:381-404                          -> prefill / forward_llm
+//   QWen2Decoder/Attention/MLP :193-335; QWenDecoder modeling_qwen.hpp:60-101; TinyLLaMABlock modeling_tinyllama.hpp:15-42;
+//   LLaMABlock modeling_llama.hpp:40-80 (all: RMSNorm -> MultiHeadAttention (modeling_transformer.hpp:35-219) -> +x -> RMSNorm -> SiLU MLP -> +x)
+//                                                                                                      -> the layer loop of forward_llm
+//   Qwen2VisionModel       modeling_qwen2_vl.hpp:21-191 (patch embed, VisionBlock x32, PatchMerger)   -> forward_vision (kind QWEN2VL)
+//   LLaVAVisionModel       modeling_llava.hpp:39-98 (CLIP: conv patch embed, cls row, position rows, pre_layrnorm, ViTBlock xN, projector)
+//   ViTModel               modeling_vit.hpp:63-111 (conv patch embed + bias, cls, positions, ViTBlock xN, LayerNorm(cls), classifier) -> forward_vision
+//   get_rope_index / get_position_ids  modeling_qwen2_vl.hpp:413-595                                   -> rope_index()
+//   demo loops + argmax    examples/demo_qwen2_vl.cpp:53-63, demo_qwen.cpp, demo_llava.cpp:39-57       -> prefill / decode / generate
+//   Module::generate       mllm/Module.cpp:63-100 + Generate.cpp:17-142 (greedy / top-k / top-p)       -> generate_sampled
 //   KVCache                backends/cpu/op/CPUKVCache.cpp:10-131,253-275 (fp16 slab, zero-copy append) -> kv slabs + cache_len
 // Layout in HBM: one allocation per weight tensor, Q4_K rows in their native 144-B blocks; q/k/v (and gate/up) rows are
-// concatenated at load so one GEMV/GEMM serves the three (two) projections; embed_tokens (Q4_0, tied lm_head) is split
-// into a nibble plane and an fp16 scale plane; activations live in a handful of reusable fp32 / q8k-plane buffers sized
-// for cache_limit tokens; K/V slabs are fp16 [layers][cache_limit][Hkv*D].
+// concatenated at load so one GEMV/GEMM serves the three (two) projections; embed_tokens (Q4_0) is split into a nibble plane and
+// an fp16 scale plane; activations live in a handful of reusable fp32 / q8k-plane buffers sized for cache_limit tokens; K slab fp16
+// [layers][cache_limit][Hkv*D], V slab fp16 transposed [layers][Hkv*D][vt_ld].
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +41,8 @@ namespace {
 
 struct Entry { uint64_t off, len; int dtype; };
 
+// .mllm index: int32 magic 20012; uint64 index_len; repeat { int32 name_len; name; uint64 data_len; uint64 file_offset; int32 dtype } (ParamLoader.cpp:157-286).
+// Nothing in the header is trusted: every length is checked against the mapped size before it is used.
 struct MllmFile {
     int fd = -1;
     uint8_t *base = nullptr;
@@ -46,6 +54,7 @@ struct MllmFile {
         struct stat st;
         if (fstat(fd, &st) != 0) return false;
         size = st.st_size;
+        if (size < 12) return false;
         base = (uint8_t *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
         if (base == MAP_FAILED) { base = nullptr; return false; }
         int32_t magic;
@@ -53,15 +62,19 @@ struct MllmFile {
         if (magic != 20012) return false;  // _MAGIC_NUMBER, mllm/ParamLoader.hpp:48
         uint64_t ilen;
         memcpy(&ilen, base + 4, 8);
+        if (ilen > size - 12) return false;
         const uint8_t *p = base + 12, *end = base + 12 + ilen;
         while (p < end) {
+            if ((size_t)(end - p) < 4) return false;
             int32_t nl;
             memcpy(&nl, p, 4); p += 4;
+            if (nl < 0 || (size_t)(end - p) < (size_t)nl + 20) return false;
             std::string name((const char *)p, nl); p += nl;
             Entry e;
             memcpy(&e.len, p, 8); memcpy(&e.off, p + 8, 8);
             int32_t dt; memcpy(&dt, p + 16, 4); e.dtype = dt;
             p += 20;
+            if (e.off > size || e.len > size - e.off) return false;      // data must lie inside the file
             idx[name] = e;
         }
         return true;
@@ -70,12 +83,72 @@ struct MllmFile {
     ~MllmFile() { if (base) munmap(base, size); if (fd >= 0) ::close(fd); }
 };
 
+// mmap -> pinned staging (two buffers) -> hipMemcpyAsync on a copy stream.  The CPU fills buffer b+1 from the page cache while the DMA engine
+// drains buffer b; repack kernels of tensors that have landed run meanwhile on the compute stream behind fence() (SURVEY N1;
+// precedent for a device upload at load: mllm/backends/opencl/OpenCLBackend.cpp:928-980).
+struct Loader {
+    static constexpr size_t CH = (size_t)32 << 20;
+    hipStream_t copy = nullptr;
+    uint8_t *pin[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr}, first = nullptr, last = nullptr, fence_ev = nullptr;
+    bool used[2] = {false, false}, started = false;
+    int cur = 0;
+    int64_t bytes = 0;
+    int init() {
+        MH_CHECK(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            MH_CHECK(hipHostMalloc((void **)&pin[b], CH, hipHostMallocDefault));
+            MH_CHECK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+        }
+        MH_CHECK(hipEventCreate(&first)); MH_CHECK(hipEventCreate(&last));
+        MH_CHECK(hipEventCreateWithFlags(&fence_ev, hipEventDisableTiming));
+        return 0;
+    }
+    int put(void *dst, const uint8_t *src, size_t n) {
+        if (!started) { MH_CHECK(hipEventRecord(first, copy)); started = true; }
+        for (size_t off = 0; off < n; off += CH) {
+            const size_t len = std::min(CH, n - off);
+            const int b = cur;
+            if (used[b]) MH_CHECK(hipEventSynchronize(done[b]));
+            memcpy(pin[b], src + off, len);
+            MH_CHECK(hipMemcpyAsync((uint8_t *)dst + off, pin[b], len, hipMemcpyHostToDevice, copy));
+            MH_CHECK(hipEventRecord(done[b], copy));
+            used[b] = true;
+            cur ^= 1;
+        }
+        bytes += (int64_t)n;
+        return 0;
+    }
+    // everything put() so far is visible to work enqueued on `compute` after this call
+    int fence(hipStream_t compute) {
+        MH_CHECK(hipEventRecord(fence_ev, copy));
+        MH_CHECK(hipStreamWaitEvent(compute, fence_ev, 0));
+        return 0;
+    }
+    int finish(float *h2d_ms) {
+        if (started) {
+            MH_CHECK(hipEventRecord(last, copy));
+            MH_CHECK(hipEventSynchronize(last));
+            if (h2d_ms) MH_CHECK(hipEventElapsedTime(h2d_ms, first, last));
+        } else if (h2d_ms) *h2d_ms = 0.0f;
+        return 0;
+    }
+    void destroy() {
+        for (int b = 0; b < 2; ++b) { if (pin[b]) (void)hipHostFree(pin[b]); if (done[b]) (void)hipEventDestroy(done[b]); pin[b] = nullptr; done[b] = nullptr; }
+        if (first) (void)hipEventDestroy(first);
+        if (last) (void)hipEventDestroy(last);
+        if (fence_ev) (void)hipEventDestroy(fence_ev);
+        if (copy) (void)hipStreamDestroy(copy);
+        first = last = fence_ev = nullptr; copy = nullptr;
+    }
+};
+
 struct LinearW {          // one (possibly row-concatenated) Linear
-    void *w = nullptr;    // Q4_K blocks [N][K/256] or fp32 [N][K]
+    void *w = nullptr;    // Q4_K blocks [N][K/256]
     void *wp = nullptr;   // the same rows packed for the M >= 16 GEMM (mllm_hip_q4k_prepack): prefill / vision read these
     void *wd = nullptr;   // LLM decode Linears only: the rows in decode order (decode_order_q4k) for the fused decode kernels
     float *bias = nullptr;
-    int N = 0, K = 0, dtype = MLLM_HIP_Q4_K;
+    int N = 0, K = 0;
 };
 
 struct Q8Planes { int8_t *qs = nullptr; float *d = nullptr; int16_t *bs = nullptr; };
@@ -83,42 +156,53 @@ struct Q8Planes { int8_t *qs = nullptr; float *d = nullptr; int16_t *bs = nullpt
 #define EH(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 #define HH(expr) MH_CHECK(expr)
 
+enum VKind { V_NONE = 0, V_QWEN2VL = 1, V_CLIP = 2, V_VIT = 3 };
+
 }  // namespace
 
-struct mllm_hip_qwen2vl {
-    mllm_hip_qwen2vl_config c;
+struct mllm_hip_model {
+    mllm_hip_model_config c;
     hipStream_t st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<void *> allocs;
+    std::vector<void *> allocs, temps, vis_allocs;
+    Loader ld;
     int D = 0, HD = 0, KVD = 0, QKV = 0;
+    bool has_llm = false, mrope = false;
+    std::string prefix;     // "language_model." for LLaVA's text side
     // LLM weights
     struct Layer { float *in_norm, *post_norm; LinearW qkv, o, gu, down; };
     std::vector<Layer> layers;
     float *final_norm = nullptr;
     uint8_t *emb_qs = nullptr; uint16_t *emb_d = nullptr;
+    LinearW head;           // Linear lm_head when not tied
     // vision weights
+    int vkind = V_NONE;
     struct VBlock { float *n1w, *n1b, *n2w, *n2b; LinearW qkv, proj, fc1, fc2; };
     std::vector<VBlock> vblocks;
-    float *patch_w = nullptr, *lnq_w = nullptr, *lnq_b = nullptr;
-    LinearW m0, m2;
+    float *patch_w = nullptr, *patch_b = nullptr, *cls_tok = nullptr, *pos_emb = nullptr, *pre_w = nullptr, *pre_b = nullptr;
+    float *lnq_w = nullptr, *lnq_b = nullptr;      // QWEN2VL merger.ln_q; VIT: final layernorm
+    LinearW m0, m2;                                // QWEN2VL merger mlp.0 / mlp.2; LLAVA projector linear_1 / linear_2; VIT: m0 = classifier
     uint16_t *lut_gelu = nullptr, *lut_qgelu = nullptr;
-    bool has_vision = false;
     // activations
     int max_tok = 0;
     float *h0 = nullptr, *h1 = nullptr, *qkv = nullptr, *attn = nullptr, *gu = nullptr, *act = nullptr, *logits = nullptr, *normed = nullptr;
     float *ids_f = nullptr; int *idx_i = nullptr; int *tok_dev = nullptr;
-    Q8Planes xq, xq2;            // K = hidden (also v_dim / merger width), K = inter (also v_mlp)
+    Q8Planes xq, xq2;            // K = hidden, K = inter
+    Q8Planes vxq, vxq2;          // vision: K = v_dim, K = max(v_ffn, merger width)
     int8_t *x80_qs = nullptr; uint16_t *x80_d = nullptr;
     float *rope_sin = nullptr, *rope_cos = nullptr;
+    std::vector<float> hf_sin, hf_cos;   // CPURoPE's static table [cache_limit][D/2] (HF rotary archs)
     uint16_t *kslab = nullptr, *vslab = nullptr;
     int vt_ld = 0;
     void *fa_ws = nullptr;
     void *xpack = nullptr;
     size_t xpack_bytes = 0;
-    // vision activations
+    // vision activations (sized for max_patch tokens)
     int max_patch = 0;
-    float *vx = nullptr, *vr = nullptr, *vqkv = nullptr, *vattn = nullptr, *vfc = nullptr, *vact = nullptr, *vpix = nullptr, *vsin = nullptr, *vcos = nullptr,
-          *vemb = nullptr, *vm0 = nullptr;
+    float *vx = nullptr, *vr = nullptr, *vqkv = nullptr, *vattn = nullptr, *vfc = nullptr, *vact = nullptr, *vpix[2] = {nullptr, nullptr}, *vpatch = nullptr, *vsin = nullptr,
+          *vcos = nullptr, *vemb = nullptr, *vm0 = nullptr;
+    hipEvent_t vup[2] = {nullptr, nullptr}, vfree[2] = {nullptr, nullptr};
+    float *pin_img = nullptr; size_t pin_img_bytes = 0;
     // fused decode path (kernels_decode.hip): device-side step state, per-step rotary rows, captured graph
     DecodeState *d_state = nullptr;
     float *dec_sin = nullptr, *dec_cos = nullptr, *part_val = nullptr, *cur_sin = nullptr, *cur_cos = nullptr;
@@ -129,22 +213,24 @@ struct mllm_hip_qwen2vl {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool use_graph = true;
+    // sampling scratch (generate_sampled)
+    float *samp_val = nullptr; int *samp_idx = nullptr; float *samp_prob = nullptr; void *sort_ws = nullptr; size_t sort_ws_bytes = 0;
     // state
     int cache_len = 0;
     float last_pos = -1.0f;
     int64_t decode_weight_bytes = 0;
+    float load_total_ms = 0, load_h2d_ms = 0, load_tail_ms = 0;
 
-    template <typename T> int dalloc(T **p, size_t n) {
+    template <typename T> int dalloc(T **p, size_t n, std::vector<void *> *list = nullptr) {
         void *q = nullptr;
         MH_CHECK(hipMalloc(&q, n ? n : 16));
-        allocs.push_back(q);
+        (list ? *list : allocs).push_back(q);
         *p = (T *)q;
         return 0;
     }
-    int upload(void *dst, const void *src, size_t n) { MH_CHECK(hipMemcpy(dst, src, n, hipMemcpyHostToDevice)); return 0; }
 };
 
-typedef mllm_hip_qwen2vl M;
+typedef mllm_hip_model M;
 
 static int need(const MllmFile &f, const std::string &n, const Entry **e, int dtype, uint64_t len) {
     *e = f.find(n);
@@ -159,11 +245,11 @@ static int load_f32(M *m, const MllmFile &f, const std::string &n, size_t count,
     const Entry *e;
     EH(need(f, n, &e, MLLM_HIP_F32, count * 4));
     EH(m->dalloc(out, count * 4));
-    return m->upload(*out, f.base + e->off, count * 4);
+    return m->ld.put(*out, f.base + e->off, count * 4);
 }
 
-// rows of several Q4_K Linear weights (same K) concatenated; biases concatenated (zeros where a part has none)
-static int load_linear_q4k(M *m, const MllmFile &f, const std::vector<std::string> &names, const std::vector<int> &Ns, int K, bool bias, LinearW *lw) {
+// rows of several Q4_K Linear weights (same K) concatenated; biases concatenated.  `decode`: also the decode-order copy for the fused decode kernels.
+static int load_linear_q4k(M *m, const MllmFile &f, const std::vector<std::string> &names, const std::vector<int> &Ns, int K, bool bias, bool decode, LinearW *lw) {
     int N = 0;
     for (int n : Ns) N += n;
     const size_t row = (size_t)K / 256 * 144;
@@ -173,153 +259,193 @@ static int load_linear_q4k(M *m, const MllmFile &f, const std::vector<std::strin
     for (size_t i = 0; i < names.size(); ++i) {
         const Entry *e;
         EH(need(f, names[i] + ".weight", &e, MLLM_HIP_Q4_K, row * Ns[i]));
-        EH(m->upload(w + ro * row, f.base + e->off, row * Ns[i]));
+        EH(m->ld.put(w + ro * row, f.base + e->off, row * Ns[i]));
         ro += Ns[i];
     }
-    lw->w = w; lw->N = N; lw->K = K; lw->dtype = MLLM_HIP_Q4_K;
-    {
-        uint8_t *wp;
-        EH(m->dalloc(&wp, mllm_hip_q4k_prepack_bytes(N, K)));
-        EH(mllm_hip_q4k_prepack(w, N, K, wp, m->st));
-        lw->wp = wp;
-    }
+    lw->w = w; lw->N = N; lw->K = K;
     if (bias) {
         EH(m->dalloc(&lw->bias, (size_t)N * 4));
         size_t bo = 0;
         for (size_t i = 0; i < names.size(); ++i) {
             const Entry *e;
             EH(need(f, names[i] + ".bias", &e, MLLM_HIP_F32, (uint64_t)Ns[i] * 4));
-            EH(m->upload(lw->bias + bo, f.base + e->off, (size_t)Ns[i] * 4));
+            EH(m->ld.put(lw->bias + bo, f.base + e->off, (size_t)Ns[i] * 4));
             bo += Ns[i];
         }
     }
-    return 0;
-}
-
-static int alloc_q8(M *m, Q8Planes *p, int M_, int K) {
-    EH(m->dalloc(&p->qs, (size_t)M_ * K));
-    EH(m->dalloc(&p->d, (size_t)M_ * (K / 256) * 4));
-    EH(m->dalloc(&p->bs, (size_t)M_ * (K / 16) * 2));
-    return 0;
-}
-
-extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const char *path, mllm_hip_qwen2vl **out) {
-    if (!cfg || !path || !out) return MLLM_HIP_ERR_ARG;
-    MllmFile f;
-    if (!f.open(path)) { fprintf(stderr, "mllm_hip: cannot open/parse %s\n", path); return MLLM_HIP_ERR_IO; }
-    M *m = new M();
-    m->c = *cfg;
-    const auto &c = m->c;
-    if (c.hidden % c.heads || c.hidden % 256 || c.inter % 256 || c.heads % c.kv_heads) { delete m; return MLLM_HIP_ERR_SHAPE; }
-    m->D = c.hidden / c.heads;
-    m->HD = c.heads * m->D;
-    m->KVD = c.kv_heads * m->D;
-    m->QKV = m->HD + 2 * m->KVD;
-    if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != m->D / 2) { delete m; return MLLM_HIP_ERR_SHAPE; }
-    int rc = 0;
-#define CK(expr) do { rc = (expr); if (rc) { mllm_hip_qwen2vl_destroy(m); return rc; } } while (0)
-    if (hipStreamCreate(&m->st) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess) {
-        mllm_hip_qwen2vl_destroy(m); return MLLM_HIP_ERR_HIP;
+    // load-time repacks on the compute stream, behind the copies of this tensor; the next tensor's copies run meanwhile
+    EH(m->ld.fence(m->st));
+    {
+        uint8_t *wp;
+        EH(m->dalloc(&wp, mllm_hip_q4k_prepack_bytes(N, K)));
+        EH(mllm_hip_q4k_prepack(w, N, K, wp, m->st));
+        lw->wp = wp;
     }
+    if (decode) {
+        const int64_t nblk = (int64_t)N * (K / 256);
+        uint8_t *wd = nullptr;
+        EH(m->dalloc(&wd, (size_t)nblk * 144));
+        EH(decode_order_q4k(w, wd, nblk, m->st));
+        lw->wd = wd;
+    }
+    return 0;
+}
+
+static int alloc_q8(M *m, Q8Planes *p, int M_, int K, std::vector<void *> *list = nullptr) {
+    EH(m->dalloc(&p->qs, (size_t)M_ * K, list));
+    EH(m->dalloc(&p->d, (size_t)M_ * (K / 256) * 4, list));
+    EH(m->dalloc(&p->bs, (size_t)M_ * (K / 16) * 2, list));
+    return 0;
+}
+
+static int load_vblock(M *m, const MllmFile &f, M::VBlock &B, const std::string &n1, const std::string &n2, const std::vector<std::string> &qkv,
+                       const std::string &proj, const std::string &fc1, const std::string &fc2, int V, int F) {
+    EH(load_f32(m, f, n1 + ".weight", V, &B.n1w)); EH(load_f32(m, f, n1 + ".bias", V, &B.n1b));
+    EH(load_f32(m, f, n2 + ".weight", V, &B.n2w)); EH(load_f32(m, f, n2 + ".bias", V, &B.n2b));
+    if (qkv.size() == 1) EH(load_linear_q4k(m, f, qkv, {3 * V}, V, true, false, &B.qkv));
+    else EH(load_linear_q4k(m, f, qkv, {V, V, V}, V, true, false, &B.qkv));
+    EH(load_linear_q4k(m, f, {proj}, {V}, V, true, false, &B.proj));
+    EH(load_linear_q4k(m, f, {fc1}, {F}, V, true, false, &B.fc1));
+    EH(load_linear_q4k(m, f, {fc2}, {V}, F, true, false, &B.fc2));
+    return 0;
+}
+
+static int create_impl(M *m, const MllmFile &f) {
+    const auto &c = m->c;
     const int H = c.hidden, I = c.inter;
     // ---- LLM ----
-    {
-        const Entry *e;
-        const uint64_t nblk = (uint64_t)c.vocab * (H / 32);
-        CK(need(f, "model.embed_tokens.weight", &e, MLLM_HIP_Q4_0, nblk * 18));
-        uint8_t *raw;
-        CK(m->dalloc(&raw, nblk * 18));
-        CK(m->upload(raw, f.base + e->off, nblk * 18));
-        CK(m->dalloc(&m->emb_qs, nblk * 16));
-        CK(m->dalloc(&m->emb_d, nblk * 2));
-        CK(mllm_hip_repack_q40(raw, m->emb_qs, m->emb_d, (int64_t)nblk, m->st));
-        CK(hipStreamSynchronize(m->st) == hipSuccess ? 0 : MLLM_HIP_ERR_HIP);
-        m->allocs.erase(std::find(m->allocs.begin(), m->allocs.end(), (void *)raw));
-        CK(hipFree(raw) == hipSuccess ? 0 : MLLM_HIP_ERR_HIP);
-        if (!c.tie_embedding) { fprintf(stderr, "mllm_hip: untied lm_head not implemented in this engine\n"); mllm_hip_qwen2vl_destroy(m); return MLLM_HIP_ERR_ARG; }
-    }
-    m->layers.resize(c.layers);
-    for (int i = 0; i < c.layers; ++i) {
-        auto &L = m->layers[i];
-        const std::string p = "model.layers." + std::to_string(i) + ".";
-        CK(load_f32(m, f, p + "input_layernorm.weight", H, &L.in_norm));
-        CK(load_f32(m, f, p + "post_attention_layernorm.weight", H, &L.post_norm));
-        CK(load_linear_q4k(m, f, {p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"}, {m->HD, m->KVD, m->KVD}, H, true, &L.qkv));
-        CK(load_linear_q4k(m, f, {p + "self_attn.o_proj"}, {H}, m->HD, false, &L.o));
-        CK(load_linear_q4k(m, f, {p + "mlp.gate_proj", p + "mlp.up_proj"}, {I, I}, H, false, &L.gu));
-        CK(load_linear_q4k(m, f, {p + "mlp.down_proj"}, {H}, I, false, &L.down));
-    }
-    CK(load_f32(m, f, "model.norm.weight", H, &m->final_norm));
-    m->decode_weight_bytes = (int64_t)c.layers * ((int64_t)(m->QKV + H) * (H / 256) * 144 + (int64_t)2 * I * (H / 256) * 144 + (int64_t)H * (I / 256) * 144)
-                             + (int64_t)c.vocab * (H / 32) * 18;
-    // ---- vision ----
-    m->has_vision = f.find("visual.patch_embed.proj.weight") != nullptr && c.v_dim > 0;
-    if (m->has_vision) {
-        const int V = c.v_dim, VM = 4 * V, PE = 3 * 2 * c.v_patch * c.v_patch, MM = V * c.v_merge * c.v_merge;
-        if (V % 256 || V % c.v_heads) { mllm_hip_qwen2vl_destroy(m); return MLLM_HIP_ERR_SHAPE; }
-        CK(load_f32(m, f, "visual.patch_embed.proj.weight", (size_t)V * PE, &m->patch_w));
-        m->vblocks.resize(c.v_blocks);
-        for (int i = 0; i < c.v_blocks; ++i) {
-            auto &B = m->vblocks[i];
-            const std::string p = "visual.blocks." + std::to_string(i) + ".";
-            CK(load_f32(m, f, p + "norm1.weight", V, &B.n1w)); CK(load_f32(m, f, p + "norm1.bias", V, &B.n1b));
-            CK(load_f32(m, f, p + "norm2.weight", V, &B.n2w)); CK(load_f32(m, f, p + "norm2.bias", V, &B.n2b));
-            CK(load_linear_q4k(m, f, {p + "attn.qkv"}, {3 * V}, V, true, &B.qkv));
-            CK(load_linear_q4k(m, f, {p + "attn.proj"}, {V}, V, true, &B.proj));
-            CK(load_linear_q4k(m, f, {p + "mlp.fc1"}, {VM}, V, true, &B.fc1));
-            CK(load_linear_q4k(m, f, {p + "mlp.fc2"}, {V}, VM, true, &B.fc2));
+    if (m->has_llm) {
+        const std::string &P = m->prefix;
+        {
+            const Entry *e;
+            const uint64_t nblk = (uint64_t)c.vocab * (H / 32);
+            EH(need(f, P + "model.embed_tokens.weight", &e, MLLM_HIP_Q4_0, nblk * 18));
+            uint8_t *raw;
+            EH(m->dalloc(&raw, nblk * 18, &m->temps));
+            EH(m->ld.put(raw, f.base + e->off, nblk * 18));
+            EH(m->dalloc(&m->emb_qs, nblk * 16));
+            EH(m->dalloc(&m->emb_d, nblk * 2));
+            EH(m->ld.fence(m->st));
+            EH(mllm_hip_repack_q40(raw, m->emb_qs, m->emb_d, (int64_t)nblk, m->st));
         }
-        CK(load_f32(m, f, "visual.merger.ln_q.weight", V, &m->lnq_w)); CK(load_f32(m, f, "visual.merger.ln_q.bias", V, &m->lnq_b));
-        CK(load_linear_q4k(m, f, {"visual.merger.mlp.0"}, {MM}, MM, true, &m->m0));
-        CK(load_linear_q4k(m, f, {"visual.merger.mlp.2"}, {H}, MM, true, &m->m2));
+        m->layers.resize(c.layers);
+        for (int i = 0; i < c.layers; ++i) {
+            auto &L = m->layers[i];
+            const std::string p = P + "model.layers." + std::to_string(i) + ".";
+            EH(load_f32(m, f, p + "input_layernorm.weight", H, &L.in_norm));
+            EH(load_f32(m, f, p + "post_attention_layernorm.weight", H, &L.post_norm));
+            EH(load_linear_q4k(m, f, {p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"}, {m->HD, m->KVD, m->KVD}, H, c.qkv_bias != 0, true, &L.qkv));
+            EH(load_linear_q4k(m, f, {p + "self_attn.o_proj"}, {H}, m->HD, false, true, &L.o));
+            EH(load_linear_q4k(m, f, {p + "mlp.gate_proj", p + "mlp.up_proj"}, {I, I}, H, false, true, &L.gu));
+            EH(load_linear_q4k(m, f, {p + "mlp.down_proj"}, {H}, I, false, true, &L.down));
+        }
+        EH(load_f32(m, f, P + "model.norm.weight", H, &m->final_norm));
+        m->decode_weight_bytes = (int64_t)c.layers * ((int64_t)(m->QKV + H) * (H / 256) * 144 + (int64_t)2 * I * (H / 256) * 144 + (int64_t)H * (I / 256) * 144);
+        if (c.tie_embedding) {
+            m->decode_weight_bytes += (int64_t)c.vocab * (H / 32) * 18;
+        } else {
+            EH(load_linear_q4k(m, f, {P + "lm_head"}, {c.vocab}, H, false, true, &m->head));
+            m->decode_weight_bytes += (int64_t)c.vocab * (H / 256) * 144;
+        }
+    }
+    // ---- vision ----
+    if (m->vkind != V_NONE) {
+        const int V = c.v_dim;
+        if (m->vkind == V_QWEN2VL) {
+            const int VM = 4 * V, PE = 3 * 2 * c.v_patch * c.v_patch, MM = V * c.v_merge * c.v_merge;
+            EH(load_f32(m, f, "visual.patch_embed.proj.weight", (size_t)V * PE, &m->patch_w));
+            m->vblocks.resize(c.v_blocks);
+            for (int i = 0; i < c.v_blocks; ++i) {
+                const std::string p = "visual.blocks." + std::to_string(i) + ".";
+                EH(load_vblock(m, f, m->vblocks[i], p + "norm1", p + "norm2", {p + "attn.qkv"}, p + "attn.proj", p + "mlp.fc1", p + "mlp.fc2", V, VM));
+            }
+            EH(load_f32(m, f, "visual.merger.ln_q.weight", V, &m->lnq_w)); EH(load_f32(m, f, "visual.merger.ln_q.bias", V, &m->lnq_b));
+            EH(load_linear_q4k(m, f, {"visual.merger.mlp.0"}, {MM}, MM, true, false, &m->m0));
+            EH(load_linear_q4k(m, f, {"visual.merger.mlp.2"}, {H}, MM, true, false, &m->m2));
+        } else {
+            const bool clip = m->vkind == V_CLIP;
+            const int F = c.v_ffn, KK = 3 * c.v_patch * c.v_patch, NP = (c.v_img / c.v_patch) * (c.v_img / c.v_patch) + 1;
+            // names: ViTNameConfig "clip" / "vit" (models/vit/configuration_vit.hpp:27-64)
+            const std::string base = clip ? "vision_tower.vision_model." : "vit.", e = base + "embeddings.";
+            EH(load_f32(m, f, e + (clip ? "patch_embedding.weight" : "patch_embeddings.projection.weight"), (size_t)V * KK, &m->patch_w));
+            if (!clip) EH(load_f32(m, f, e + "patch_embeddings.projection.bias", V, &m->patch_b));
+            EH(load_f32(m, f, e + (clip ? "class_embedding" : "cls_token"), V, &m->cls_tok));
+            EH(load_f32(m, f, e + (clip ? "position_embedding.weight" : "position_embeddings"), (size_t)NP * V, &m->pos_emb));
+            if (clip) { EH(load_f32(m, f, base + "pre_layrnorm.weight", V, &m->pre_w)); EH(load_f32(m, f, base + "pre_layrnorm.bias", V, &m->pre_b)); }
+            m->vblocks.resize(c.v_blocks);
+            for (int i = 0; i < c.v_blocks; ++i) {
+                if (clip) {
+                    const std::string p = base + "encoder.layers." + std::to_string(i) + ".";
+                    EH(load_vblock(m, f, m->vblocks[i], p + "layer_norm1", p + "layer_norm2", {p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"},
+                                   p + "self_attn.out_proj", p + "mlp.fc1", p + "mlp.fc2", V, F));
+                } else {
+                    const std::string p = base + "encoder.layer." + std::to_string(i) + ".";
+                    EH(load_vblock(m, f, m->vblocks[i], p + "layernorm_before", p + "layernorm_after",
+                                   {p + "attention.attention.query", p + "attention.attention.key", p + "attention.attention.value"}, p + "attention.output.dense",
+                                   p + "intermediate.dense", p + "output.dense", V, F));
+                }
+            }
+            if (clip) {
+                EH(load_linear_q4k(m, f, {"multi_modal_projector.linear_1"}, {F}, V, true, false, &m->m0));
+                EH(load_linear_q4k(m, f, {"multi_modal_projector.linear_2"}, {F}, F, true, false, &m->m2));
+            } else {
+                EH(load_f32(m, f, "vit.layernorm.weight", V, &m->lnq_w)); EH(load_f32(m, f, "vit.layernorm.bias", V, &m->lnq_b));
+                EH(load_linear_q4k(m, f, {"classifier"}, {c.v_classes}, V, false, false, &m->m0));
+            }
+        }
         std::vector<uint16_t> g(65536), q(65536);
         mllm_hip_build_act_luts(g.data(), q.data());
-        CK(m->dalloc(&m->lut_gelu, 65536 * 2)); CK(m->dalloc(&m->lut_qgelu, 65536 * 2));
-        CK(m->upload(m->lut_gelu, g.data(), 65536 * 2)); CK(m->upload(m->lut_qgelu, q.data(), 65536 * 2));
+        EH(m->dalloc(&m->lut_gelu, 65536 * 2)); EH(m->dalloc(&m->lut_qgelu, 65536 * 2));
+        HH(hipMemcpy(m->lut_gelu, g.data(), 65536 * 2, hipMemcpyHostToDevice)); HH(hipMemcpy(m->lut_qgelu, q.data(), 65536 * 2, hipMemcpyHostToDevice));
+        for (int b = 0; b < 2; ++b) { HH(hipEventCreateWithFlags(&m->vup[b], hipEventDisableTiming)); HH(hipEventCreateWithFlags(&m->vfree[b], hipEventDisableTiming)); }
     }
-    // ---- activations ----
+    if (!m->has_llm) return 0;
+    // ---- LLM activations ----
     const int T = c.cache_limit;
     m->max_tok = T;
-    CK(m->dalloc(&m->h0, (size_t)T * H * 4)); CK(m->dalloc(&m->h1, (size_t)T * H * 4));
-    CK(m->dalloc(&m->qkv, (size_t)T * m->QKV * 4)); CK(m->dalloc(&m->attn, (size_t)T * m->HD * 4));
-    CK(m->dalloc(&m->gu, (size_t)T * 2 * I * 4)); CK(m->dalloc(&m->act, (size_t)T * I * 4));
-    CK(m->dalloc(&m->logits, (size_t)c.vocab * 4)); CK(m->dalloc(&m->normed, (size_t)H * 4));
-    CK(m->dalloc(&m->ids_f, (size_t)T * 4)); CK(m->dalloc(&m->idx_i, (size_t)T * 4)); CK(m->dalloc(&m->tok_dev, 16));
-    CK(alloc_q8(m, &m->xq, T, H > m->HD ? H : m->HD)); CK(alloc_q8(m, &m->xq2, T, I));
-    CK(m->dalloc(&m->x80_qs, (size_t)H)); CK(m->dalloc(&m->x80_d, (size_t)(H / 32) * 2));
-    CK(m->dalloc(&m->rope_sin, (size_t)T * (m->D / 2) * 4)); CK(m->dalloc(&m->rope_cos, (size_t)T * (m->D / 2) * 4));
-    // + 64 rows: the decode attention reads whole 64-key splits speculatively
-    // K slab [layers][T][KVD] (the reference's BSHD cache rows); V slab transposed [layers][KVD][vt_ld], vt_ld = T rounded up + 128 keys
-    // of zero padding (the decode walk over-reads whole 16-byte vectors; prefill reads 4 keys at a time)
+    EH(m->dalloc(&m->h0, (size_t)T * H * 4)); EH(m->dalloc(&m->h1, (size_t)T * H * 4));
+    EH(m->dalloc(&m->qkv, (size_t)T * m->QKV * 4)); EH(m->dalloc(&m->attn, (size_t)T * m->HD * 4));
+    EH(m->dalloc(&m->gu, (size_t)T * 2 * I * 4)); EH(m->dalloc(&m->act, (size_t)T * I * 4));
+    EH(m->dalloc(&m->logits, (size_t)c.vocab * 4)); EH(m->dalloc(&m->normed, (size_t)H * 4));
+    EH(m->dalloc(&m->ids_f, (size_t)T * 4)); EH(m->dalloc(&m->idx_i, (size_t)T * 4)); EH(m->dalloc(&m->tok_dev, 16));
+    EH(alloc_q8(m, &m->xq, T, H > m->HD ? H : m->HD)); EH(alloc_q8(m, &m->xq2, T, I));
+    EH(m->dalloc(&m->x80_qs, (size_t)H)); EH(m->dalloc(&m->x80_d, (size_t)(H / 32) * 2));
+    EH(m->dalloc(&m->rope_sin, (size_t)T * (m->D / 2) * 4)); EH(m->dalloc(&m->rope_cos, (size_t)T * (m->D / 2) * 4));
+    if (!m->mrope) {
+        // CPURoPE's static table (CPURoPE.cpp:100-128) for every position the cache can hold; the two halves of a row are equal, half is kept
+        std::vector<float> s((size_t)T * m->D), co((size_t)T * m->D);
+        EH(mllm_hip_rope_table_hf(c.rope_theta, m->D, T, s.data(), co.data()));
+        const int half = m->D / 2;
+        m->hf_sin.resize((size_t)T * half); m->hf_cos.resize((size_t)T * half);
+        for (int p = 0; p < T; ++p)
+            for (int i = 0; i < half; ++i) { m->hf_sin[(size_t)p * half + i] = s[(size_t)p * m->D + i]; m->hf_cos[(size_t)p * half + i] = co[(size_t)p * m->D + i]; }
+    }
+    // K slab [layers][T][KVD] (the reference's BSHD cache rows; + 64 rows: the decode attention reads whole key splits speculatively); V slab
+    // transposed [layers][KVD][vt_ld], vt_ld = T rounded up + 128 keys of zero padding (the decode walk over-reads whole 16-byte vectors)
     m->vt_ld = ((T + 63) & ~63) + 128;
-    CK(m->dalloc(&m->kslab, ((size_t)c.layers * T + 64) * m->KVD * 2)); CK(m->dalloc(&m->vslab, (size_t)c.layers * m->KVD * m->vt_ld * 2));
-    CK(hipMemset(m->kslab, 0, ((size_t)c.layers * T + 64) * m->KVD * 2) == hipSuccess ? 0 : MLLM_HIP_ERR_HIP);
-    CK(hipMemset(m->vslab, 0, (size_t)c.layers * m->KVD * m->vt_ld * 2) == hipSuccess ? 0 : MLLM_HIP_ERR_HIP);
+    EH(m->dalloc(&m->kslab, ((size_t)c.layers * T + 64) * m->KVD * 2)); EH(m->dalloc(&m->vslab, (size_t)c.layers * m->KVD * m->vt_ld * 2));
+    HH(hipMemsetAsync(m->kslab, 0, ((size_t)c.layers * T + 64) * m->KVD * 2, m->st));
+    HH(hipMemsetAsync(m->vslab, 0, (size_t)c.layers * m->KVD * m->vt_ld * 2, m->st));
     m->nsplit = (T + 63) / 64;
     {
         size_t wsb = mllm_hip_fa2_workspace_bytes(1, c.heads, m->D, T), wsd = (size_t)c.heads * m->nsplit * 136 * 4;
-        CK(m->dalloc((uint8_t **)&m->fa_ws, wsb > wsd ? wsb : wsd));
+        wsb = std::max(std::max(wsb, wsd), (size_t)m->HD * 4);
+        EH(m->dalloc((uint8_t **)&m->fa_ws, wsb));
     }
-    CK(m->dalloc(&m->d_state, sizeof(DecodeState)));
-    CK(m->dalloc(&m->dec_sin, (size_t)T * (m->D / 2) * 4)); CK(m->dalloc(&m->dec_cos, (size_t)T * (m->D / 2) * 4));
-    CK(m->dalloc(&m->cur_sin, (size_t)m->D * 4)); CK(m->dalloc(&m->cur_cos, (size_t)m->D * 4));
-    CK(m->dalloc(&m->part_val, (size_t)m->max_parts * 4)); CK(m->dalloc(&m->part_idx, (size_t)m->max_parts * 4));
-    CK(m->dalloc(&m->history, (size_t)T * 4));
+    EH(m->dalloc(&m->d_state, sizeof(DecodeState)));
+    EH(m->dalloc(&m->dec_sin, (size_t)T * (m->D / 2) * 4)); EH(m->dalloc(&m->dec_cos, (size_t)T * (m->D / 2) * 4));
+    EH(m->dalloc(&m->cur_sin, (size_t)m->D * 4)); EH(m->dalloc(&m->cur_cos, (size_t)m->D * 4));
+    EH(m->dalloc(&m->part_val, (size_t)m->max_parts * 4)); EH(m->dalloc(&m->part_idx, (size_t)m->max_parts * 4));
+    EH(m->dalloc(&m->history, (size_t)T * 4));
     {
         DecodeCtx &d = m->dctx;
         d.state = m->d_state; d.H = H; d.I = I; d.heads = c.heads; d.kv_heads = c.kv_heads; d.D = m->D; d.vocab = c.vocab; d.cache_limit = T;
-        d.nsplit = m->nsplit; d.max_parts = m->max_parts; d.eps = c.rms_eps; d.emb_qs = m->emb_qs; d.emb_d = m->emb_d; d.final_norm = m->final_norm;
+        d.nsplit = m->nsplit; d.max_parts = m->max_parts; d.eps = c.rms_eps; d.final_eps = c.final_eps; d.emb_qs = m->emb_qs; d.emb_d = m->emb_d; d.final_norm = m->final_norm;
+        d.Whead = (const uint8_t *)m->head.wd;
         d.x0 = m->h0; d.x1 = m->h1; d.qkv = m->qkv; d.act = m->act; d.logits = m->logits; d.fa_ws = (float *)m->fa_ws; d.part_val = m->part_val;
         d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos; d.cur_sin = m->cur_sin; d.cur_cos = m->cur_cos;
         d.kslab = m->kslab; d.vslab = m->vslab; d.vt_ld = m->vt_ld; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
         for (auto &L : m->layers) {
-            for (LinearW *lw : {&L.qkv, &L.o, &L.gu, &L.down}) {
-                const int64_t nblk = (int64_t)lw->N * (lw->K / 256);
-                uint8_t *wd = nullptr;
-                CK(m->dalloc(&wd, (size_t)nblk * 144));
-                CK(decode_order_q4k(lw->w, wd, nblk, m->st));
-                lw->wd = wd;
-            }
             DecodeLayer dl;
             dl.in_norm = L.in_norm; dl.post_norm = L.post_norm; dl.Wqkv = (const uint8_t *)L.qkv.wd; dl.bqkv = L.qkv.bias; dl.qkv_N = L.qkv.N;
             dl.Wo = (const uint8_t *)L.o.wd; dl.Wgu = (const uint8_t *)L.gu.wd; dl.Wdown = (const uint8_t *)L.down.wd;
@@ -328,28 +454,102 @@ extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *cfg, const
         }
         m->use_graph = getenv("MLLM_HIP_NO_GRAPH") == nullptr;
     }
-    *out = m;
-    return MLLM_HIP_OK;
-#undef CK
+    return 0;
 }
 
-extern "C" void mllm_hip_qwen2vl_destroy(mllm_hip_qwen2vl *m) {
+extern "C" int mllm_hip_model_create(const mllm_hip_model_config *cfg, const char *path, mllm_hip_model **out) {
+    if (!cfg || !path || !out) return MLLM_HIP_ERR_ARG;
+    const auto &c0 = *cfg;
+    if (c0.arch < MLLM_HIP_ARCH_QWEN2VL || c0.arch > MLLM_HIP_ARCH_VIT) return MLLM_HIP_ERR_ARG;
+    const bool has_llm = c0.arch != MLLM_HIP_ARCH_VIT;
+    const int vkind = c0.v_dim <= 0 ? V_NONE : (c0.arch == MLLM_HIP_ARCH_QWEN2VL ? V_QWEN2VL : (c0.arch == MLLM_HIP_ARCH_LLAVA ? V_CLIP : (c0.arch == MLLM_HIP_ARCH_VIT ? V_VIT : V_NONE)));
+    // everything the kernels divide by or index with is validated here, before any file or device work (ERR_ARG: nonsense, ERR_SHAPE: unsupported)
+    if (has_llm) {
+        if (c0.hidden <= 0 || c0.inter <= 0 || c0.layers <= 0 || c0.heads <= 0 || c0.kv_heads <= 0 || c0.vocab <= 0 || c0.cache_limit <= 0) return MLLM_HIP_ERR_ARG;
+        if (c0.hidden % c0.heads || c0.hidden % 256 || c0.inter % 256 || c0.heads % c0.kv_heads) return MLLM_HIP_ERR_SHAPE;
+        const int D = c0.hidden / c0.heads;
+        if (D != 64 && D != 128) return MLLM_HIP_ERR_SHAPE;                     // the decode attention is built for these head sizes
+        if (c0.hidden > 6 * 2048 || c0.inter > 6 * 2048) return MLLM_HIP_ERR_SHAPE;   // GEMV row forms: at most 48 super-blocks per row
+        if (c0.arch == MLLM_HIP_ARCH_QWEN2VL && c0.mrope_section[0] + c0.mrope_section[1] + c0.mrope_section[2] != D / 2) return MLLM_HIP_ERR_SHAPE;
+    } else if (vkind == V_NONE) return MLLM_HIP_ERR_ARG;
+    if (vkind != V_NONE) {
+        if (c0.v_heads <= 0 || c0.v_blocks <= 0 || c0.v_patch <= 0) return MLLM_HIP_ERR_ARG;
+        if (c0.v_dim % 256 || c0.v_dim % c0.v_heads) return MLLM_HIP_ERR_SHAPE;
+        const int VD = c0.v_dim / c0.v_heads;
+        if (VD != 16 && VD != 64 && VD != 80 && VD != 128) return MLLM_HIP_ERR_SHAPE;     // head sizes mllm_hip_fa2 is instantiated for
+        if (vkind == V_QWEN2VL) { if (c0.v_merge <= 0) return MLLM_HIP_ERR_ARG; }
+        else {
+            if (c0.v_ffn <= 0 || c0.v_img <= 0 || c0.v_img % c0.v_patch || c0.v_ffn % 256) return MLLM_HIP_ERR_SHAPE;
+            if (vkind == V_VIT && c0.v_classes <= 0) return MLLM_HIP_ERR_ARG;
+            if (vkind == V_CLIP && c0.v_ffn != c0.hidden) return MLLM_HIP_ERR_SHAPE;   // linear_2 is v_ffn x v_ffn and feeds the text embedding rows
+        }
+    }
+    MllmFile f;
+    if (!f.open(path)) { fprintf(stderr, "mllm_hip: cannot open/parse %s (missing, truncated or corrupt index)\n", path); return MLLM_HIP_ERR_IO; }
+    const auto t0 = std::chrono::steady_clock::now();
+    M *m = new M();
+    m->c = *cfg;
+    m->has_llm = has_llm;
+    m->vkind = vkind;
+    m->mrope = c0.arch == MLLM_HIP_ARCH_QWEN2VL;
+    m->prefix = c0.arch == MLLM_HIP_ARCH_LLAVA ? "language_model." : "";
+    if (has_llm) {
+        m->D = c0.hidden / c0.heads;
+        m->HD = c0.heads * m->D;
+        m->KVD = c0.kv_heads * m->D;
+        m->QKV = m->HD + 2 * m->KVD;
+    }
+    if (hipStreamCreate(&m->st) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess || m->ld.init() != 0) {
+        mllm_hip_model_destroy(m); return MLLM_HIP_ERR_HIP;
+    }
+    int rc = create_impl(m, f);
+    if (!rc) rc = m->ld.finish(&m->load_h2d_ms);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (!rc && hipStreamSynchronize(m->st) != hipSuccess) rc = MLLM_HIP_ERR_HIP;
+    const auto t2 = std::chrono::steady_clock::now();
+    for (void *p : m->temps) (void)hipFree(p);
+    m->temps.clear();
+    m->ld.destroy();                      // the pinned staging buffers are only needed during the load
+    if (rc) { mllm_hip_model_destroy(m); return rc; }
+    m->load_total_ms = std::chrono::duration<float, std::milli>(t2 - t0).count();
+    m->load_tail_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
+    *out = m;
+    return MLLM_HIP_OK;
+}
+
+extern "C" int mllm_hip_model_load_stats(const mllm_hip_model *m, float *total_ms, int64_t *file_bytes, float *h2d_ms, float *repack_ms) {
+    if (!m) return MLLM_HIP_ERR_ARG;
+    if (total_ms) *total_ms = m->load_total_ms;
+    if (file_bytes) *file_bytes = m->ld.bytes;
+    if (h2d_ms) *h2d_ms = m->load_h2d_ms;
+    if (repack_ms) *repack_ms = m->load_tail_ms;     // repack work left on the compute stream after the last copy had landed (the part not overlapped)
+    return MLLM_HIP_OK;
+}
+
+extern "C" void mllm_hip_model_destroy(mllm_hip_model *m) {
     if (!m) return;
     // teardown: nothing useful can be done with a failing release, the codes are dropped on purpose
+    if (m->st) (void)hipStreamSynchronize(m->st);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->graph) (void)hipGraphDestroy(m->graph);
     for (void *p : m->allocs) (void)hipFree(p);
+    for (void *p : m->vis_allocs) (void)hipFree(p);
+    for (void *p : m->temps) (void)hipFree(p);
     if (m->xpack) (void)hipFree(m->xpack);
+    if (m->sort_ws) (void)hipFree(m->sort_ws);
+    if (m->pin_img) (void)hipHostFree(m->pin_img);
+    m->ld.destroy();
+    for (int b = 0; b < 2; ++b) { if (m->vup[b]) (void)hipEventDestroy(m->vup[b]); if (m->vfree[b]) (void)hipEventDestroy(m->vfree[b]); }
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->st) (void)hipStreamDestroy(m->st);
     delete m;
 }
-extern "C" int mllm_hip_qwen2vl_clear_kvcache(mllm_hip_qwen2vl *m) { m->cache_len = 0; m->last_pos = -1.0f; return MLLM_HIP_OK; }
-extern "C" int64_t mllm_hip_qwen2vl_decode_weight_bytes(const mllm_hip_qwen2vl *m) { return m->decode_weight_bytes; }
-extern "C" void *mllm_hip_qwen2vl_stream(mllm_hip_qwen2vl *m) { return (void *)m->st; }
+extern "C" int mllm_hip_model_clear_kvcache(mllm_hip_model *m) { if (!m) return MLLM_HIP_ERR_ARG; m->cache_len = 0; m->last_pos = -1.0f; return MLLM_HIP_OK; }
+extern "C" int64_t mllm_hip_model_decode_weight_bytes(const mllm_hip_model *m) { return m ? m->decode_weight_bytes : 0; }
+extern "C" void *mllm_hip_model_stream(mllm_hip_model *m) { return m ? (void *)m->st : nullptr; }
 // bring-up aid (not part of include/mllm_hip.h): device pointers of the prefill activations, 0 h0, 1 h1, 2 qkv, 3 attn, 4 gate|up, 5 act
-extern "C" void *mllm_hip_qwen2vl_debug_ptr(mllm_hip_qwen2vl *m, int which) {
+extern "C" void *mllm_hip_qwen2vl_debug_ptr(mllm_hip_model *m, int which) {
     switch (which) { case 0: return m->h0; case 1: return m->h1; case 2: return m->qkv; case 3: return m->attn; case 4: return m->gu; case 5: return m->act; case 6: return m->kslab; case 7: return m->vslab; case 8: return m->logits; }
     return nullptr;
 }
@@ -440,87 +640,166 @@ static int lin(M *m, const LinearW &w, const Q8Planes &x, void *y, int ydt, int6
     return mllm_hip_linear_q4k_q8k(w.w, w.bias, x.qs, x.d, x.bs, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
 }
 
-// Qwen2VisionModel::Forward for one image already resident in m->vpix ([N][PE]); writes [N/merge^2][hidden] to `out`
-static int forward_vision(M *m, const int32_t *grid, float *out) {
+// tokens / output rows of one image's tower for this config
+static void vision_dims(const M *m, const int32_t *meta, int *n_tok, int *out_rows, int *out_cols, size_t *img_elems) {
     const auto &c = m->c;
-    const int N = grid[0] * grid[1] * grid[2], V = c.v_dim, VM = 4 * V, PE = 3 * 2 * c.v_patch * c.v_patch;
-    const int VD = V / c.v_heads, MM = V * c.v_merge * c.v_merge, NT = N / (c.v_merge * c.v_merge);
-    hipStream_t st = m->st;
-    {   // rotary tables (CPUVisionRoPE): rot_dim = head_dim/2
-        std::vector<float> s((size_t)N * (VD / 2)), co((size_t)N * (VD / 2));
-        EH(mllm_hip_vision_rope_table(grid[0], grid[1], grid[2], c.v_merge, VD / 2, s.data(), co.data()));
-        HH(hipMemcpyAsync(m->vsin, s.data(), s.size() * 4, hipMemcpyHostToDevice, st));
-        HH(hipMemcpyAsync(m->vcos, co.data(), co.size() * 4, hipMemcpyHostToDevice, st));
-        HH(hipStreamSynchronize(st));
+    if (m->vkind == V_QWEN2VL) {
+        const int N = meta[0] * meta[1] * meta[2];
+        *n_tok = N; *out_rows = N / (c.v_merge * c.v_merge); *out_cols = c.hidden; *img_elems = (size_t)N * 3 * 2 * c.v_patch * c.v_patch;
+    } else {
+        const int g = c.v_img / c.v_patch;
+        *n_tok = g * g + 1; *img_elems = (size_t)c.v_img * 3 * c.v_img;
+        if (m->vkind == V_CLIP) { *out_rows = g * g; *out_cols = c.v_ffn; } else { *out_rows = 1; *out_cols = c.v_classes; }
     }
-    EH(mllm_hip_patch_gemm_f32(m->vpix, m->patch_w, nullptr, m->vx, N, PE, V, st));
+}
+extern "C" int mllm_hip_model_vision_shape(const mllm_hip_model *m, const int32_t *image_meta, int *rows, int *cols) {
+    if (!m || m->vkind == V_NONE || (m->vkind == V_QWEN2VL && !image_meta)) return MLLM_HIP_ERR_ARG;
+    int nt, r, cc; size_t ie;
+    vision_dims(m, image_meta, &nt, &r, &cc, &ie);
+    if (rows) *rows = r;
+    if (cols) *cols = cc;
+    return MLLM_HIP_OK;
+}
+
+// VisionBlock (modeling_qwen2_vl.hpp:116-140) / ViTBlock (modeling_vit.hpp:31-61): LN -> qkv -> [2-D rotary] -> FlashAttention2 (non-causal, fp32 K/V)
+// -> proj + x -> LN -> fc1 -> act (fp16 LUT) -> fc2 + residual.  x in m->vx (N rows), result back in m->vx.
+static int vision_blocks(M *m, int N, float ln_eps, const uint16_t *lut, bool rope) {
+    const auto &c = m->c;
+    const int V = c.v_dim, VD = V / c.v_heads;
+    hipStream_t st = m->st;
     float *x = m->vx, *r = m->vr;
     for (auto &B : m->vblocks) {
-        EH(q_layernorm(m, x, B.n1w, B.n1b, m->xq, N, V, 1e-6f));
-        EH(lin(m, B.qkv, m->xq, m->vqkv, MLLM_HIP_F32, 3 * V, nullptr, N));
+        const int F = B.fc1.N;
+        EH(q_layernorm(m, x, B.n1w, B.n1b, m->vxq, N, V, ln_eps));
+        EH(lin(m, B.qkv, m->vxq, m->vqkv, MLLM_HIP_F32, 3 * V, nullptr, N));
         // q and k are columns [0, 2V) of the same rows: one launch over 2 * heads heads rotates both in place
-        EH(mllm_hip_rope_apply(m->vqkv, 3 * V, m->vsin, m->vcos, VD / 2, m->vqkv, MLLM_HIP_F32, 3 * V, N, 2 * c.v_heads, VD, st));
+        if (rope) EH(mllm_hip_rope_apply(m->vqkv, 3 * V, m->vsin, m->vcos, VD / 2, m->vqkv, MLLM_HIP_F32, 3 * V, N, 2 * c.v_heads, VD, st));
         EH(mllm_hip_fa2(m->vqkv, 3 * V, m->vqkv + V, 3 * V, m->vqkv + 2 * V, 3 * V, MLLM_HIP_F32, m->vattn, V, N, N, c.v_heads, c.v_heads, VD, 0,
                         nullptr, nullptr, st));
-        EH(q_quant(m, m->vattn, m->xq, N, V));
-        EH(lin(m, B.proj, m->xq, r, MLLM_HIP_F32, V, x, N));                       // residual = proj(attn) + x
-        EH(q_layernorm(m, r, B.n2w, B.n2b, m->xq, N, V, 1e-6f));
-        EH(lin(m, B.fc1, m->xq, m->vfc, MLLM_HIP_F32, VM, nullptr, N));
-        EH(q_act_quant(m, m->vfc, m->vact, m->lut_qgelu, m->xq2, N, VM));
-        EH(lin(m, B.fc2, m->xq2, x, MLLM_HIP_F32, V, r, N));                        // x = fc2(act) + residual
+        EH(q_quant(m, m->vattn, m->vxq, N, V));
+        EH(lin(m, B.proj, m->vxq, r, MLLM_HIP_F32, V, x, N));                       // residual = proj(attn) + x
+        EH(q_layernorm(m, r, B.n2w, B.n2b, m->vxq, N, V, ln_eps));
+        EH(lin(m, B.fc1, m->vxq, m->vfc, MLLM_HIP_F32, F, nullptr, N));
+        EH(q_act_quant(m, m->vfc, m->vact, lut, m->vxq2, N, F));
+        EH(lin(m, B.fc2, m->vxq2, x, MLLM_HIP_F32, V, r, N));                        // x = fc2(act) + residual
     }
-    // PatchMerger: ln_q -> view [NT][MM] -> mlp.0 -> GELU -> mlp.2
-    EH(mllm_hip_layernorm(x, m->lnq_w, m->lnq_b, r, nullptr, nullptr, nullptr, N, V, 1e-6f, st));
-    EH(q_quant(m, r, m->xq2, NT, MM));
-    EH(lin(m, m->m0, m->xq2, m->vm0, MLLM_HIP_F32, MM, nullptr, NT));
-    EH(q_act_quant(m, m->vm0, m->vfc, m->lut_gelu, m->xq2, NT, MM));
-    EH(lin(m, m->m2, m->xq2, out, MLLM_HIP_F32, c.hidden, nullptr, NT));
     return 0;
 }
 
-static int ensure_vision_buffers(M *m, int N) {
-    if (N <= m->max_patch) return 0;
+// One image already resident in `pix` (QWEN2VL: [N][PE] patches; CLIP / VIT: [H][C][W]); writes the tower's output rows to `out` (device)
+static int forward_vision(M *m, const float *pix, const int32_t *meta, float *out) {
     const auto &c = m->c;
-    const int V = c.v_dim, VM = 4 * V, PE = 3 * 2 * c.v_patch * c.v_patch, MM = V * c.v_merge * c.v_merge, NT = N / (c.v_merge * c.v_merge);
+    const int V = c.v_dim;
+    hipStream_t st = m->st;
+    if (m->vkind == V_QWEN2VL) {
+        const int N = meta[0] * meta[1] * meta[2], PE = 3 * 2 * c.v_patch * c.v_patch;
+        const int VD = V / c.v_heads, MM = V * c.v_merge * c.v_merge, NT = N / (c.v_merge * c.v_merge);
+        {   // rotary tables (CPUVisionRoPE): rot_dim = head_dim/2
+            std::vector<float> s((size_t)N * (VD / 2)), co((size_t)N * (VD / 2));
+            EH(mllm_hip_vision_rope_table(meta[0], meta[1], meta[2], c.v_merge, VD / 2, s.data(), co.data()));
+            HH(hipMemcpyAsync(m->vsin, s.data(), s.size() * 4, hipMemcpyHostToDevice, st));
+            HH(hipMemcpyAsync(m->vcos, co.data(), co.size() * 4, hipMemcpyHostToDevice, st));
+            HH(hipStreamSynchronize(st));
+        }
+        EH(mllm_hip_patch_gemm_f32(pix, m->patch_w, nullptr, m->vx, N, PE, V, st));
+        EH(vision_blocks(m, N, 1e-6f, m->lut_qgelu, true));
+        // PatchMerger: ln_q -> view [NT][MM] -> mlp.0 -> GELU -> mlp.2
+        EH(mllm_hip_layernorm(m->vx, m->lnq_w, m->lnq_b, m->vr, nullptr, nullptr, nullptr, N, V, 1e-6f, st));
+        EH(q_quant(m, m->vr, m->vxq2, NT, MM));
+        EH(lin(m, m->m0, m->vxq2, m->vm0, MLLM_HIP_F32, MM, nullptr, NT));
+        EH(q_act_quant(m, m->vm0, m->vfc, m->lut_gelu, m->vxq2, NT, MM));
+        EH(lin(m, m->m2, m->vxq2, out, MLLM_HIP_F32, c.hidden, nullptr, NT));
+        return 0;
+    }
+    // LLaVAVisionEmbedding (modeling_llava.hpp:39-60) / ViTEmbedding (modeling_vit.hpp:63-83): Conv2D patch embedding as im2patch + GEMM over the
+    // receptive fields; row 0 = the class token; + position rows (an Embedding over 0..N-1 / a Parameter: both a plain row-wise add)
+    const int g = c.v_img / c.v_patch, NP = g * g, N = NP + 1, KK = 3 * c.v_patch * c.v_patch, F = c.v_ffn;
+    EH(mllm_hip_im2patch_hcw(pix, m->vpatch, c.v_img, 3, c.v_img, c.v_patch, st));
+    EH(mllm_hip_patch_gemm_f32(m->vpatch, m->patch_w, m->patch_b, m->vr + V, NP, KK, V, st));
+    HH(hipMemcpyAsync(m->vr, m->cls_tok, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
+    EH(mllm_hip_add(m->pos_emb, m->vr, m->vx, (int64_t)N * V, st));
+    if (m->vkind == V_CLIP) {
+        EH(mllm_hip_layernorm(m->vx, m->pre_w, m->pre_b, m->vr, nullptr, nullptr, nullptr, N, V, 1e-6f, st));       // pre_layrnorm (:69)
+        HH(hipMemcpyAsync(m->vx, m->vr, (size_t)N * V * 4, hipMemcpyDeviceToDevice, st));
+        EH(vision_blocks(m, N, 1e-5f, m->lut_qgelu, false));
+        // clip off the class row (:90), multi_modal_projector: linear_1 -> GELU -> linear_2
+        EH(q_quant(m, m->vx + V, m->vxq, NP, V));
+        EH(lin(m, m->m0, m->vxq, m->vfc, MLLM_HIP_F32, F, nullptr, NP));
+        EH(q_act_quant(m, m->vfc, m->vact, m->lut_gelu, m->vxq2, NP, F));
+        EH(lin(m, m->m2, m->vxq2, out, MLLM_HIP_F32, F, nullptr, NP));
+        return 0;
+    }
+    // VIT: the class row alone goes on (clip({0}), modeling_vit.hpp:106): LayerNorm 1e-6, classifier without bias
+    EH(vision_blocks(m, N, 1e-5f, m->lut_gelu, false));
+    EH(mllm_hip_layernorm(m->vx, m->lnq_w, m->lnq_b, nullptr, m->vxq.qs, m->vxq.d, m->vxq.bs, 1, V, 1e-6f, st));
+    EH(lin(m, m->m0, m->vxq, out, MLLM_HIP_F32, c.v_classes, nullptr, 1));
+    return 0;
+}
+
+static int ensure_vision_buffers(M *m, const int32_t *meta) {
+    const auto &c = m->c;
+    int N, orows, ocols; size_t img_elems;
+    vision_dims(m, meta, &N, &orows, &ocols, &img_elems);
+    if (N <= m->max_patch) return 0;
+    // a larger image than any before: release the previous set (nothing of it is in flight after the sync) and size a new one
+    HH(hipStreamSynchronize(m->st));
+    for (void *p : m->vis_allocs) HH(hipFree(p));
+    m->vis_allocs.clear();
+    m->max_patch = 0;
+    auto *L = &m->vis_allocs;
+    const int V = c.v_dim;
+    const int F = m->vkind == V_QWEN2VL ? 4 * V : c.v_ffn, MM = m->vkind == V_QWEN2VL ? V * c.v_merge * c.v_merge : 0;
     const int VD = V / c.v_heads;
-    EH(m->dalloc(&m->vx, (size_t)N * V * 4)); EH(m->dalloc(&m->vr, (size_t)N * V * 4));
-    EH(m->dalloc(&m->vqkv, (size_t)N * 3 * V * 4)); EH(m->dalloc(&m->vattn, (size_t)N * V * 4));
-    EH(m->dalloc(&m->vfc, (size_t)N * VM * 4)); EH(m->dalloc(&m->vact, (size_t)N * VM * 4));
-    EH(m->dalloc(&m->vpix, (size_t)N * PE * 4));
-    EH(m->dalloc(&m->vsin, (size_t)N * (VD / 2) * 4)); EH(m->dalloc(&m->vcos, (size_t)N * (VD / 2) * 4));
-    EH(m->dalloc(&m->vemb, (size_t)NT * c.hidden * 4)); EH(m->dalloc(&m->vm0, (size_t)NT * MM * 4));
-    // the shared q8k planes must hold N rows of V (xq) and of VM / NT rows of MM (xq2)
-    Q8Planes a, b;
-    EH(alloc_q8(m, &a, N, V)); EH(alloc_q8(m, &b, N, VM > MM ? VM : MM));
-    if ((size_t)N * V > (size_t)m->max_tok * std::max(c.hidden, m->HD)) m->xq = a;
-    if ((size_t)N * VM > (size_t)m->max_tok * c.inter) m->xq2 = b;
+    const int Fw = std::max(F, MM);
+    EH(m->dalloc(&m->vx, (size_t)N * V * 4, L)); EH(m->dalloc(&m->vr, (size_t)N * V * 4, L));
+    EH(m->dalloc(&m->vqkv, (size_t)N * 3 * V * 4, L)); EH(m->dalloc(&m->vattn, (size_t)N * V * 4, L));
+    EH(m->dalloc(&m->vfc, (size_t)N * Fw * 4, L)); EH(m->dalloc(&m->vact, (size_t)N * Fw * 4, L));
+    EH(m->dalloc(&m->vpix[0], img_elems * 4, L)); EH(m->dalloc(&m->vpix[1], img_elems * 4, L));
+    EH(m->dalloc(&m->vemb, (size_t)orows * ocols * 4, L));
+    if (m->vkind == V_QWEN2VL) {
+        EH(m->dalloc(&m->vsin, (size_t)N * (VD / 2) * 4, L)); EH(m->dalloc(&m->vcos, (size_t)N * (VD / 2) * 4, L));
+        EH(m->dalloc(&m->vm0, (size_t)orows * MM * 4, L));
+    } else {
+        EH(m->dalloc(&m->vpatch, (size_t)(N - 1) * 3 * c.v_patch * c.v_patch * 4, L));
+    }
+    // Q8_K planes for fewer than 16 rows only (larger row counts go through the packed GEMM operand m->xpack); sized generously for N rows anyway
+    EH(alloc_q8(m, &m->vxq, N, V, L)); EH(alloc_q8(m, &m->vxq2, N, Fw, L));
+    if (img_elems * 4 > m->pin_img_bytes) {
+        if (m->pin_img) HH(hipHostFree(m->pin_img));
+        m->pin_img = nullptr; m->pin_img_bytes = 0;
+        HH(hipHostMalloc((void **)&m->pin_img, 2 * img_elems * 4, hipHostMallocDefault));
+        m->pin_img_bytes = img_elems * 4;
+    }
     m->max_patch = N;
     return 0;
 }
 
-// One LLM forward over S new tokens whose embeddings are in m->h0 ([S][H]); logits of the last token -> m->logits
+// One LLM forward over S new tokens whose embeddings are in m->h0 ([S][H]); logits of the last token -> m->logits.
+// pos3: QWEN2VL position ids [3][S]; the HF-rotary archs take positions cache_len .. cache_len + S - 1 (CPURoPE's h_cnt_, CPURoPE.cpp:510-513)
 static int forward_llm(M *m, int S, const float *pos3) {
     const auto &c = m->c;
-    const int H = c.hidden, I = c.inter, D = m->D, T0 = m->cache_len;
+    const int H = c.hidden, I = c.inter, D = m->D, T0 = m->cache_len, half = D / 2;
     hipStream_t st = m->st;
     if (T0 + S > c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + %d > %d)\n", T0, S, c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
-    {   // M-RoPE tables for these S positions
-        std::vector<float> s((size_t)S * (D / 2)), co((size_t)S * (D / 2));
+    if (m->mrope) {   // M-RoPE tables for these S positions
+        std::vector<float> s((size_t)S * half), co((size_t)S * half);
         EH(mllm_hip_mrope_table(c.rope_theta, D, pos3, S, c.mrope_section, 3, s.data(), co.data()));
         HH(hipMemcpyAsync(m->rope_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice, st));
         HH(hipMemcpyAsync(m->rope_cos, co.data(), co.size() * 4, hipMemcpyHostToDevice, st));
         HH(hipStreamSynchronize(st));  // host vectors go out of scope
+    } else {
+        HH(hipMemcpyAsync(m->rope_sin, m->hf_sin.data() + (size_t)T0 * half, (size_t)S * half * 4, hipMemcpyHostToDevice, st));
+        HH(hipMemcpyAsync(m->rope_cos, m->hf_cos.data() + (size_t)T0 * half, (size_t)S * half * 4, hipMemcpyHostToDevice, st));
     }
     float *h = m->h0, *h2 = m->h1;
-    const int n_layers = getenv("MLLM_HIP_MAX_LAYERS") ? std::min(c.layers, atoi(getenv("MLLM_HIP_MAX_LAYERS"))) : c.layers;   // bring-up aid
-    for (int li = 0; li < n_layers; ++li) {
+    for (int li = 0; li < c.layers; ++li) {
         auto &L = m->layers[li];
         uint16_t *kl = m->kslab + (size_t)li * c.cache_limit * m->KVD, *vl = m->vslab + (size_t)li * m->KVD * m->vt_ld;
         EH(q_rmsnorm(m, h, L.in_norm, m->xq, S, H, c.rms_eps));
         EH(lin(m, L.qkv, m->xq, m->qkv, MLLM_HIP_F32, m->QKV, nullptr, S));
         // q_rope in place; k_rope -> fp16 slab rows [T0, T0+S); v -> fp16 slab (KVCache zero-copy append)
-        EH(mllm_hip_rope_apply(m->qkv, m->QKV, m->rope_sin, m->rope_cos, D / 2, m->qkv, MLLM_HIP_F32, m->QKV, S, c.heads, D, st));
-        EH(mllm_hip_rope_apply(m->qkv + m->HD, m->QKV, m->rope_sin, m->rope_cos, D / 2, kl + (size_t)T0 * m->KVD, MLLM_HIP_F16, m->KVD, S, c.kv_heads, D, st));
+        EH(mllm_hip_rope_apply(m->qkv, m->QKV, m->rope_sin, m->rope_cos, half, m->qkv, MLLM_HIP_F32, m->QKV, S, c.heads, D, st));
+        EH(mllm_hip_rope_apply(m->qkv + m->HD, m->QKV, m->rope_sin, m->rope_cos, half, kl + (size_t)T0 * m->KVD, MLLM_HIP_F16, m->KVD, S, c.kv_heads, D, st));
         EH(mllm_hip_store_f16_t(m->qkv + m->HD + m->KVD, m->QKV, vl + T0, m->vt_ld, S, m->KVD, st));
         EH(mllm_hip_fa2_vt(m->qkv, m->QKV, kl, m->KVD, vl, m->vt_ld, m->attn, m->HD, S, T0 + S, c.heads, c.kv_heads, D, 1, st));
         EH(q_quant(m, m->attn, m->xq, S, m->HD));
@@ -530,10 +809,16 @@ static int forward_llm(M *m, int S, const float *pos3) {
         EH(q_silu_mul_quant(m, m->gu, m->act, m->xq2, S, I));
         EH(lin(m, L.down, m->xq2, h, MLLM_HIP_F32, H, h2, S));                      // x = down(...) + tmp
     }
-    // final norm on the last token only (norm then clip({-1}) == clip then norm), tied lm_head through Q8_0 activations
-    EH(mllm_hip_rmsnorm(h + (size_t)(S - 1) * H, m->final_norm, m->normed, nullptr, nullptr, nullptr, 1, H, 1e-6f, 0, st));
-    EH(mllm_hip_quantize_q80(m->normed, m->x80_qs, m->x80_d, 1, H, st));
-    EH(mllm_hip_linear_q40_q80(m->emb_qs, m->emb_d, nullptr, m->x80_qs, m->x80_d, m->logits, c.vocab, 1, c.vocab, H, st));
+    // final norm on the last token only (norm then clip({-1}) == clip then norm; TinyLLaMAModel does not clip (modeling_tinyllama.hpp:67-75) but the demo
+    // reads the last row), then the head: tied = Tensor::mm with embed_tokens^T through Q8_0 activations, else the Linear lm_head through Q8_K
+    if (c.tie_embedding) {
+        EH(mllm_hip_rmsnorm(h + (size_t)(S - 1) * H, m->final_norm, m->normed, nullptr, nullptr, nullptr, 1, H, c.final_eps, 0, st));
+        EH(mllm_hip_quantize_q80(m->normed, m->x80_qs, m->x80_d, 1, H, st));
+        EH(mllm_hip_linear_q40_q80(m->emb_qs, m->emb_d, nullptr, m->x80_qs, m->x80_d, m->logits, c.vocab, 1, c.vocab, H, st));
+    } else {
+        EH(mllm_hip_rmsnorm(h + (size_t)(S - 1) * H, m->final_norm, nullptr, m->xq.qs, m->xq.d, m->xq.bs, 1, H, c.final_eps, 0, st));
+        EH(mllm_hip_linear_q4k_q8k(m->head.w, nullptr, m->xq.qs, m->xq.d, m->xq.bs, m->logits, MLLM_HIP_F32, c.vocab, nullptr, 1, c.vocab, H, st));
+    }
     EH(mllm_hip_argmax(m->logits, c.vocab, m->tok_dev, st));
     m->cache_len = T0 + S;
     return 0;
@@ -550,53 +835,78 @@ static int finish(M *m, float *logits_host, int32_t *next_token, float *elapsed_
     return 0;
 }
 
-extern "C" int mllm_hip_qwen2vl_prefill(mllm_hip_qwen2vl *m, const int32_t *ids, int n_ids, const float *pixel_values, const int32_t *grid_thw,
-                                        float *logits_host, int32_t *next_token, float *elapsed_ms) {
-    if (!m || !ids || n_ids <= 0 || n_ids > m->c.cache_limit) return MLLM_HIP_ERR_ARG;
+extern "C" int mllm_hip_model_prefill(mllm_hip_model *m, const int32_t *ids, int n_ids, const float *image, const int32_t *image_meta, const float *visual_dev,
+                                      int n_visual_rows, float *logits_host, int32_t *next_token, float *elapsed_ms) {
+    if (!m || !m->has_llm || !ids || n_ids <= 0 || n_ids > m->c.cache_limit) return MLLM_HIP_ERR_ARG;
     const auto &c = m->c;
-    const bool has_img = pixel_values != nullptr;
-    if (has_img && (!m->has_vision || !grid_thw)) return MLLM_HIP_ERR_ARG;
+    const bool has_img = image != nullptr || visual_dev != nullptr;
+    if (has_img && m->vkind == V_NONE) return MLLM_HIP_ERR_ARG;
+    if (has_img && m->vkind == V_QWEN2VL && !image_meta) return MLLM_HIP_ERR_ARG;
     std::vector<float> idf(n_ids);
     std::vector<int> where;
     for (int i = 0; i < n_ids; ++i) { idf[i] = (float)ids[i]; if (ids[i] == c.image_token_id) where.push_back(i); }
-    int N = 0;
+    int vrows = 0, vcols = 0, S = n_ids;
+    const float *vis = visual_dev;
     if (has_img) {
-        N = grid_thw[0] * grid_thw[1] * grid_thw[2];
-        if ((int)where.size() != N / (c.v_merge * c.v_merge)) { fprintf(stderr, "mllm_hip: %zu image tokens but %d visual tokens\n", where.size(), N / (c.v_merge * c.v_merge)); return MLLM_HIP_ERR_SHAPE; }
-        EH(ensure_vision_buffers(m, N));
-        HH(hipMemcpy(m->vpix, pixel_values, (size_t)N * 3 * 2 * c.v_patch * c.v_patch * 4, hipMemcpyHostToDevice));
-        HH(hipMemcpy(m->idx_i, where.data(), where.size() * 4, hipMemcpyHostToDevice));
+        int nt; size_t ie;
+        vision_dims(m, image_meta, &nt, &vrows, &vcols, &ie);
+        if (visual_dev && n_visual_rows != vrows) return MLLM_HIP_ERR_SHAPE;
+        if (m->vkind == V_QWEN2VL) {
+            if ((int)where.size() != vrows) { fprintf(stderr, "mllm_hip: %zu image tokens but %d visual tokens\n", where.size(), vrows); return MLLM_HIP_ERR_SHAPE; }
+        } else {
+            if (where.size() != 1) { fprintf(stderr, "mllm_hip: LLaVA takes exactly one <image> token per prompt, got %zu\n", where.size()); return MLLM_HIP_ERR_SHAPE; }
+            S = n_ids - 1 + vrows;
+            if (S > c.cache_limit) return MLLM_HIP_ERR_SHAPE;
+        }
+        if (!visual_dev) {
+            EH(ensure_vision_buffers(m, image_meta));
+            HH(hipMemcpy(m->vpix[0], image, ie * 4, hipMemcpyHostToDevice));
+            vis = m->vemb;
+        }
+        if (m->vkind == V_QWEN2VL) HH(hipMemcpy(m->idx_i, where.data(), where.size() * 4, hipMemcpyHostToDevice));
     }
     HH(hipMemcpy(m->ids_f, idf.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice));
     std::vector<float> pos;
-    rope_index(m, ids, n_ids, grid_thw, has_img, pos);
+    if (m->mrope) rope_index(m, ids, n_ids, image_meta, has_img, pos);
     // ---- timed region: inputs resident in HBM ----
     HH(hipEventRecord(m->ev0, m->st));
-    EH(mllm_hip_embedding_q40(m->ids_f, m->emb_qs, m->emb_d, m->h0, n_ids, c.hidden, c.vocab, m->st));
-    if (has_img) {
-        EH(forward_vision(m, grid_thw, m->vemb));
-        EH(mllm_hip_index_put_rows(m->h0, m->vemb, m->idx_i, (int)where.size(), c.hidden, m->st));
+    if (has_img && !visual_dev) EH(forward_vision(m, m->vpix[0], image_meta, m->vemb));
+    if (has_img && m->vkind == V_CLIP) {
+        // text rows before the <image> row, the visual rows in its place, the text rows after it (Tensor::where + index_put, modeling_llava.hpp:128-132)
+        const int at = where[0];
+        EH(mllm_hip_embedding_q40(m->ids_f, m->emb_qs, m->emb_d, m->h0, at, c.hidden, c.vocab, m->st));
+        HH(hipMemcpyAsync(m->h0 + (size_t)at * c.hidden, vis, (size_t)vrows * c.hidden * 4, hipMemcpyDeviceToDevice, m->st));
+        EH(mllm_hip_embedding_q40(m->ids_f + at + 1, m->emb_qs, m->emb_d, m->h0 + (size_t)(at + vrows) * c.hidden, n_ids - at - 1, c.hidden, c.vocab, m->st));
+    } else {
+        EH(mllm_hip_embedding_q40(m->ids_f, m->emb_qs, m->emb_d, m->h0, n_ids, c.hidden, c.vocab, m->st));
+        if (has_img) EH(mllm_hip_index_put_rows(m->h0, vis, m->idx_i, (int)where.size(), c.hidden, m->st));
     }
-    EH(forward_llm(m, n_ids, pos.data()));
-    m->last_pos = pos[(size_t)n_ids - 1];  // row 0 (t axis), last column: get_position_ids' decode branch
+    EH(forward_llm(m, S, pos.data()));
+    // the position the decode loop continues from: M-RoPE row 0 (t axis), last column (get_position_ids' decode branch); HF rotary: the token count
+    m->last_pos = m->mrope ? pos[(size_t)n_ids - 1] : (float)(m->cache_len - 1);
     EH(finish(m, logits_host, next_token, elapsed_ms));
     return arm_decode(m);
 }
 
-// After a prefill: device step state {T, step = 0, token}, and the M-RoPE rows of every position the decode loop can still
-// reach (get_position_ids' decode branch: all three axes = last_pos + 1 + step, modeling_qwen2_vl.hpp:423-432).
+// After a prefill: device step state {T, step = 0, token}, and the rotary rows of every position the decode loop can still reach
+// (QWEN2VL: all three axes = last_pos + 1 + step, modeling_qwen2_vl.hpp:423-432; HF rotary: position = tokens in the cache).
 static int arm_decode(M *m) {
     const auto &c = m->c;
-    const int rows = c.cache_limit - m->cache_len;
+    const int rows = c.cache_limit - m->cache_len, half = m->D / 2;
     m->dec_rows = rows;
     if (rows > 0) {
-        std::vector<float> pos((size_t)3 * rows), s((size_t)rows * (m->D / 2)), co((size_t)rows * (m->D / 2));
-        for (int a = 0; a < 3; ++a) for (int r = 0; r < rows; ++r) pos[(size_t)a * rows + r] = m->last_pos + 1.0f + (float)r;
-        EH(mllm_hip_mrope_table(c.rope_theta, m->D, pos.data(), rows, c.mrope_section, 3, s.data(), co.data()));
-        HH(hipMemcpy(m->dec_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
-        HH(hipMemcpy(m->dec_cos, co.data(), co.size() * 4, hipMemcpyHostToDevice));
-        HH(hipMemcpy(m->cur_sin, s.data(), (size_t)(m->D / 2) * 4, hipMemcpyHostToDevice));
-        HH(hipMemcpy(m->cur_cos, co.data(), (size_t)(m->D / 2) * 4, hipMemcpyHostToDevice));
+        if (m->mrope) {
+            std::vector<float> pos((size_t)3 * rows), s((size_t)rows * half), co((size_t)rows * half);
+            for (int a = 0; a < 3; ++a) for (int r = 0; r < rows; ++r) pos[(size_t)a * rows + r] = m->last_pos + 1.0f + (float)r;
+            EH(mllm_hip_mrope_table(c.rope_theta, m->D, pos.data(), rows, c.mrope_section, 3, s.data(), co.data()));
+            HH(hipMemcpy(m->dec_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+            HH(hipMemcpy(m->dec_cos, co.data(), co.size() * 4, hipMemcpyHostToDevice));
+        } else {
+            HH(hipMemcpy(m->dec_sin, m->hf_sin.data() + (size_t)m->cache_len * half, (size_t)rows * half * 4, hipMemcpyHostToDevice));
+            HH(hipMemcpy(m->dec_cos, m->hf_cos.data() + (size_t)m->cache_len * half, (size_t)rows * half * 4, hipMemcpyHostToDevice));
+        }
+        HH(hipMemcpy(m->cur_sin, m->dec_sin, (size_t)half * 4, hipMemcpyDeviceToDevice));
+        HH(hipMemcpy(m->cur_cos, m->dec_cos, (size_t)half * 4, hipMemcpyDeviceToDevice));
     }
     int tok = 0;
     HH(hipMemcpy(&tok, m->tok_dev, 4, hipMemcpyDeviceToHost));
@@ -621,8 +931,8 @@ static int launch_step(M *m) {
     return decode_step_launch(m->dctx, m->dlayers.data(), (int)m->dlayers.size(), m->st);
 }
 
-extern "C" int mllm_hip_qwen2vl_decode(mllm_hip_qwen2vl *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms) {
-    if (!m || m->cache_len <= 0) return MLLM_HIP_ERR_ARG;
+extern "C" int mllm_hip_model_decode(mllm_hip_model *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms) {
+    if (!m || !m->has_llm || m->cache_len <= 0) return MLLM_HIP_ERR_ARG;
     if (m->cache_len + 1 > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + 1 > %d)\n", m->cache_len, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
     HH(hipMemcpyAsync(&m->d_state->token, &token, 4, hipMemcpyHostToDevice, m->st));
     HH(hipStreamSynchronize(m->st));
@@ -633,8 +943,8 @@ extern "C" int mllm_hip_qwen2vl_decode(mllm_hip_qwen2vl *m, int32_t token, float
     return finish(m, logits_host, next_token, elapsed_ms);
 }
 
-extern "C" int mllm_hip_qwen2vl_generate(mllm_hip_qwen2vl *m, int32_t first_token, int steps, int32_t *tokens_host, float *elapsed_ms) {
-    if (!m || m->cache_len <= 0 || steps <= 0) return MLLM_HIP_ERR_ARG;
+extern "C" int mllm_hip_model_generate(mllm_hip_model *m, int32_t first_token, int steps, int32_t *tokens_host, float *elapsed_ms) {
+    if (!m || !m->has_llm || m->cache_len <= 0 || steps <= 0) return MLLM_HIP_ERR_ARG;
     if (m->cache_len + steps > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + %d > %d)\n", m->cache_len, steps, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
     DecodeState st0;
     HH(hipMemcpy(&st0, m->d_state, sizeof(st0), hipMemcpyDeviceToHost));
@@ -649,32 +959,126 @@ extern "C" int mllm_hip_qwen2vl_generate(mllm_hip_qwen2vl *m, int32_t first_toke
     return 0;
 }
 
-extern "C" int mllm_hip_qwen2vl_vision(mllm_hip_qwen2vl *m, const float *pixel_values_host, const int32_t *grid_thw, int n_img, float *embeds_dev,
-                                       float *elapsed_ms) {
-    if (!m || !m->has_vision || !grid_thw || n_img <= 0) return MLLM_HIP_ERR_ARG;
-    const auto &c = m->c;
-    const int N = grid_thw[0] * grid_thw[1] * grid_thw[2], PE = 3 * 2 * c.v_patch * c.v_patch, NT = N / (c.v_merge * c.v_merge);
-    EH(ensure_vision_buffers(m, N));
-    float total = 0.0f;
-    for (int i = 0; i < n_img; ++i) {
-        HH(hipMemcpy(m->vpix, pixel_values_host + (size_t)i * N * PE, (size_t)N * PE * 4, hipMemcpyHostToDevice));
-        HH(hipEventRecord(m->ev0, m->st));
-        EH(forward_vision(m, grid_thw, embeds_dev + (size_t)i * NT * c.hidden));
-        HH(hipEventRecord(m->ev1, m->st));
-        HH(hipEventSynchronize(m->ev1));
-        float ms;
-        HH(hipEventElapsedTime(&ms, m->ev0, m->ev1));
-        total += ms;
+// Module::generate's loop (mllm/Module.cpp:63-100) with the method switch of :76-88: greedy / top-k / top-p.  The forward and the candidate selection
+// run on the device; what crosses PCIe per step is the k candidates (top-k) or the sorted prefix that reaches the nucleus mass (top-p, in chunks), and
+// the chosen id going back.  The temperature softmax over the candidates (Generate.cpp:69-87 / :120-136: float exp results, double sum, float
+// renormalisation) and the draw are host arithmetic as in the reference; the draw consumes u01[step] by inverse CDF over the float probabilities where
+// the reference seeds a std::discrete_distribution from std::random_device (Generate.hpp:38-44), which no caller can reproduce.
+extern "C" int mllm_hip_model_generate_sampled(mllm_hip_model *m, int32_t first_token, int steps, int method, int top_k, float top_p, float temperature,
+                                               const float *u01, int32_t eos, int32_t *tokens_host, int *n_out, float *elapsed_ms) {
+    if (!m || !m->has_llm || m->cache_len <= 0 || steps <= 0 || method < 0 || method > 2) return MLLM_HIP_ERR_ARG;
+    if (method != 0 && (!u01 || !(temperature > 0.0f))) return MLLM_HIP_ERR_ARG;
+    if (method == 1 && (top_k < 0 || top_k > 64 || top_k > m->c.vocab)) return MLLM_HIP_ERR_SHAPE;
+    if (m->cache_len + steps > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + %d > %d)\n", m->cache_len, steps, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
+    const int V = m->c.vocab;
+    if (method != 0 && !m->samp_val) {
+        EH(m->dalloc(&m->samp_val, (size_t)V * 4)); EH(m->dalloc(&m->samp_idx, (size_t)V * 4)); EH(m->dalloc(&m->samp_prob, (size_t)V * 4));
+        m->sort_ws_bytes = mllm_hip_sort_desc_workspace_bytes(V);
+        HH(hipMalloc(&m->sort_ws, m->sort_ws_bytes));
     }
-    if (elapsed_ms) *elapsed_ms = total;
+    const auto t0 = std::chrono::steady_clock::now();
+    int32_t tok = first_token;
+    int made = 0;
+    std::vector<float> val, prob;
+    std::vector<int> idx;
+    for (int s = 0; s < steps; ++s) {
+        HH(hipMemcpyAsync(&m->d_state->token, &tok, 4, hipMemcpyHostToDevice, m->st));
+        EH(launch_step(m));
+        m->cache_len += 1;
+        m->last_pos += 1.0f;
+        int32_t next = 0;
+        if (method == 0 || (method == 1 && top_k <= 1)) {
+            // greedy: the device argmax of the step (std::max_element, first maximum); top-k with k in {0, 1} is the same (Generate.cpp:50-54)
+            HH(hipMemcpyAsync(&next, m->tok_dev, 4, hipMemcpyDeviceToHost, m->st));
+            HH(hipStreamSynchronize(m->st));
+        } else if (method == 1) {
+            EH(mllm_hip_topk(m->logits, V, top_k, m->samp_val, m->samp_idx, m->st));
+            val.resize(top_k); idx.resize(top_k); prob.resize(top_k);
+            HH(hipMemcpyAsync(val.data(), m->samp_val, (size_t)top_k * 4, hipMemcpyDeviceToHost, m->st));
+            HH(hipMemcpyAsync(idx.data(), m->samp_idx, (size_t)top_k * 4, hipMemcpyDeviceToHost, m->st));
+            HH(hipStreamSynchronize(m->st));
+            EH(mllm_hip_topk_probs_host(val.data(), top_k, temperature, prob.data()));
+            next = idx[mllm_hip_sample_index_host(prob.data(), top_k, u01[s])];
+        } else {
+            // top-p expects probabilities (it throws when the largest score exceeds 1, Generate.cpp:104-106): the caller's graph ends in a softmax over the
+            // vocabulary row (CPUSoftMax), then all scores are sorted descending and the prefix whose running float sum reaches p is kept
+            EH(mllm_hip_softmax(m->logits, m->samp_prob, 1, V, nullptr, m->st));
+            EH(mllm_hip_sort_desc(m->samp_prob, V, m->samp_val, m->samp_idx, m->sort_ws, m->sort_ws_bytes, m->st));
+            val.clear(); idx.clear();
+            float p = 0.0f;
+            int have = 0;
+            bool done = false;
+            while (!done && have < V) {
+                const int chunk = std::min(V - have, have == 0 ? 256 : 4096);
+                val.resize(have + chunk); idx.resize(have + chunk);
+                HH(hipMemcpyAsync(val.data() + have, m->samp_val + have, (size_t)chunk * 4, hipMemcpyDeviceToHost, m->st));
+                HH(hipMemcpyAsync(idx.data() + have, m->samp_idx + have, (size_t)chunk * 4, hipMemcpyDeviceToHost, m->st));
+                HH(hipStreamSynchronize(m->st));
+                int n = have;
+                while (n < have + chunk && p < top_p) { p += val[n]; ++n; }       // `while (p < m_p)` of Generate.cpp:108-115, float accumulation
+                if (p >= top_p || n < have + chunk) { val.resize(n); idx.resize(n); done = true; }
+                have = n;
+            }
+            const int k = (int)val.size();
+            if (k <= 1) next = idx.empty() ? 0 : idx[0];
+            else {
+                prob.resize(k);
+                EH(mllm_hip_topk_probs_host(val.data(), k, temperature, prob.data()));
+                next = idx[mllm_hip_sample_index_host(prob.data(), k, u01[s])];
+            }
+        }
+        if (tokens_host) tokens_host[made] = next;
+        ++made;
+        tok = next;
+        if (eos >= 0 && next == eos) break;
+    }
+    HH(hipStreamSynchronize(m->st));
+    if (n_out) *n_out = made;
+    if (elapsed_ms) *elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
 
-extern "C" int mllm_hip_qwen2vl_time_gemv(mllm_hip_qwen2vl *m, int which, int iters, float *ms_per_launch, int64_t *bytes_per_launch) {
+// n_img images through the tower; the upload of image i+1 (pinned staging, copy on the load stream of the moment) runs while the tower works on image i
+extern "C" int mllm_hip_model_vision(mllm_hip_model *m, const float *images_host, const int32_t *image_meta, int n_img, float *out_dev, float *elapsed_ms) {
+    if (!m || m->vkind == V_NONE || !images_host || !out_dev || n_img <= 0) return MLLM_HIP_ERR_ARG;
+    if (m->vkind == V_QWEN2VL && !image_meta) return MLLM_HIP_ERR_ARG;
+    int nt, orows, ocols; size_t ie;
+    vision_dims(m, image_meta, &nt, &orows, &ocols, &ie);
+    EH(ensure_vision_buffers(m, image_meta));
+    hipStream_t cp;
+    HH(hipStreamCreateWithFlags(&cp, hipStreamNonBlocking));
+    auto upload = [&](int i) -> int {
+        const int b = i & 1;
+        float *pin = m->pin_img + (size_t)b * ie;
+        if (i >= 2) HH(hipEventSynchronize(m->vfree[b]));          // the tower has finished with image i-2, which sat in this device buffer
+        memcpy(pin, images_host + (size_t)i * ie, ie * 4);           // (its H2D copy was waited for by the compute stream before that)
+        HH(hipMemcpyAsync(m->vpix[b], pin, ie * 4, hipMemcpyHostToDevice, cp));
+        HH(hipEventRecord(m->vup[b], cp));
+        return 0;
+    };
+    int rc = upload(0);
+    if (!rc) { hipError_t e = hipEventRecord(m->ev0, m->st); if (e != hipSuccess) rc = MLLM_HIP_ERR_HIP; }
+    for (int i = 0; i < n_img && !rc; ++i) {
+        const int b = i & 1;
+        if (hipStreamWaitEvent(m->st, m->vup[b], 0) != hipSuccess) { rc = MLLM_HIP_ERR_HIP; break; }
+        if (i + 1 < n_img) rc = upload(i + 1);
+        if (!rc) rc = forward_vision(m, m->vpix[b], image_meta, out_dev + (size_t)i * orows * ocols);
+        if (!rc && hipEventRecord(m->vfree[b], m->st) != hipSuccess) rc = MLLM_HIP_ERR_HIP;
+    }
+    if (!rc) {
+        if (hipEventRecord(m->ev1, m->st) != hipSuccess || hipEventSynchronize(m->ev1) != hipSuccess) rc = MLLM_HIP_ERR_HIP;
+        else if (elapsed_ms && hipEventElapsedTime(elapsed_ms, m->ev0, m->ev1) != hipSuccess) rc = MLLM_HIP_ERR_HIP;
+    }
+    (void)hipStreamSynchronize(cp);
+    (void)hipStreamDestroy(cp);
+    return rc;
+}
+
+extern "C" int mllm_hip_model_time_kernel(mllm_hip_model *m, int which, int iters, float *ms_per_launch, int64_t *bytes_per_launch) {
     // which 0..3: stand-alone Q4_K GEMV launcher on gate|up, down, qkv, o; which 10..14: fused decode kernels qkv, attn, o-proj,
     // gate|up, down.  Launch i uses layer i % layers, so consecutive launches stream different weights (28 x 15.5 MB does not
     // fit the 256 MiB Infinity Cache): the time is that of a cold HBM stream, like inside the decode step.
-    if (!m || iters <= 0) return MLLM_HIP_ERR_ARG;
+    if (!m || !m->has_llm || iters <= 0) return MLLM_HIP_ERR_ARG;
     int nl = (int)m->layers.size();
     if (const char *e = getenv("MLLM_HIP_TIME_LAYERS")) nl = std::max(1, std::min(nl, atoi(e)));   // fewer layers: an Infinity-Cache-warm stream
     auto launch = [&](int i) -> int {
@@ -698,4 +1102,43 @@ extern "C" int mllm_hip_qwen2vl_time_gemv(mllm_hip_qwen2vl *m, int which, int it
     const LinearW *w = which == 0 || k == 3 ? &L0.gu : (which == 1 || k == 4 ? &L0.down : (which == 2 || k == 0 ? &L0.qkv : &L0.o));
     if (bytes_per_launch) *bytes_per_launch = k == 1 ? (int64_t)2 * m->cache_len * m->KVD * 2 : (int64_t)w->N * (w->K / 256) * 144;
     return 0;
+}
+
+// ---- round-1 entry points of the Qwen2-VL engine: forwards onto the generic engine ----------------------------------------------------------
+extern "C" int mllm_hip_qwen2vl_create(const mllm_hip_qwen2vl_config *q, const char *path, mllm_hip_qwen2vl **out) {
+    if (!q || !path || !out) return MLLM_HIP_ERR_ARG;
+    mllm_hip_model_config c;
+    memset(&c, 0, sizeof(c));
+    c.arch = MLLM_HIP_ARCH_QWEN2VL;
+    c.hidden = q->hidden; c.inter = q->inter; c.layers = q->layers; c.heads = q->heads; c.kv_heads = q->kv_heads; c.vocab = q->vocab;
+    c.rms_eps = q->rms_eps; c.final_eps = 1e-6f;      // Qwen2VLModel's model.norm: RMSNorm(hidden_dim, 1e-6, ...) (modeling_qwen2_vl.hpp:374)
+    c.rope_theta = q->rope_theta;
+    for (int i = 0; i < 3; ++i) c.mrope_section[i] = q->mrope_section[i];
+    c.cache_limit = q->cache_limit; c.tie_embedding = q->tie_embedding; c.qkv_bias = 1;
+    c.v_dim = q->v_dim; c.v_heads = q->v_heads; c.v_blocks = q->v_blocks; c.v_patch = q->v_patch; c.v_merge = q->v_merge;
+    c.image_token_id = q->image_token_id; c.vision_start_token_id = q->vision_start_token_id; c.vision_end_token_id = q->vision_end_token_id;
+    c.video_token_id = q->video_token_id;
+    return mllm_hip_model_create(&c, path, out);
+}
+extern "C" void mllm_hip_qwen2vl_destroy(mllm_hip_qwen2vl *m) { mllm_hip_model_destroy(m); }
+extern "C" int mllm_hip_qwen2vl_clear_kvcache(mllm_hip_qwen2vl *m) { return mllm_hip_model_clear_kvcache(m); }
+extern "C" int mllm_hip_qwen2vl_prefill(mllm_hip_qwen2vl *m, const int32_t *ids, int n_ids, const float *pixel_values, const int32_t *grid_thw,
+                                        float *logits_host, int32_t *next_token, float *elapsed_ms) {
+    if (pixel_values && !grid_thw) return MLLM_HIP_ERR_ARG;
+    return mllm_hip_model_prefill(m, ids, n_ids, pixel_values, grid_thw, nullptr, 0, logits_host, next_token, elapsed_ms);
+}
+extern "C" int mllm_hip_qwen2vl_decode(mllm_hip_qwen2vl *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms) {
+    return mllm_hip_model_decode(m, token, logits_host, next_token, elapsed_ms);
+}
+extern "C" int mllm_hip_qwen2vl_generate(mllm_hip_qwen2vl *m, int32_t first_token, int steps, int32_t *tokens_host, float *elapsed_ms) {
+    return mllm_hip_model_generate(m, first_token, steps, tokens_host, elapsed_ms);
+}
+extern "C" int mllm_hip_qwen2vl_vision(mllm_hip_qwen2vl *m, const float *pixel_values_host, const int32_t *grid_thw, int n_img, float *embeds_dev, float *elapsed_ms) {
+    if (!grid_thw) return MLLM_HIP_ERR_ARG;
+    return mllm_hip_model_vision(m, pixel_values_host, grid_thw, n_img, embeds_dev, elapsed_ms);
+}
+extern "C" int64_t mllm_hip_qwen2vl_decode_weight_bytes(const mllm_hip_qwen2vl *m) { return mllm_hip_model_decode_weight_bytes(m); }
+extern "C" void *mllm_hip_qwen2vl_stream(mllm_hip_qwen2vl *m) { return mllm_hip_model_stream(m); }
+extern "C" int mllm_hip_qwen2vl_time_gemv(mllm_hip_qwen2vl *m, int which, int iters, float *ms_per_launch, int64_t *bytes_per_launch) {
+    return mllm_hip_model_time_kernel(m, which, iters, ms_per_launch, bytes_per_launch);
 }

@@ -847,8 +847,10 @@ static int allow_lds(KernelT kern, size_t lds) {
     if (lds > 48 * 1024) MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return MLLM_HIP_OK;
 }
+// RMSNorm(x) -> Q8_K -> W rows (+bias) -> y: the q|k|v projection of a layer, and the Linear lm_head of the models whose head is not tied
 template <int NS>
-static int launch_qkv(const DecodeLayer &L, const DecodeCtx &c, bool embed, const float *x, float *x_out, hipStream_t st) {
+static int launch_norm_gemv(const DecodeCtx &c, const float *norm_w, float eps, const uint8_t *W, const float *bias, int N, bool embed, const float *x,
+                            float *x_out, float *y, hipStream_t st) {
 #ifndef QKV_ROWS
 #define QKV_ROWS 2
 #endif
@@ -856,17 +858,17 @@ static int launch_qkv(const DecodeLayer &L, const DecodeCtx &c, bool embed, cons
 #define QKV_WPB 8
 #endif
     constexpr int ROWS = NS == 1 ? QKV_ROWS : 1, WPB = QKV_WPB;
-    const int waves = (L.qkv_N + ROWS - 1) / ROWS;
+    const int waves = (N + ROWS - 1) / ROWS;
     const size_t lds = fused_lds_bytes<NS, ROWS>(c.H, false, WPB);
     constexpr int NV = (NS * 8 + WPB - 1) / WPB;   // quant blocks per wave
     int rc = embed ? allow_lds(dec_qkv_kernel<NS, ROWS, true, NV, WPB>, lds) : allow_lds(dec_qkv_kernel<NS, ROWS, false, NV, WPB>, lds);
     if (rc) return rc;
     if (embed)
-        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, true, NV, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, L.in_norm,
-                           c.eps, L.Wqkv, L.bqkv, c.qkv, L.qkv_N, c.H);
+        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, true, NV, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, norm_w,
+                           eps, W, bias, y, N, c.H);
     else
-        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, false, NV, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, L.in_norm,
-                           c.eps, L.Wqkv, L.bqkv, c.qkv, L.qkv_N, c.H);
+        hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, false, NV, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, norm_w,
+                           eps, W, bias, y, N, c.H);
     return MH_LAUNCH_OK("dec_qkv");
 }
 template <int NS>
@@ -973,22 +975,29 @@ int decode_order_q4k(const void *src, void *dst, int64_t n_blocks, hipStream_t s
 }
 
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st) {
-    if (c.D != 128 || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
+    if ((c.D != 128 && c.D != 64) || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
     float *x = c.x0, *t = c.x1;
     const DecodeLayer &L = layers[li];
     int rc = 0;
     switch (which) {
     case 0:
-        NS_DISPATCH(c.H, rc = launch_qkv<NS>(L, c, li == 0, x, x, st));
+        NS_DISPATCH(c.H, rc = launch_norm_gemv<NS>(c, L.in_norm, c.eps, L.Wqkv, L.bqkv, L.qkv_N, li == 0, x, x, c.qkv, st));
         return rc;
     case 1: {
         uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.kv_heads * c.D * c.vt_ld;
         const int nslots = decode_lds_slots(c.cache_limit, c.D, DEC_ATTN_NT, 2, true);
         const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
-        rc = allow_lds(dec_attn_kernel<128>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((dec_attn_kernel<128>), dim3(c.heads / c.kv_heads, c.kv_heads), dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads,
-                           c.kv_heads, c.cache_limit, c.vt_ld, nslots);
+        if (c.D == 128) {
+            rc = allow_lds(dec_attn_kernel<128>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((dec_attn_kernel<128>), dim3(c.heads / c.kv_heads, c.kv_heads), dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws,
+                               c.heads, c.kv_heads, c.cache_limit, c.vt_ld, nslots);
+        } else {
+            rc = allow_lds(dec_attn_kernel<64>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((dec_attn_kernel<64>), dim3(c.heads / c.kv_heads, c.kv_heads), dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws,
+                               c.heads, c.kv_heads, c.cache_limit, c.vt_ld, nslots);
+        }
         return MH_LAUNCH_OK("dec_attn");
     }
     case 2:
@@ -1012,10 +1021,18 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
             rc = decode_kernel_launch(c, layers, li, k, st);
             if (rc) return rc;
         }
+    if (c.Whead) {
+        // Linear lm_head (LLaMA-style models): model.norm -> Q8_K -> Q4_K rows, the same fused kernel as the q|k|v projection; then argmax
+        NS_DISPATCH(c.H, rc = launch_norm_gemv<NS>(c, c.final_norm, c.final_eps, c.Whead, nullptr, c.vocab, false, x, x, c.logits, st));
+        if (!rc) rc = mllm_hip_argmax(c.logits, c.vocab, c.tok_dev, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, st, c.state, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos, c.D / 2, c.cache_limit);
+        return MH_LAUNCH_OK("dec_advance");
+    }
     // tied lm_head + argmax
     if (c.H % 512 != 0 || c.H / 512 > 8) {
         // shapes the fused head kernel does not cover: the stand-alone launchers (same arithmetic), then advance the state
-        rc = mllm_hip_rmsnorm(x, c.final_norm, c.normed, nullptr, nullptr, nullptr, 1, c.H, 1e-6f, 0, st);
+        rc = mllm_hip_rmsnorm(x, c.final_norm, c.normed, nullptr, nullptr, nullptr, 1, c.H, c.final_eps, 0, st);
         if (!rc) rc = mllm_hip_quantize_q80(c.normed, c.x80_qs, c.x80_d, 1, c.H, st);
         if (!rc) rc = mllm_hip_linear_q40_q80(c.emb_qs, c.emb_d, nullptr, c.x80_qs, c.x80_d, c.logits, c.vocab, 1, c.vocab, c.H, st);
         if (!rc) rc = mllm_hip_argmax(c.logits, c.vocab, c.tok_dev, st);
@@ -1023,14 +1040,14 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
         hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, st, c.state, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos, c.D / 2, c.cache_limit);
         return MH_LAUNCH_OK("dec_advance");
     }
-    static const int head_wpc = getenv("MLLM_HIP_HEAD_WPC") ? atoi(getenv("MLLM_HIP_HEAD_WPC")) : 8;   // waves per CU the row split aims at
+    static const int head_wpc = getenv("MLLM_HIP_HEAD_WPC") ? std::max(1, atoi(getenv("MLLM_HIP_HEAD_WPC"))) : 8;   // waves per CU the row split aims at
     const int target_waves = 256 * head_wpc;
     int rpw = (c.vocab + target_waves - 1) / target_waves;
     rpw = ((rpw + 7) / 8) * 8;
     const int waves = (c.vocab + rpw - 1) / rpw, blocks = (waves + 3) / 4;
     if (blocks > c.max_parts) return MLLM_HIP_ERR_SHAPE;
     const size_t lds = (((size_t)c.H * 5 + (size_t)c.H / 32 * 4 + 15) & ~(size_t)15) + 4 * q40_tab_floats(c.H / 32) * sizeof(float);
-#define HEAD_CASE(B) case B: rc = allow_lds(dec_head_kernel<B>, lds); if (rc) return rc; hipLaunchKernelGGL((dec_head_kernel<B>), dim3(blocks), dim3(256), lds, st, x, c.final_norm, 1e-6f, c.emb_qs, c.emb_d, c.logits, c.part_val, c.part_idx, c.vocab, c.H, rpw); break;
+#define HEAD_CASE(B) case B: rc = allow_lds(dec_head_kernel<B>, lds); if (rc) return rc; hipLaunchKernelGGL((dec_head_kernel<B>), dim3(blocks), dim3(256), lds, st, x, c.final_norm, c.final_eps, c.emb_qs, c.emb_d, c.logits, c.part_val, c.part_idx, c.vocab, c.H, rpw); break;
     switch (c.H / 512) { HEAD_CASE(1) HEAD_CASE(2) HEAD_CASE(3) HEAD_CASE(4) HEAD_CASE(5) HEAD_CASE(6) HEAD_CASE(7) HEAD_CASE(8) }
 #undef HEAD_CASE
     rc = MH_LAUNCH_OK("dec_head");

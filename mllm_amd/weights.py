@@ -1,7 +1,8 @@
 """Build synthetic `*-q4_k.mllm` files with the product's own quantiser (no dependency on the reference tool).
 
 Same per-name dtype policy and block formats as `quantize <in> <out> Q4_K` of the reference
-(tools/quantizer/QuantWriter.cpp:123-157,288-300); byte-for-byte agreement with it is pinned by tests/test_quantizer.py.
+(tools/quantizer/QuantWriter.cpp:123-157,288-300); byte-for-byte agreement with it is pinned by tests/test_host.py
+(digests of files the reference tool wrote, tests/golden/*_digests.json).
 """
 from __future__ import annotations
 

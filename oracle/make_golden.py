@@ -272,13 +272,47 @@ def run_ref_llava(c, steps, threads=4):
     return ids, toks, logits
 
 
+def run_ref_llava_parts(c, steps, threads=4, n_text=10, keep=None):
+    """The reference's LLaVA graph composed from its own modules with the position ids as an input (oracle/ref_drivers/ref_llava_parts.cpp): the
+    whole-graph run LLaVAModel itself cannot give at this snapshot.  Returns ids, greedy tokens, last-row logits per step, projected visual rows."""
+    td, path = keep if keep else _ref_weights(synth.llava_tensors(c), mf.Q4_K)
+    ids, img = synth.llava_inputs(c, n_text)
+    ids.tofile(os.path.join(td, "ids.i32"))
+    img.tofile(os.path.join(td, "img.f32"))
+    cfg = f"{c.hidden},{c.heads},{c.inter},{c.layers},{c.vocab},{c.cache_limit},{c.v_hidden},{c.v_heads},{c.v_ffn},{c.v_blocks},{c.patch},{c.img}"
+    base = [os.path.join(REF, "ref_llava_parts"), "--model", path, "--ids", os.path.join(td, "ids.i32"), "--img", os.path.join(td, "img.f32"), "--threads",
+            str(threads), "--out", td, "--cfg", cfg]
+    subprocess.run(base + ["--dump-vision", "1"], check=True, capture_output=True, text=True)
+    vis = np.fromfile(os.path.join(td, "vision.f32"), dtype=np.float32).reshape(c.v_tokens, c.v_ffn)
+    out = subprocess.run(base + ["--steps", str(steps)], check=True, capture_output=True, text=True)
+    toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
+    logits = np.stack([np.fromfile(os.path.join(td, f"logits_{s}.f32"), dtype=np.float32) for s in range(steps)])
+    if not keep:
+        os.remove(path)
+    return ids, toks, logits, vis, out.stdout.strip().splitlines()[-1]
+
+
 def llava_tiny():
-    """BASELINE config 5 (demo_llava) at a toy shape with the real head geometry (CLIP head_dim 64, LLaMA head_dim 128, vocab 32064).
-    Not runnable at the 2025-10-31 reference snapshot: LLaVAModel segfaults inside Tensor::range (see oracle/ref_drivers/ref_llava.cpp)."""
-    ids, tok, log = run_ref_llava(synth.llava_tiny(), 6)
+    """BASELINE config 5 (demo_llava) at a toy shape with the real head geometry (CLIP head_dim 64, LLaMA head_dim 128, vocab 32064): every logit
+    of 6 steps and every projected visual row of the reference's run (ref_llava_parts: see its header for why not LLaVAModel itself)."""
+    ids, tok, log, vis, timing = run_ref_llava_parts(synth.llava_tiny(), 6)
+    np.savez_compressed(os.path.join(GOLD, "llava_tiny.npz"), ids=ids, tokens=tok, logits=log, vision=vis)
+    print("llava_tiny.npz", tok.tolist(), timing)
+
+
+def llava_full(path=None):
+    """LLaVA-1.5-7B geometry (4096 / 11008 / 32 heads x 128, 32 layers, vocab 32064) + CLIP-ViT-L/14-336 (1024 / 4096 / 16 heads x 64, 23 blocks,
+    577 tokens) on synthetic Q4_K weights: 14-token prompt with one image (S = 589 after the splice) + 5 decode steps.  Stored: greedy ids, top-64
+    and every 97th logit of each step, and every 61st projected visual row (all 4096 columns)."""
+    c = synth.llava_7b()
+    keep = None
+    if path:      # a file weights.llava_file() wrote with the fixture quantiser (byte-identical to the reference tool's, tests/test_host.py)
+        keep = (tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP")), path)
+    ids, tok, log, vis, timing = run_ref_llava_parts(c, 6, threads=8, keep=keep)
     ti, tv, st = _sampled(log)
-    np.savez_compressed(os.path.join(GOLD, "llava_tiny.npz"), ids=ids, tokens=tok, top_idx=ti, top_val=tv, strided=st, row0=log[0])
-    print("llava_tiny.npz", tok.tolist())
+    np.savez_compressed(os.path.join(GOLD, "llava_7b.npz"), ids=ids, tokens=tok, top_idx=ti, top_val=tv, strided=st, vision_rows=vis[::61],
+                        timing=np.frombuffer(timing.encode(), dtype=np.uint8))
+    print("llava_7b.npz", tok.tolist(), timing)
 
 
 def _sampled(logits):
@@ -312,6 +346,10 @@ def configs_full():
 if __name__ == "__main__":
     if "--llava" in sys.argv:
         llava_tiny()
+        sys.exit(0)
+    if "--llava-full" in sys.argv:
+        i = sys.argv.index("--llava-full")
+        llava_full(sys.argv[i + 1] if i + 1 < len(sys.argv) else None)
         sys.exit(0)
     if "--configs" in sys.argv:
         configs_tiny()

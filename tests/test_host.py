@@ -25,12 +25,17 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_quantized_nbytes_and_errors():
-    so = lib.load()
-    assert so.mllm_hip_quantized_nbytes(lib.Q4_K, 512) == 288
-    assert so.mllm_hip_quantized_nbytes(lib.Q4_0, 64) == 36
-    assert so.mllm_hip_quantized_nbytes(lib.Q4_K, 100) == -1
+    from tools import quantlib
+    assert quantlib.nbytes(quantlib.Q4_K, 512) == 288
+    assert quantlib.nbytes(quantlib.Q4_0, 64) == 36
+    assert quantlib.nbytes(quantlib.Q4_K, 100) == -1
     with pytest.raises(lib.MllmHipError):
         lib.quantize_host(lib.Q4_K, np.zeros(100, dtype=np.float32))
+
+
+def test_product_library_does_not_contain_the_fixture_quantiser():
+    so = lib.load()
+    assert not hasattr(so, "mllm_hip_quantize_host") and not hasattr(so, "mllm_quant_rows")
 
 
 def test_mllm_file_roundtrip(tmp_path):
@@ -66,6 +71,18 @@ def test_host_quantizer_matches_reference_tool_digests(tmp_path):
     got = weights.tensor_digests(path)
     assert set(got) == set(want)
     bad = [n for n in want if got[n] != want[n]]
+    assert not bad, bad[:5]
+
+
+def test_host_quantizer_full_size_digests():
+    """The same at the benchmark's size: the 729 tensors of the Qwen2-VL-2B shaped synthetic model (2.2 B parameters) written by the fixture quantiser
+    against the digests of the file the reference's `quantize ... Q4_K` wrote from the same fp32 tensors (that file also holds an untied lm_head the
+    tied config never reads).  Uses the cached file when bench.py / the GPU tests have built it already; about a minute on 8 cores otherwise."""
+    want = json.load(open(os.path.join(GOLD, "qwen2vl_2b_q4k_digests.json")))
+    path = weights.qwen2vl_file(synth.qwen2vl_2b(), cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
+    got = weights.tensor_digests(path)
+    assert len(got) == 729 and set(got) <= set(want)
+    bad = [n for n in got if got[n] != want[n]]
     assert not bad, bad[:5]
 
 

@@ -1,4 +1,8 @@
-// mllm_amd/csrc/host_quantize.cpp
+// tools/quantizer/host_quantize.cpp -- FIXTURE TOOLING, not part of libmllm_hip.so and not declared in include/mllm_hip.h.
+//
+// Built into tools/libmllm_quant.so (tools/quantlib.py) and used only to write the synthetic `*-q4_k.mllm` files the tests and bench.py
+// run on.  The K-quant scale fit below has to produce the reference tool's bytes, so fit_group / q4k_block follow make_qkx2_quants /
+// quantize_row_q4_K_reference (QuantizeQ4.cpp:97-293) operation by operation; that closeness is why the file lives with the tooling.
 //
 // Host-side weight quantisers of the .mllm tool-chain: fp32 -> Q4_K / Q4_0 / Q8_0 blocks, byte-compatible with the
 // reference's `quantize` tool (tools/quantizer/QuantWriter.cpp:288-300 dispatch;
@@ -7,7 +11,7 @@
 // (the GPU box): SURVEY §8 row N1 / component 18.  Every fused multiply-add the reference binary (g++ -O2 -mfma, default
 // contraction) performs in the K-quant scale fit is written here as an explicit fmaf() and this file is compiled with
 // -ffp-contract=off, so the search rounds identically whatever the compiler; the byte-for-byte
-// agreement with the reference tool is checked by tests/test_quantizer.py against a committed digest.
+// agreement with the reference tool is checked by tests/test_host.py against committed digests (tests/golden/*_digests.json).
 //
 // Rows are independent, so quantisation is parallelised over blocks with OpenMP (the reference tool is serial).
 #include <cmath>
@@ -15,7 +19,9 @@
 #include <cstring>
 #include <immintrin.h>
 
-#include "../../include/mllm_hip.h"
+
+// DataType values of mllm/Types.hpp:63-97
+enum { QT_F32 = 0, QT_F16 = 1, QT_Q4_0 = 2, QT_Q8_0 = 8, QT_Q4_K = 12, QT_Q8_K = 15 };
 
 namespace {
 
@@ -205,36 +211,36 @@ void q4k_block(const float *x, BlockQ4K *y) {
 
 }  // namespace
 
-extern "C" int64_t mllm_hip_quantized_nbytes(int dtype, int64_t n) {
+extern "C" int64_t mllm_quant_nbytes(int dtype, int64_t n) {
     switch (dtype) {
-    case MLLM_HIP_F32: return n * 4;
-    case MLLM_HIP_F16: return n * 2;
-    case MLLM_HIP_Q4_0: return n % 32 ? -1 : n / 32 * 18;
-    case MLLM_HIP_Q8_0: return n % 32 ? -1 : n / 32 * 34;
-    case MLLM_HIP_Q4_K: return n % 256 ? -1 : n / 256 * 144;
-    case MLLM_HIP_Q8_K: return n % 256 ? -1 : n / 256 * 292;
+    case QT_F32: return n * 4;
+    case QT_F16: return n * 2;
+    case QT_Q4_0: return n % 32 ? -1 : n / 32 * 18;
+    case QT_Q8_0: return n % 32 ? -1 : n / 32 * 34;
+    case QT_Q4_K: return n % 256 ? -1 : n / 256 * 144;
+    case QT_Q8_K: return n % 256 ? -1 : n / 256 * 292;
     default: return -1;
     }
 }
 
-extern "C" int mllm_hip_quantize_host(int dtype, const float *x, void *y, int64_t n) {
-    if (mllm_hip_quantized_nbytes(dtype, n) < 0) return MLLM_HIP_ERR_SHAPE;
-    if (dtype == MLLM_HIP_Q4_K) {
+extern "C" int mllm_quant_rows(int dtype, const float *x, void *y, int64_t n) {
+    if (mllm_quant_nbytes(dtype, n) < 0) return -2;
+    if (dtype == QT_Q4_K) {
         const int64_t nb = n / 256;
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < nb; ++i) q4k_block(x + i * 256, (BlockQ4K *)y + i);
-    } else if (dtype == MLLM_HIP_Q4_0) {
+    } else if (dtype == QT_Q4_0) {
         const int64_t nb = n / 32;
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < nb; ++i) q40_block(x + i * 32, (BlockQ40 *)y + i);
-    } else if (dtype == MLLM_HIP_Q8_0) {
+    } else if (dtype == QT_Q8_0) {
         const int64_t nb = n / 32;
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < nb; ++i) q80_block(x + i * 32, (BlockQ80 *)y + i);
-    } else if (dtype == MLLM_HIP_F32) {
+    } else if (dtype == QT_F32) {
         std::memcpy(y, x, n * 4);
     } else {
-        return MLLM_HIP_ERR_DTYPE;
+        return -3;
     }
-    return MLLM_HIP_OK;
+    return 0;
 }
