@@ -490,7 +490,8 @@ extern "C" int mllm_hip_model_create(const mllm_hip_model_config *cfg, const cha
     M *m = new M();
     m->c = *cfg;
     m->has_llm = has_llm;
-    m->vkind = vkind;
+    // a text-only Qwen2-VL file (no visual.* tensors) loads as the language model alone, as the reference's loader would leave the tower unset
+    m->vkind = (vkind == V_QWEN2VL && !f.find("visual.patch_embed.proj.weight")) ? V_NONE : vkind;
     m->mrope = c0.arch == MLLM_HIP_ARCH_QWEN2VL;
     m->prefix = c0.arch == MLLM_HIP_ARCH_LLAVA ? "language_model." : "";
     if (has_llm) {

@@ -169,19 +169,26 @@ __device__ __forceinline__ void fa2_decode_fetch_v(uint4 *dst, const void *V, in
         }
     }
 }
+// `part`: 0 = everything (speculative: rows below `cap` always exist), 1 = only the first NT/8 keys of the staged form (speculative), 2 = the rest of
+// the staged form, limited to keys below `nkeys` (issued once the key count is known: at short contexts the fixed-size speculative fetch read up to 40x
+// the bytes the step needs)
 template <int D, bool F16, int NT, bool VT>
 __device__ __forceinline__ void fa2_decode_prefetch(DecodePrefetch<D, F16, NT, VT> &P, const void *K, int64_t ldk, const void *V, int64_t ldv, int kvoff,
-                                                    int cap, int nslots) {
-    P.etab = expf_tab_fetch();
+                                                    int cap, int nslots, int part = 0, int nkeys = 0) {
+    if (part != 2) P.etab = expf_tab_fetch();
     if (VT && nslots == 4 && fa_kstage_fits<D, NT>()) {
         // coalesced: one wave instruction = 1 KiB of consecutive key rows (the strided per-lane form below costs one cache line per lane)
         constexpr int ROWK = D * 2 / 16;
+        constexpr int NSPEC = (D / 16) / 4 > 0 ? (D / 16) / 4 : 1;     // vectors per thread of the speculative part: NT * NSPEC / ROWK keys
 #pragma unroll
         for (int i = 0; i < D / 16; ++i) {
-            const int vi = threadIdx.x + NT * i, key = min(vi / ROWK, cap - 1), part = vi % ROWK;
-            P.kc[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(K) + (int64_t)key * ldk + kvoff + part * 8);
+            if (part == 1 && i >= NSPEC) continue;
+            if (part == 2 && i < NSPEC) continue;
+            const int vi = threadIdx.x + NT * i, key = min(vi / ROWK, cap - 1), part16 = vi % ROWK;
+            if (part == 2 && key >= nkeys) continue;
+            P.kc[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(K) + (int64_t)key * ldk + kvoff + part16 * 8);
         }
-    } else if (F16) {
+    } else if (F16 && part != 2) {
         const int j = min((int)threadIdx.x >> 1, cap - 1), hf = threadIdx.x & 1;
         const uint16_t *kp = reinterpret_cast<const uint16_t *>(K) + (int64_t)j * ldk + kvoff + 4 * hf;
 #pragma unroll

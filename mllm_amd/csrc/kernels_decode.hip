@@ -45,12 +45,12 @@ namespace mllm_hip {
 constexpr bool g_nt = MLLM_HIP_NT != 0;
 
 #ifdef MLLM_HIP_STAMPS
-__device__ unsigned long long g_stamps[8192 * 8];
+__device__ unsigned long long g_stamps[8192 * 16];
 #define STAMP(i)                                                                                         \
     do {                                                                                                 \
         if (threadIdx.x == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) {                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
+            g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
@@ -58,16 +58,16 @@ __device__ unsigned long long g_stamps[8192 * 8];
     do {                                                                                                 \
         if (threadIdx.x == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) {                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memtime();                               \
+            g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = __builtin_amdgcn_s_memtime();                               \
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
-#define STAMPV(i, v) do { if (threadIdx.x == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = (v); } while (0)
+#define STAMPV(i, v) do { if (threadIdx.x == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = (v); } while (0)
 #define STAMPT(i, t)                                                                                     \
     do {                                                                                                 \
         if (threadIdx.x == (t) && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) {                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
+            g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                           \
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
@@ -623,21 +623,29 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__r
 // qkv: [Hq*D | Hkv*D | Hkv*D] fp32 of this token.  K slab [cache_limit][Hkv*D] fp16, V slab transposed [Hkv*D][vt_ld] fp16.  out: [Hq*D] fp32.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int DEC_ATTN_NT = 1024;
+// Workgroup placement: the heads of one K/V group read the same slab rows, so they are given equal blockIdx.x % 8 -- workgroups b and b + 8 share an XCD
+// (and its L2) under the dispatcher's round-robin, a speed matter only.  K/V head k sits in column k % 8; inside a column the order is (k / 8, head of the
+// group).  Grid = 8 * ceil(Hkv / 8) * (Hq / Hkv) workgroups; those whose K/V head does not exist leave at once.
+__host__ __device__ static inline int dec_attn_grid(int Hq, int Hkv) { return 8 * ((Hkv + 7) / 8) * (Hq / Hkv); }
 template <int D>
 __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
                                                                const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
-                                                               float *__restrict__ out, int Hq, int Hkv, int cache_limit, int vt_ld, int nslots) {
+                                                               float *__restrict__ out, int Hq, int Hkv, int cache_limit, int vt_ld, int nslots, int flags) {
     constexpr int HALF = D / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint16_t knew[D];
     __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
+    const int gsize = Hq / Hkv;
+    int kvh, gh;
+    if (flags & 1) { const int col = blockIdx.x & 7, idx = blockIdx.x >> 3; kvh = (idx / gsize) * 8 + col; gh = idx % gsize; }
+    else { kvh = blockIdx.x / gsize; gh = blockIdx.x % gsize; }
+    if (kvh >= Hkv) return;
+    const int head = kvh * gsize + gh;
     const DecodeLds L = carve_decode(smem, cache_limit, D, DEC_ATTN_NT, nslots);
     const int tid = threadIdx.x;
-    // grid = (Hq / Hkv, Hkv): no run-time division on the way to the first loads
-    const int gsize = gridDim.x, kvh = blockIdx.y, head = kvh * gsize + blockIdx.x;
     const int HD = Hq * D, KVD = Hkv * D;
     // the step's own small operands first (vmcnt retires in issue order), then -- speculatively, T only masks them afterwards -- the
-    // slab rows of the first pass
+    // slab rows of the first keys; the remaining rows of the first pass once T has arrived
     STAMP(1);
     const int T_raw = state->T;
     float qa = 0.0f, qb = 0.0f, sn = 0.0f, cs = 0.0f;
@@ -646,9 +654,12 @@ __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState
     else if (tid < 2 * D) qa = qkv[HD + KVD + kvh * D + (tid - D)];
     __builtin_amdgcn_sched_barrier(0);
     DecodePrefetch<D, true, DEC_ATTN_NT, true> P;
-    fa2_decode_prefetch<D, true, DEC_ATTN_NT, true>(P, kslab, KVD, vslab, vt_ld, kvh * D, cache_limit, nslots);
+    const bool two_stage = flags & 2;
+    fa2_decode_prefetch<D, true, DEC_ATTN_NT, true>(P, kslab, KVD, vslab, vt_ld, kvh * D, cache_limit, nslots, two_stage ? 1 : 0);
     __builtin_amdgcn_sched_barrier(0);
     const int T = min(T_raw, cache_limit - 1), Sk = T + 1;
+    if (two_stage) fa2_decode_prefetch<D, true, DEC_ATTN_NT, true>(P, kslab, KVD, vslab, vt_ld, kvh * D, cache_limit, nslots, 2, T);
+    __builtin_amdgcn_sched_barrier(0);
     if (tid < HALF) {
         L.qs[tid] = __fmaf_rn(qa, cs, -(qb * sn));
         L.qs[tid + HALF] = __fmaf_rn(qa, sn, qb * cs);
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState
         vnew[tid - D] = f2h(qa);
     }
     __syncthreads();
-    if (blockIdx.x == 0 && tid < D) {
+    if (gh == 0 && tid < D) {
         kslab[(int64_t)T * KVD + kvh * D + tid] = knew[tid];
         vslab[(int64_t)(kvh * D + tid) * vt_ld + T] = vnew[tid];
     }
@@ -987,17 +998,19 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.kv_heads * c.D * c.vt_ld;
         const int nslots = decode_lds_slots(c.cache_limit, c.D, DEC_ATTN_NT, 2, true);
         const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
-        if (c.D == 128) {
-            rc = allow_lds(dec_attn_kernel<128>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((dec_attn_kernel<128>), dim3(c.heads / c.kv_heads, c.kv_heads), dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws,
-                               c.heads, c.kv_heads, c.cache_limit, c.vt_ld, nslots);
-        } else {
-            rc = allow_lds(dec_attn_kernel<64>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((dec_attn_kernel<64>), dim3(c.heads / c.kv_heads, c.kv_heads), dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws,
-                               c.heads, c.kv_heads, c.cache_limit, c.vt_ld, nslots);
-        }
+        // bit 0: XCD placement of a K/V group's heads, bit 1: two-stage key fetch (both neutral in time at T = 290..430, profiles/r02_attn_experiments.md;
+        // the second keeps the fetched bytes near the algorithmic ones at short contexts)
+        static const int flags = getenv("MLLM_HIP_ATTN_FLAGS") ? atoi(getenv("MLLM_HIP_ATTN_FLAGS")) : 3;
+        const dim3 grid((flags & 1) ? dec_attn_grid(c.heads, c.kv_heads) : c.heads);
+#define DEC_ATTN_CASE(DD)                                                                                                                          \
+    {                                                                                                                                              \
+        rc = allow_lds(dec_attn_kernel<DD>, lds);                                                                                                  \
+        if (rc) return rc;                                                                                                                         \
+        hipLaunchKernelGGL((dec_attn_kernel<DD>), grid, dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads, \
+                           c.kv_heads, c.cache_limit, c.vt_ld, nslots, flags);                                                                     \
+    }
+        if (c.D == 128) DEC_ATTN_CASE(128) else DEC_ATTN_CASE(64)
+#undef DEC_ATTN_CASE
         return MH_LAUNCH_OK("dec_attn");
     }
     case 2:

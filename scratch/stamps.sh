@@ -1,11 +1,10 @@
 #!/bin/bash
 # diagnostic build with in-kernel stamps into a scratch .so (never the production library); extra -D flags via $1
 set -e
-cd /root/repo/mllm_amd/csrc
+cd "$(dirname "$0")/../mllm_amd/csrc"
 mkdir -p /tmp/stampobj
-for f in runtime kernels_elem kernels_linear kernels_attn kernels_decode engine; do
+for f in runtime kernels_elem kernels_linear kernels_attn kernels_decode kernels_sample engine; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DMLLM_HIP_STAMPS $1 -c $f.hip -o /tmp/stampobj/$f.o &
 done
-g++ -std=c++17 -O2 -mavx2 -mf16c -mfma -ffp-contract=off -fopenmp -fPIC -c host_quantize.cpp -o /tmp/stampobj/hq.o
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libmllm_hip_stamps.so /tmp/stampobj/*.o -fopenmp -lgomp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libmllm_hip_stamps.so /tmp/stampobj/*.o -L/opt/rocm/lib -lrccl
