@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NT) void fa2_decode_kernel(const float *__restrict_
     const DecodeLds L = carve_decode(fa_smem, cap, D, NT, nslots);
     if (threadIdx.x < D) L.qs[threadIdx.x] = Q[head * D + threadIdx.x];
     __syncthreads();
-    fa2_decode_head<D, F16, NT, VT>(L, P, K, ldk, V, ldv, kvh * D, Sk, cap, nullptr, nullptr, -1);
+    fa2_decode_head<D, F16, NT, VT>(L, P, K, ldk, V, ldv, kvh * D, kvh * D, Sk, cap, nullptr, nullptr, -1);
     if (threadIdx.x < D) O[head * D + threadIdx.x] = L.ob[threadIdx.x];
 }
 }  // namespace mllm_hip

@@ -134,19 +134,22 @@ __device__ __forceinline__ DecodeLds carve_decode(char *smem, int cap, int D, in
 // reads 8 keys per ds_read_b128; with the reference layout ([key][D] rows) the walker reads one fp16 / fp32 per key.
 constexpr int FA_VPITCH = FA_VCH * 2 + 16;
 
-template <int D, bool F16, int NT, bool VT>
+// DV (transposed slab only): the value dims THIS workgroup walks.  The decode kernel splits a head's D dims over D / DV workgroups: every one of them computes
+// the scores (it needs all of K) but fetches, parks and walks only its DV rows of V -- the front half of the kernel is bound by what one CU can pull from HBM.
+template <int D, bool F16, int NT, bool VT, int DV = D>
 struct DecodeGeom {
+    static_assert(DV == D || VT, "a dim slice needs the transposed slab");
     static constexpr int ELT = F16 ? 2 : 4;
     static constexpr int ROWV = VT ? FA_VCH * 2 / 16 : D * ELT / 16;   // 16-byte vectors per ring row
-    static constexpr int CHV = VT ? D * ROWV : FA_VCH * ROWV;          // vectors per chunk
+    static constexpr int CHV = VT ? DV * ROWV : FA_VCH * ROWV;         // vectors per chunk
     static constexpr int VPT = (CHV + NT - 1) / NT;                    // vectors per thread per chunk
-    static constexpr size_t SLOT = VT ? (size_t)D * FA_VPITCH : (size_t)FA_VCH * D * ELT;
+    static constexpr size_t SLOT = VT ? (size_t)DV * FA_VPITCH : (size_t)FA_VCH * D * ELT;
 };
 // What a thread requests from memory before anything else in the kernel (speculatively: rows below `cap` always exist): its half of
 // the key row of pass 0 and its vectors of the first V chunks.  The loads fly while the prologue (rotary, barriers) runs.
-template <int D, bool F16, int NT, bool VT>
+template <int D, bool F16, int NT, bool VT, int DV = D>
 struct DecodePrefetch {
-    uint4 v[4][DecodeGeom<D, F16, NT, VT>::VPT];
+    uint4 v[4][DecodeGeom<D, F16, NT, VT, DV>::VPT];
     uint2 k[F16 ? D / 8 : 1];     // direct form: this lane's half of its key row (strided 8-byte pieces)
     uint4 kc[VT ? D / 16 : 1];    // staged form: coalesced 16-byte pieces of the pass-0 key rows, parked in the (not yet used) V ring
     uint64_t etab;                // this lane's entry of glibc_expf's table (requested with the other early loads, stored to LDS later)
@@ -156,9 +159,9 @@ template <int D>
 __host__ __device__ constexpr int fa_kpitch() { return D * 2 + 16; }
 template <int D, int NT>
 __host__ __device__ constexpr bool fa_kstage_fits() { return (size_t)(NT / 2) * fa_kpitch<D>() <= (size_t)4 * D * (FA_VCH * 2 + 16); }
-template <int D, bool F16, int NT, bool VT>
+template <int D, bool F16, int NT, bool VT, int DV = D>
 __device__ __forceinline__ void fa2_decode_fetch_v(uint4 *dst, const void *V, int64_t ldv, int kvoff, int ch, int cap) {
-    using G = DecodeGeom<D, F16, NT, VT>;
+    using G = DecodeGeom<D, F16, NT, VT, DV>;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < G::VPT; ++i) {
@@ -172,8 +175,8 @@ __device__ __forceinline__ void fa2_decode_fetch_v(uint4 *dst, const void *V, in
 // `part`: 0 = everything (speculative: rows below `cap` always exist), 1 = only the first NT/8 keys of the staged form (speculative), 2 = the rest of
 // the staged form, limited to keys below `nkeys` (issued once the key count is known: at short contexts the fixed-size speculative fetch read up to 40x
 // the bytes the step needs)
-template <int D, bool F16, int NT, bool VT>
-__device__ __forceinline__ void fa2_decode_prefetch(DecodePrefetch<D, F16, NT, VT> &P, const void *K, int64_t ldk, const void *V, int64_t ldv, int kvoff,
+template <int D, bool F16, int NT, bool VT, int DV = D>
+__device__ __forceinline__ void fa2_decode_prefetch(DecodePrefetch<D, F16, NT, VT, DV> &P, const void *K, int64_t ldk, const void *V, int64_t ldv, int kvoff,
                                                     int cap, int nslots, int part = 0, int nkeys = 0) {
     if (part != 2) P.etab = expf_tab_fetch();
     if (VT && nslots == 4 && fa_kstage_fits<D, NT>()) {
@@ -200,11 +203,12 @@ __device__ __forceinline__ void fa2_decode_prefetch(DecodePrefetch<D, F16, NT, V
 // ring slot of chunk ch: the usual 4-slot ring needs no division
 __device__ __forceinline__ int fa_slot(int ch, int nslots) { return nslots == 4 ? (ch & 3) : ch % nslots; }
 
-template <int D, bool F16, int NT, bool VT = false>
-__device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefetch<D, F16, NT, VT> &P, const void *K, int64_t ldk, const void *V,
-                                                int64_t ldv, int kvoff, int Sk, int cap, const uint16_t *knew, const uint16_t *vnew, int tnew) {
+// voff: first V row of this workgroup (kvoff + its dim slice); vnew points at the slice's first element
+template <int D, bool F16, int NT, bool VT = false, int DV = D>
+__device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefetch<D, F16, NT, VT, DV> &P, const void *K, int64_t ldk, const void *V,
+                                                int64_t ldv, int kvoff, int voff, int Sk, int cap, const uint16_t *knew, const uint16_t *vnew, int tnew) {
     static_assert(!VT || F16, "the transposed slab is fp16");
-    using G = DecodeGeom<D, F16, NT, VT>;
+    using G = DecodeGeom<D, F16, NT, VT, DV>;
     constexpr int VPT = G::VPT, ROWV = G::ROWV, CHV = G::CHV;
     constexpr size_t SLOT = G::SLOT;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -237,7 +241,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-        if (s < npre) fa2_decode_fetch_v<D, F16, NT, VT>(P.v[s], V, ldv, kvoff, s, cap);
+        if (s < npre) fa2_decode_fetch_v<D, F16, NT, VT, DV>(P.v[s], V, ldv, voff, s, cap);
     if (kstaged) __syncthreads();
     // ---- A + B: two lanes per key (chains l = 0..3 and 4..7), NT/2 keys per pass ------------------------------------------------------
     float carry = FA_NEG;
@@ -330,11 +334,11 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
     // c_j is stored as exactly 1.0f when the maximum did not move, so "o * c" and "fma(logsum, c, p)" may be evaluated for every key
     // (x * 1.0f == x, fma(x, 1.0f, p) == x + p bit for bit); the mask only spares the common step the LDS reads of c.
     float o = 0.0f, lsum = 0.0f;
-    const bool walker = tid < D, summer = tid == ((D + 63) & ~63);
+    const bool walker = tid < DV, summer = tid == ((DV + 63) & ~63);
     uint4 vref[VPT];
     for (int ch = 0; ch < nch; ++ch) {
         const bool refill = ch + L.nslots < nch;
-        if (refill) fa2_decode_fetch_v<D, F16, NT, VT>(vref, V, ldv, kvoff, ch + L.nslots, cap);
+        if (refill) fa2_decode_fetch_v<D, F16, NT, VT, DV>(vref, V, ldv, voff, ch + L.nslots, cap);
         const int j0 = ch * FA_VCH, n = min(FA_VCH, nkv - j0);
         // the chunk's 128 mask bits, wave-uniform in SGPRs (one LDS read per chunk instead of one per step on the critical path)
         unsigned long long chunk_mask_lo, chunk_mask_hi;
@@ -493,7 +497,7 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
                 if (k16 + 16 < ns) { rd(k16 + 32, A); step(k16 + 16, B); }
             }
         }
-        if (ch == nch - 1) { STAMPT(5, 0); STAMPT(6, 64); STAMPT(7, (D + 63) & ~63); }
+        if (ch == nch - 1) { STAMPT(5, 0); STAMPT(6, DV > 64 ? 64 : 0); STAMPT(7, (DV + 63) & ~63); }
         if (nch > L.nslots) __syncthreads();   // only a ring that gets refilled needs the walkers and the parking threads to meet per chunk (T <= nslots * 128 keys: never)
         if (refill) park_chunk(ch + L.nslots, vref);
     }

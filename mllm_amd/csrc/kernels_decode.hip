@@ -626,8 +626,9 @@ constexpr int DEC_ATTN_NT = 1024;
 // Workgroup placement: the heads of one K/V group read the same slab rows, so they are given equal blockIdx.x % 8 -- workgroups b and b + 8 share an XCD
 // (and its L2) under the dispatcher's round-robin, a speed matter only.  K/V head k sits in column k % 8; inside a column the order is (k / 8, head of the
 // group).  Grid = 8 * ceil(Hkv / 8) * (Hq / Hkv) workgroups; those whose K/V head does not exist leave at once.
-__host__ __device__ static inline int dec_attn_grid(int Hq, int Hkv) { return 8 * ((Hkv + 7) / 8) * (Hq / Hkv); }
-template <int D>
+// DS: workgroups per head (dim split): each computes the head's scores and softmax statistics and walks D / DS of its value dims.
+__host__ __device__ static inline int dec_attn_grid(int Hq, int Hkv, int ds) { return 8 * ((Hkv + 7) / 8) * (Hq / Hkv) * ds; }
+template <int D, int DS>
 __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
                                                                const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
                                                                float *__restrict__ out, int Hq, int Hkv, int cache_limit, int vt_ld, int nslots, int flags) {
@@ -635,11 +636,13 @@ __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint16_t knew[D];
     __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
-    const int gsize = Hq / Hkv;
-    int kvh, gh;
-    if (flags & 1) { const int col = blockIdx.x & 7, idx = blockIdx.x >> 3; kvh = (idx / gsize) * 8 + col; gh = idx % gsize; }
-    else { kvh = blockIdx.x / gsize; gh = blockIdx.x % gsize; }
+    constexpr int DV = D / DS;
+    const int gsize = Hq / Hkv, per_kv = gsize * DS;
+    int kvh, sub;
+    if (flags & 1) { const int col = blockIdx.x & 7, idx = blockIdx.x >> 3; kvh = (idx / per_kv) * 8 + col; sub = idx % per_kv; }
+    else { kvh = blockIdx.x / per_kv; sub = blockIdx.x % per_kv; }
     if (kvh >= Hkv) return;
+    const int gh = sub / DS, vdim0 = (sub % DS) * DV;
     const int head = kvh * gsize + gh;
     const DecodeLds L = carve_decode(smem, cache_limit, D, DEC_ATTN_NT, nslots);
     const int tid = threadIdx.x;
@@ -653,12 +656,12 @@ __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState
     else if (tid < D) { const float *kp = qkv + HD + kvh * D; qa = kp[tid - HALF]; qb = kp[tid]; sn = sin_t[tid - HALF]; cs = cos_t[tid - HALF]; }
     else if (tid < 2 * D) qa = qkv[HD + KVD + kvh * D + (tid - D)];
     __builtin_amdgcn_sched_barrier(0);
-    DecodePrefetch<D, true, DEC_ATTN_NT, true> P;
+    DecodePrefetch<D, true, DEC_ATTN_NT, true, DV> P;
     const bool two_stage = flags & 2;
-    fa2_decode_prefetch<D, true, DEC_ATTN_NT, true>(P, kslab, KVD, vslab, vt_ld, kvh * D, cache_limit, nslots, two_stage ? 1 : 0);
+    fa2_decode_prefetch<D, true, DEC_ATTN_NT, true, DV>(P, kslab, KVD, vslab, vt_ld, kvh * D, cache_limit, nslots, two_stage ? 1 : 0);
     __builtin_amdgcn_sched_barrier(0);
     const int T = min(T_raw, cache_limit - 1), Sk = T + 1;
-    if (two_stage) fa2_decode_prefetch<D, true, DEC_ATTN_NT, true>(P, kslab, KVD, vslab, vt_ld, kvh * D, cache_limit, nslots, 2, T);
+    if (two_stage) fa2_decode_prefetch<D, true, DEC_ATTN_NT, true, DV>(P, kslab, KVD, vslab, vt_ld, kvh * D, cache_limit, nslots, 2, T);
     __builtin_amdgcn_sched_barrier(0);
     if (tid < HALF) {
         L.qs[tid] = __fmaf_rn(qa, cs, -(qb * sn));
@@ -670,12 +673,12 @@ __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState
         vnew[tid - D] = f2h(qa);
     }
     __syncthreads();
-    if (gh == 0 && tid < D) {
+    if (sub == 0 && tid < D) {
         kslab[(int64_t)T * KVD + kvh * D + tid] = knew[tid];
         vslab[(int64_t)(kvh * D + tid) * vt_ld + T] = vnew[tid];
     }
-    fa2_decode_head<D, true, DEC_ATTN_NT, true>(L, P, kslab, KVD, vslab, vt_ld, kvh * D, Sk, cache_limit, knew, vnew, T);
-    if (tid < D) out[head * D + tid] = L.ob[tid];
+    fa2_decode_head<D, true, DEC_ATTN_NT, true, DV>(L, P, kslab, KVD, vslab, vt_ld, kvh * D, kvh * D + vdim0, Sk, cache_limit, knew, vnew + vdim0, T);
+    if (tid < DV) out[head * D + vdim0 + tid] = L.ob[tid];
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1001,15 +1004,18 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         // bit 0: XCD placement of a K/V group's heads, bit 1: two-stage key fetch (both neutral in time at T = 290..430, profiles/r02_attn_experiments.md;
         // the second keeps the fetched bytes near the algorithmic ones at short contexts)
         static const int flags = getenv("MLLM_HIP_ATTN_FLAGS") ? atoi(getenv("MLLM_HIP_ATTN_FLAGS")) : 3;
-        const dim3 grid((flags & 1) ? dec_attn_grid(c.heads, c.kv_heads) : c.heads);
-#define DEC_ATTN_CASE(DD)                                                                                                                          \
-    {                                                                                                                                              \
-        rc = allow_lds(dec_attn_kernel<DD>, lds);                                                                                                  \
-        if (rc) return rc;                                                                                                                         \
-        hipLaunchKernelGGL((dec_attn_kernel<DD>), grid, dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads, \
-                           c.kv_heads, c.cache_limit, c.vt_ld, nslots, flags);                                                                     \
+        static const int ds_env = getenv("MLLM_HIP_ATTN_DS") ? atoi(getenv("MLLM_HIP_ATTN_DS")) : 0;     // workgroups per head (1, 2 or 4); 0 = default
+        const int ds = ds_env == 1 || ds_env == 2 || ds_env == 4 ? ds_env : 2;
+        const dim3 grid((flags & 1) ? dec_attn_grid(c.heads, c.kv_heads, ds) : c.heads * ds);
+#define DEC_ATTN_CASE(DD, DSV)                                                                                                                          \
+    {                                                                                                                                                   \
+        rc = allow_lds(dec_attn_kernel<DD, DSV>, lds);                                                                                                  \
+        if (rc) return rc;                                                                                                                              \
+        hipLaunchKernelGGL((dec_attn_kernel<DD, DSV>), grid, dim3(DEC_ATTN_NT), lds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, c.heads, \
+                           c.kv_heads, c.cache_limit, c.vt_ld, nslots, flags);                                                                          \
     }
-        if (c.D == 128) DEC_ATTN_CASE(128) else DEC_ATTN_CASE(64)
+        if (c.D == 128) { if (ds == 1) DEC_ATTN_CASE(128, 1) else if (ds == 2) DEC_ATTN_CASE(128, 2) else DEC_ATTN_CASE(128, 4) }
+        else { if (ds == 1) DEC_ATTN_CASE(64, 1) else if (ds == 2) DEC_ATTN_CASE(64, 2) else DEC_ATTN_CASE(64, 4) }
 #undef DEC_ATTN_CASE
         return MH_LAUNCH_OK("dec_attn");
     }
