@@ -9,6 +9,7 @@ latency-bound on 7 x 153 GB/s links, <1 % of a ViT forward -- issued on the comp
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Callable, Tuple
 
 import torch
@@ -48,3 +49,37 @@ def sharded_vision(run_vision: Callable[[torch.Tensor], torch.Tensor], batch: to
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     return gather_visual_tokens(run_vision(local_slice(batch, rank, world)), batch.shape[0], group)
+
+
+class RowGather:
+    """The same exchange through the C ABI (mllm_hip_comm_* / mllm_hip_all_gather_rows: one ncclAllGather of RCCL on a given stream) -- the form a C++ host
+    (the reference-side HIPBackend) uses, with no torch type crossing the boundary.  The 128-byte unique id travels from rank 0 to the other
+    ranks by whatever bootstrap the host has; here torch.distributed's object broadcast (only the id: the tokens never touch it)."""
+
+    def __init__(self, world: int, rank: int, group=None):
+        from . import lib as L
+        self._L, self.world, self.rank = L, world, rank
+        idbuf = (C.c_uint8 * 128)()
+        if rank == 0:
+            L.check(L.load().mllm_hip_comm_unique_id(idbuf), "comm_unique_id")
+        box = [bytes(idbuf)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self._comm = C.c_void_p()
+        L.check(L.load().mllm_hip_comm_create(box[0], C.c_int(world), C.c_int(rank), C.byref(self._comm)), "comm_create")
+
+    def gather(self, local: torch.Tensor, n_items: int, stream: int = 0) -> torch.Tensor:
+        """local `[per, tokens, hidden]` fp32 on this rank's device -> `[n_items, tokens, hidden]` on every rank, rank order, padding dropped."""
+        L = self._L
+        local = local.contiguous()
+        per = local.shape[0]
+        rows, cols = per * local.shape[1], local.shape[2]
+        full = torch.empty((self.world * per,) + tuple(local.shape[1:]), dtype=torch.float32, device=local.device)
+        L.check(L.load().mllm_hip_all_gather_rows(self._comm, L.vp(local), L.vp(full), L.i64(rows), C.c_int(cols), L.vp(stream)), "all_gather_rows")
+        L.check(L.load().mllm_hip_sync(L.vp(stream)), "sync")       # the caller reads `full` on its own stream
+        return full[:n_items]
+
+    def close(self):
+        if self._comm:
+            self._L.load().mllm_hip_comm_destroy(self._comm)
+            self._comm = C.c_void_p()

@@ -315,6 +315,35 @@ def llava_full(path=None):
     print("llava_7b.npz", tok.tolist(), timing)
 
 
+def sampling():
+    """candidate ids and pre-draw probabilities of the reference's top-k / top-p methods (oracle/ref_drivers/ref_sampling.cpp: the library's own
+    Generate.cpp code with only the random draw interposed) on fixed rows: 4 rows of 2048 logits ~ N(0, 2^2), and their softmax rows sharpened by 3 / 1 / 0.5 / 6
+    so that the nuclei at p = 0.92 span one to many hundred candidates."""
+    r = np.random.default_rng(29)
+    n, rows = 2048, 4
+    logits = (r.standard_normal((rows, n)) * 2.0).astype(np.float32)
+    probs = []
+    for i, sharp in enumerate((3.0, 1.0, 0.5, 6.0)):
+        z = logits[i].astype(np.float64) * sharp
+        e = np.exp(z - z.max())
+        probs.append((e / e.sum()).astype(np.float32))
+    probs = np.stack(probs)
+    out = {"logits": logits, "probs": probs, "k": 5, "p": np.float32(0.92), "temp": np.float32(0.7)}
+    for name, data in (("l", logits), ("s", probs)):
+        td = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP"))
+        data.tofile(os.path.join(td, "rows.f32"))
+        subprocess.run([os.path.join(REF, "ref_sampling"), "--in", os.path.join(td, "rows.f32"), "--n", str(n), "--rows", str(rows), "--k", "5", "--p", "0.92",
+                        "--temp", "0.7", "--out", td], check=True, capture_output=True, text=True)
+        for i in range(rows):
+            out[f"topk_{name}{i}_idx"] = np.fromfile(os.path.join(td, f"topk_{i}.idx"), dtype=np.uint32)
+            out[f"topk_{name}{i}_prob"] = np.fromfile(os.path.join(td, f"topk_{i}.prob"), dtype=np.float32)
+            if name == "s":
+                out[f"topp_{i}_idx"] = np.fromfile(os.path.join(td, f"topp_{i}.idx"), dtype=np.uint32)
+                out[f"topp_{i}_prob"] = np.fromfile(os.path.join(td, f"topp_{i}.prob"), dtype=np.float32)
+    np.savez_compressed(os.path.join(GOLD, "sampling.npz"), **out)
+    print("sampling.npz", [len(out[f"topp_{i}_idx"]) for i in range(rows)], out["topk_l0_idx"], out["topk_l0_prob"])
+
+
 def _sampled(logits):
     idx = np.stack([np.argsort(-l, kind="stable")[:64] for l in logits]).astype(np.int32)
     return idx, np.take_along_axis(logits, idx, axis=1), np.ascontiguousarray(logits[:, ::97])
@@ -346,6 +375,9 @@ def configs_full():
 if __name__ == "__main__":
     if "--llava" in sys.argv:
         llava_tiny()
+        sys.exit(0)
+    if "--sampling" in sys.argv:
+        sampling()
         sys.exit(0)
     if "--llava-full" in sys.argv:
         i = sys.argv.index("--llava-full")

@@ -226,8 +226,8 @@ def f32_to_f16(a):
 
 
 def topk_sampling_probs(logits, k, temperature):
-    """N2 restatement (pure Python/numpy; parity unpinned -- the reference's generate() ends in a random_device-seeded draw and exposes no
-    intermediate): _LlmTextGenerateTopkSamplingMethod::generate, mllm/Generate.cpp:56-87.  Returns (indices, values, probabilities)."""
+    """N2 restatement (pure Python/numpy) of _LlmTextGenerateTopkSamplingMethod::generate, mllm/Generate.cpp:56-87; pinned by tests/golden/sampling.npz
+    (the reference's own candidates and pre-draw probabilities, oracle/ref_drivers/ref_sampling.cpp).  Returns (indices, values, probabilities)."""
     import math
     x = np.asarray(logits, dtype=np.float32).ravel()
     order = np.argsort(-x.astype(np.float64), kind="stable")[:k]          # partial_sort by descending logit; equal logits by index
@@ -244,3 +244,21 @@ def topk_sampling_probs(logits, k, temperature):
     for i in range(k):
         soft[i] = np.float32(soft[i] / fsum)
     return order.astype(np.int32), top, soft
+
+
+def topp_sampling_probs(probs, p, temperature):
+    """N2 restatement of _LlmTextGenerateToppSamplingMethod::generate (mllm/Generate.cpp:93-142): sort all (score, index) descending, keep the prefix whose
+    running FLOAT sum reaches p (`while (p < m_p)`), then the same temperature softmax over the kept scores; pinned by tests/golden/sampling.npz.
+    Returns (indices, values, probabilities); a one-element nucleus returns probability 1."""
+    x = np.asarray(probs, dtype=np.float32).ravel()
+    order = np.argsort(-x.astype(np.float64), kind="stable")
+    acc = np.float32(0.0)
+    n = 0
+    while acc < np.float32(p):
+        acc = np.float32(acc + x[order[n]])
+        n += 1
+    idx = order[:n].astype(np.int32)
+    if n == 1:
+        return idx, x[idx], np.ones(1, dtype=np.float32)
+    _, _, soft = topk_sampling_probs(x[idx], n, temperature)      # the kept scores are already in descending order
+    return idx, x[idx], soft

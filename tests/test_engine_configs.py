@@ -166,3 +166,17 @@ def test_engine_llava_7b_geometry_matches_reference():
     assert toks == g["tokens"].tolist(), (toks, g["tokens"].tolist())
     assert max(_sample_err(g, s, lg) for s, lg in enumerate(logits)) == 0.0
     m.close()
+
+
+@pytest.mark.gpu
+def test_cabi_row_gather_single_rank():
+    """The RCCL all-gather behind the C ABI (mllm_hip_comm_*, mllm_hip_all_gather_rows) on the one GPU of this box: a world of one rank returns the local
+    rows, in order, padding dropped.  (More ranks need more GPUs; the partition / padding / order logic is covered over gloo in test_parallel_gloo.py.)"""
+    import torch
+    from mllm_amd import parallel
+    g = parallel.RowGather(1, 0)
+    x = torch.arange(3 * 5 * 8, dtype=torch.float32, device="cuda").reshape(3, 5, 8)
+    y = g.gather(x, 2)
+    torch.cuda.synchronize()
+    assert y.shape == (2, 5, 8) and torch.equal(y, x[:2])
+    g.close()
