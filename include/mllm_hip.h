@@ -130,6 +130,9 @@ int mllm_hip_mul(const float *a, const float *b, float *y, int64_t n, void *stre
 int mllm_hip_softmax(const float *x, float *y, int rows, int n, const int *valid, void *stream);
 /* CPUIndexPutFunc (op/CPUIndexPutFunc.hpp:25-92): rows of `value` replace rows idx[i] of `dst` */
 int mllm_hip_index_put_rows(float *dst, const float *value, const int *idx, int n_rows, int dim, void *stream);
+/* the data-moving case of CPUTransposeFunc (op/CPUTransposeFunc.hpp; most transposes of the graphs are metadata): y[c][r] = x[r][c].  Used by the
+ * reference-side Conv2D adapter to hand its `[oh*ow][OC]` rows back in the reference's `[OC][oh][ow]` output order (Convolution.cpp:35-82). */
+int mllm_hip_transpose_f32(const float *x, float *y, int rows, int cols, void *stream);
 /* host argmax of the logits row (processing_qwen2_vl.hpp:284-289), moved to device */
 int mllm_hip_argmax(const float *x, int n, int *out_index, void *stream);
 /* SURVEY N2, top-k sampling (mllm/Generate.cpp:45-90, _LlmTextGenerateTopkSamplingMethod::generate): the k largest logits in descending

@@ -391,6 +391,17 @@ __global__ __launch_bounds__(256) void index_put_rows_kernel(float *__restrict__
     for (int i = threadIdx.x; i < dim / 4; i += 256) out[i] = src[i];
 }
 
+// out[c][r] = in[r][c]: 32 x 32 tiles through LDS (pitch 33: conflict-free both ways), coalesced on both sides
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(int64_t)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(int64_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
 // first-maximum argmax of one row (std::max_element semantics, processing_qwen2_vl.hpp:284-289), single workgroup
 __global__ __launch_bounds__(1024) void argmax_kernel(const float *__restrict__ x, int n, int *__restrict__ out) {
     __shared__ float sv[16];
@@ -678,6 +689,12 @@ extern "C" int mllm_hip_index_put_rows(float *dst, const float *value, const int
     if (n_rows <= 0) return MLLM_HIP_OK;
     hipLaunchKernelGGL(index_put_rows_kernel, dim3(n_rows), dim3(256), 0, as_stream(stream), dst, value, idx, dim);
     return MH_LAUNCH_OK("index_put_rows");
+}
+extern "C" int mllm_hip_transpose_f32(const float *x, float *y, int rows, int cols, void *stream) {
+    if (rows <= 0 || cols <= 0) return MLLM_HIP_ERR_SHAPE;
+    if (!x || !y || x == y) return MLLM_HIP_ERR_ARG;
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, as_stream(stream), x, y, rows, cols);
+    return MH_LAUNCH_OK("transpose_f32");
 }
 extern "C" int mllm_hip_argmax(const float *x, int n, int *out_index, void *stream) {
     if (n <= 0) return MLLM_HIP_ERR_SHAPE;

@@ -349,3 +349,16 @@ def test_fa2_decode_reads_sk_from_device():
     o = ops.flash_attention2(q, torch.from_numpy(k), torch.from_numpy(v), 1, 800, 12, 2, 128, True, sk_dev=sk)
     ref = orc.attention(q, k[:300].view(np.uint16), v[:300].view(np.uint16), 1, 300, 12, 2, 128, True)
     assert eq(o, ref), md(o, ref)
+
+
+def test_transpose_f32_moves_every_element():
+    """mllm_hip_transpose_f32 (the data-moving F_TRANSPOSE case, used by the reference-side Conv2D adapter): ragged edges of the 32 x 32 tiles included."""
+    import ctypes as C
+    import torch
+    from mllm_amd import lib
+    for rows, cols in ((576, 1024), (196, 768), (33, 65), (1, 7), (31, 32)):
+        x = torch.arange(rows * cols, dtype=torch.float32, device="cuda").reshape(rows, cols)
+        y = torch.empty((cols, rows), dtype=torch.float32, device="cuda")
+        lib.check(lib.load().mllm_hip_transpose_f32(lib.vp(x), lib.vp(y), C.c_int(rows), C.c_int(cols), None), "transpose_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(y, x.t().contiguous()), (rows, cols)
