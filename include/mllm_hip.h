@@ -71,7 +71,7 @@ int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, const float 
                             float *y, int64_t ldy, int M, int N, int K, void *stream);
 /* Q4_K weights that stay resident and meet M >= 16 rows (prefill, vision tower) are packed ONCE into the operand layout of
  * the matrix-core GEMM (fp16 values nibble*scale per column class of vec_dot_q4_K_q8_K's AVX2 lanes, VecDotQ4.cpp:220-283;
- * 4.3 bytes per weight in HBM): mllm_hip_q4k_prepack -> `out` of mllm_hip_q4k_prepack_bytes(N, K) bytes.  The GEMM packs the
+ * 2.16 bytes per weight in HBM): mllm_hip_q4k_prepack -> `out` of mllm_hip_q4k_prepack_bytes(N, K) bytes.  The GEMM packs the
  * Q8_K activation planes the same way into `xpack` (mllm_hip_q4k_prepack_bytes(M, K) bytes of scratch) and gives the same
  * bits as mllm_hip_linear_q4k_q8k, which for M >= 16 on raw blocks does both packs into stream-ordered scratch itself. */
 size_t mllm_hip_q4k_prepack_bytes(int rows, int K);

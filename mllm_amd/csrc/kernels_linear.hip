@@ -5,11 +5,14 @@
 //     load covers 8 consecutive blocks = 1152 contiguous bytes), the Q8_K activation slice of each lane is loop
 //     invariant and lives in registers, the 4x8-bit dot products run on v_dot4_i32_i8, integers are reduced exactly
 //     with wavefront shuffles and only then scaled (int-exact per super-block like vec_dot_q4_K_q8_K).
-//   prefill / vision (M >= 16): int8 MFMA GEMM (v_mfma_i32_32x32x32_i8): one MFMA per 32-wide sub-block so the 6-bit
-//     sub-block scales can be applied to exact int32 partial sums; the `mins` term is a second MFMA whose B operand
-//     is the broadcast 6-bit min (sum_e q8[e]*min_{sb(e)} == sum_j bsums[j]*min_{j/2}, VecDotQ4.cpp:318).
-//   fp32 weights (patch-embed conv, fp32 models): f32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 fma chain).
+//   prefill / vision (M >= 16): class-decomposed exact GEMM on v_mfma_f32_32x32x16_f16 (gemm_q4k_kernel below): per column class of
+//     vec_dot_q4_K_q8_K's AVX2 lanes the integer sum of (nibble * 6-bit scale) x q8 -- all operands and partial sums exact in fp16 / fp32 --
+//     comes out of two MFMAs on pre-packed fp16 operands; the mins term sum_j mn_j * bsum_j is one more MFMA per pair of sub-blocks;
+//     the reference's per-super-block fp32 chain step acc = fma(d_x d_w, sum, acc) then runs on the VALU, so the result is bit-identical.
+//   fp32 weights (patch-embed conv, fp32 models): gemm_f32_kernel, vec_dot_fp32's 32 chains + ordered leftovers on the VALU.
 #include <type_traits>
+#include <atomic>
+
 #include "common.h"
 #include "q4k_dot.h"
 #include "q40_dot.h"
@@ -626,11 +629,15 @@ static int launch_gemm_packed(const void *Wpacked, const float *bias, const void
     const int nb = K / 256;
     dim3 grid((N + 63) / 64, (M + 63) / 64);
     constexpr int lds = GQ_LDS + 1024;   // ring + scratch tail
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: one bit per device id, set once (a second mllm_hip_init(device) in the same process must not inherit device 0's flag)
+    static std::atomic<uint64_t> attr_done{0};
+    int dev = 0;
+    MH_CHECK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     // 64 x 64 workgroup tiles; 32 x 64 only for very small problems (measured: at M = 282 the 64 x 64 form is 1.6x faster despite 120-160 workgroups)
     if ((int)(grid.x * grid.y) >= 48) {
