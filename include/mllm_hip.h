@@ -186,6 +186,15 @@ int mllm_hip_patch_gemm_f32(const float *patches, const float *W, const float *b
 /* gather of conv2d receptive fields from the (h, c, w)-ordered image into `[oh*ow][c][kh][kw]` rows (Convolution.cpp:8-33,45-60) */
 int mllm_hip_im2patch_hcw(const float *img, float *patches, int H, int C, int W, int p, void *stream);
 
+/* ---- Qwen2-VL image preprocessing on the device.  Qwen2VLImageProcessor::preprocess_images (models/qwen2_vl/processing_qwen2_vl.hpp:190-235) after the
+ *      decode: x/255 (processor/PreProcess.cpp:37-43), smart_resize (:84-109), the cubic B-spline resample of stb_image_resize2 with edge clamp (PreProcess.cpp:84-154), per-channel
+ *      normalise (:233-262), the frame doubled, convertPatches (:119-177).  rgb_host: decoded image `[height][width][3]` uint8; patches_dev: device fp32
+ *      `[grid_h*grid_w][1176]` (size it with _shape); grid_thw: 3 host ints out.  min/max_pixels: the processor's 4*28*28 / 16384*28*28 unless set_pixels changed them.
+ *      The result can be handed to mllm_hip_model_prefill / _vision as the image (they accept device memory).  Held to the reference within 2e-5 absolute (the library's SIMD
+ *      summation order is not reproduced), see kernels_image.hip. -------------------------------------------------------------------------------------------------------- */
+int mllm_hip_qwen2vl_preprocess_shape(int height, int width, int min_pixels, int max_pixels, int32_t *grid_thw);
+int mllm_hip_qwen2vl_preprocess(const uint8_t *rgb_host, int height, int width, int min_pixels, int max_pixels, float *patches_dev, int32_t *grid_thw, void *stream);
+
 /* ================================================================================================================
  * Engine: the reference's model graphs for the hot-path configs, resident on the device, on top of the
  * launchers above.  One engine type serves the five BASELINE configs; `arch` picks the graph and the tensor names:
@@ -233,7 +242,7 @@ void mllm_hip_model_destroy(mllm_hip_model *m);
 int mllm_hip_model_load_stats(const mllm_hip_model *m, float *total_ms, int64_t *file_bytes, float *h2d_ms, float *repack_ms);
 /* Module::clear_kvcache: KVCache sequence counters and RoPE position counters back to 0 (CPUKVCache.hpp:26-29, CPURoPE.hpp:63-65) */
 int mllm_hip_model_clear_kvcache(mllm_hip_model *m);
-/* One prefill forward.  ids: n_ids host ints.  image (optional, host fp32): QWEN2VL pixel_values `[n_patch][3*2*14*14]` with
+/* One prefill forward.  ids: n_ids host ints.  image (optional, fp32, host or device memory): QWEN2VL pixel_values `[n_patch][3*2*14*14]` with
  * image_meta = grid_thw (3 ints); LLAVA one image `[H][C][W]` (CLIP img2Tensor layout, models/clip/processing_clip.hpp:28-44),
  * image_meta NULL.  visual_dev (optional, device fp32): the tower's output rows already computed (e.g. all-gathered from the ranks
  * of the image shard) -- then `image` is not run.  QWEN2VL puts row i at the i-th image_token_id position (where + index_put,

@@ -861,7 +861,7 @@ extern "C" int mllm_hip_model_prefill(mllm_hip_model *m, const int32_t *ids, int
         }
         if (!visual_dev) {
             EH(ensure_vision_buffers(m, image_meta));
-            HH(hipMemcpy(m->vpix[0], image, ie * 4, hipMemcpyHostToDevice));
+            HH(hipMemcpy(m->vpix[0], image, ie * 4, hipMemcpyDefault));      // host or device pixels (mllm_hip_qwen2vl_preprocess leaves them on the device)
             vis = m->vemb;
         }
         if (m->vkind == V_QWEN2VL) HH(hipMemcpy(m->idx_i, where.data(), where.size() * 4, hipMemcpyHostToDevice));

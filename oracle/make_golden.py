@@ -315,6 +315,42 @@ def llava_full(path=None):
     print("llava_7b.npz", tok.tolist(), timing)
 
 
+def write_bmp(path, rgb):
+    """24-bit uncompressed BMP (bottom-up rows, BGR, rows padded to 4 bytes) of an [H][W][3] uint8 array."""
+    import struct
+    h, w, _ = rgb.shape
+    row = (3 * w + 3) & ~3
+    body = bytearray()
+    for y in range(h - 1, -1, -1):
+        line = rgb[y, :, ::-1].tobytes()
+        body += line + b"\0" * (row - len(line))
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", 54 + len(body), 0, 0, 54))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(body), 2835, 2835, 0, 0))
+        f.write(bytes(body))
+
+
+def preprocess_images():
+    """SURVEY N3: the reference's Qwen2VLImageProcessor::preprocess_images (oracle/ref_drivers/ref_preprocess.cpp) on three synthetic BMPs: a 60 x 90 image
+    (slight downsample to 56 x 84), a 51 x 37 one (upsample to 84 x 56 through the min_pixels branch of smart_resize) and a 112 x 112 one (same size: the cubic
+    B-spline still smooths).  Stored: the RGB bytes, the flattened patches and the grid of each."""
+    r = np.random.default_rng(31)
+    out = {}
+    for i, (h, w) in enumerate(((60, 90), (51, 37), (112, 112))):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) * 3 % 256)], axis=-1).astype(np.int32)
+        rgb = np.clip(base + r.integers(-40, 41, size=base.shape), 0, 255).astype(np.uint8)
+        td = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP"))
+        write_bmp(os.path.join(td, "img.bmp"), rgb)
+        subprocess.run([os.path.join(REF, "ref_preprocess"), "--img", os.path.join(td, "img.bmp"), "--out", td], check=True, capture_output=True, text=True)
+        grid = np.fromfile(os.path.join(td, "grid.i32"), dtype=np.int32)
+        out[f"rgb{i}"] = rgb
+        out[f"grid{i}"] = grid
+        out[f"patches{i}"] = np.fromfile(os.path.join(td, "patches.f32"), dtype=np.float32).reshape(int(grid.prod()), 1176)
+    np.savez_compressed(os.path.join(GOLD, "preprocess.npz"), **out)
+    print("preprocess.npz", [out[f"grid{i}"].tolist() for i in range(3)])
+
+
 def sampling():
     """candidate ids and pre-draw probabilities of the reference's top-k / top-p methods (oracle/ref_drivers/ref_sampling.cpp: the library's own
     Generate.cpp code with only the random draw interposed) on fixed rows: 4 rows of 2048 logits ~ N(0, 2^2), and their softmax rows sharpened by 3 / 1 / 0.5 / 6
@@ -375,6 +411,9 @@ def configs_full():
 if __name__ == "__main__":
     if "--llava" in sys.argv:
         llava_tiny()
+        sys.exit(0)
+    if "--preprocess" in sys.argv:
+        preprocess_images()
         sys.exit(0)
     if "--sampling" in sys.argv:
         sampling()

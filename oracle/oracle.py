@@ -262,3 +262,129 @@ def topp_sampling_probs(probs, p, temperature):
         return idx, x[idx], np.ones(1, dtype=np.float32)
     _, _, soft = topk_sampling_probs(x[idx], n, temperature)      # the kept scores are already in descending order
     return idx, x[idx], soft
+
+
+# ---- Qwen2-VL image preprocessing (mllm/models/qwen2_vl/processing_qwen2_vl.hpp:84-235, mllm/processor/PreProcess.cpp:37-43,84-154,233-262) -------------
+# TEST INFRASTRUCTURE.  The resize is third-party code the reference vendors: stb_image_resize2.h (third_party/stb, v2.x) with STBIR_FILTER_CUBICBSPLINE, STBIR_EDGE_CLAMP,
+# float RGB.  Its published algorithm is restated here: per axis a gather with coefficients B(distance) (cubic B-spline, support 2, stretched by 1/scale when shrinking),
+# normalised to sum 1, out-of-range taps folded into the edge pixel (stb_image_resize2.h:2821-2832 kernel, :3176-3283 upsample taps, :3287-3380 downsample taps, :3382-3500
+# normalisation + clamp).  The library's SIMD gather loops and its horizontal/vertical ordering heuristic fix the ORDER of the float additions; that order is not restated, so
+# this function is pinned to the reference's output (tests/golden/preprocess.npz) within a stated tolerance, not bit for bit.
+QWEN2VL_MEAN = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+QWEN2VL_STD = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+
+
+def smart_resize(height, width, factor=28, min_pixels=4 * 28 * 28, max_pixels=16384 * 28 * 28):
+    """processing_qwen2_vl.hpp:84-109 (float beta, integer rounding by factor)."""
+    import math
+    if max(height, width) / np.float32(min(height, width)) > 200:
+        raise ValueError("absolute aspect ratio must be smaller than 200")
+    rnd = lambda v: ((v + factor // 2) // factor) * factor
+    h_bar, w_bar = max(factor, rnd(height)), max(factor, rnd(width))
+    if h_bar * w_bar > max_pixels:
+        beta = np.float32(math.sqrt(np.float32(height * width) / np.float32(max_pixels)))
+        h_bar = int(math.floor(np.float32(height) / beta / factor)) * factor
+        w_bar = int(math.floor(np.float32(width) / beta / factor)) * factor
+    elif h_bar * w_bar < min_pixels:
+        beta = np.float32(math.sqrt(np.float32(min_pixels) / np.float32(height * width)))
+        h_bar = int(math.ceil(np.float32(height) * beta / factor)) * factor
+        w_bar = int(math.ceil(np.float32(width) * beta / factor)) * factor
+    return h_bar, w_bar
+
+
+def _bspline(x):
+    f = np.float32
+    x = f(abs(x))
+    if x < f(1.0):
+        return f((f(4.0) + x * x * (f(3.0) * x - f(6.0))) / f(6.0))
+    if x < f(2.0):
+        return f((f(8.0) + x * (f(-12.0) + x * (f(6.0) - x))) / f(6.0))
+    return f(0.0)
+
+
+def stb_axis_taps(in_size, out_size):
+    """Per output index: (first input pixel, float32 coefficients), normalised, clamped to [0, in_size)."""
+    import math
+    f = np.float32
+    small = f(1.0 / (1 << 20))
+    scale = f(out_size / in_size)
+    inv_scale = f(1.0 / (out_size / in_size))
+    taps = [dict() for _ in range(out_size)]
+    if scale >= f(1.0) - small:
+        radius = f(2.0) * scale
+        for n in range(out_size):
+            oc = f(n) + f(0.5)
+            centre = f(oc * inv_scale)
+            first = int(math.floor(f((oc - radius) * inv_scale) + f(0.5)))
+            last = int(math.floor(f((oc + radius) * inv_scale) - f(0.5)))
+            for p in range(first, last + 1):
+                c = _bspline(centre - (f(p) + f(0.5)))
+                if abs(c) >= small:
+                    taps[n][p] = c
+    else:
+        radius = f(2.0) * inv_scale
+        margin = int(math.ceil(2.0 * 2.0 / float(scale))) // 2 + 1
+        for p in range(-margin, in_size + margin):
+            ic = f(p) + f(0.5)
+            out_centre = f(ic * scale)
+            first = max(0, int(math.floor(f((ic - radius) * scale) + f(0.5))))
+            last = min(out_size - 1, int(math.floor(f((ic + radius) * scale) - f(0.5))))
+            for o in range(first, last + 1):
+                c = f(_bspline((f(o) + f(0.5)) - out_centre) * scale)
+                if abs(c) >= small:
+                    taps[o][p] = c
+    out = []
+    for t in taps:
+        ps = sorted(t)
+        cs = np.array([t[p] for p in ps], dtype=np.float32)
+        total = f(0.0)
+        for c in cs:
+            total = f(total + c)
+        if total < f(1.0) - small or total > f(1.0) + small:
+            cs = (cs * f(f(1.0) / total)).astype(np.float32)
+        folded = {}
+        for p, c in zip(ps, cs):                      # STBIR_EDGE_CLAMP: taps outside the image act on the edge pixel
+            q = min(max(p, 0), in_size - 1)
+            folded[q] = f(folded.get(q, f(0.0)) + c)
+        qs = sorted(folded)
+        out.append((qs[0], np.array([folded.get(q, f(0.0)) for q in range(qs[0], qs[-1] + 1)], dtype=np.float32)))
+    return out
+
+
+def stb_resize_bspline(img, out_h, out_w):
+    """img float32 [H][W][C] -> [out_h][out_w][C]: horizontal gather then vertical gather, float32 sums in tap order."""
+    H, W, C = img.shape
+    tw, th = stb_axis_taps(W, out_w), stb_axis_taps(H, out_h)
+    tmp = np.zeros((H, out_w, C), dtype=np.float32)
+    for x, (p0, cs) in enumerate(tw):
+        acc = np.zeros((H, C), dtype=np.float32)
+        for k, c in enumerate(cs):
+            acc = (acc + img[:, p0 + k, :] * c).astype(np.float32)
+        tmp[:, x, :] = acc
+    out = np.zeros((out_h, out_w, C), dtype=np.float32)
+    for y, (p0, cs) in enumerate(th):
+        acc = np.zeros((out_w, C), dtype=np.float32)
+        for k, c in enumerate(cs):
+            acc = (acc + tmp[p0 + k] * c).astype(np.float32)
+        out[y] = acc
+    return out
+
+
+def qwen2vl_patchify(chw, patch=14, merge=2, tps=2):
+    """convertPatches (processing_qwen2_vl.hpp:119-177) for one image whose single frame is doubled: chw float32 [3][H][W] -> [gh*gw][3*tps*patch*patch], grid."""
+    C, H, W = chw.shape
+    gh, gw = H // patch, W // patch
+    x = chw.reshape(C, gh // merge, merge, patch, gw // merge, merge, patch)          # c, d1, d3, d7, d2, d4, d8
+    x = x.transpose(1, 4, 2, 5, 0, 3, 6)                                               # d1, d2, d3, d4, c, d7, d8
+    x = np.repeat(x[:, :, :, :, :, None], tps, axis=5)                                 # ..., c, t, d7, d8
+    return np.ascontiguousarray(x.reshape(gh * gw, C * tps * patch * patch)), np.array([1, gh, gw], dtype=np.int32)
+
+
+def qwen2vl_preprocess(rgb_u8):
+    """preprocess_images for an already decoded RGB image uint8 [H][W][3] -> (patches float32 [N][1176], grid_thw)."""
+    H, W, _ = rgb_u8.shape
+    x = (rgb_u8.astype(np.float32) / np.float32(255.0)).astype(np.float32)             # RescaleImage
+    nh, nw = smart_resize(H, W)
+    x = stb_resize_bspline(x, nh, nw)                                                  # fetch_image: always resampled, even at equal size
+    x = ((x - QWEN2VL_MEAN) / QWEN2VL_STD).astype(np.float32)                          # NormalizeImages(means, stds)
+    return qwen2vl_patchify(np.ascontiguousarray(x.transpose(2, 0, 1)))
