@@ -157,6 +157,10 @@ int mllm_hip_sample_index_host(const float *probs, int k, float u01);
  *      x `[S][H][D]` with row stride ldx (elements, per s); out fp32 or fp16 with row stride ldo: writing K straight
  *      into the fp16 cache slab is A12's zero-copy append (CPUKVCache.cpp:253-275). sin/cos `[S][ld_tab]`, cols < D/2. - */
 int mllm_hip_rope_table_hf(float base, int dim, int n_pos, float *sin_host, float *cos_host);
+/* the HF table with llama3 frequency scaling (rope_scaling {rope_type: llama3}, Layer.hpp:493-531 -> _compute_llama3_theta, CPURoPE.cpp:33-71), for the
+ * Llama-3.x family; the rotate itself is the same mllm_hip_rope_apply.  Tables `[n_pos][dim]`, both halves filled. */
+int mllm_hip_rope_table_hf_llama3(float base, int dim, int n_pos, float factor, float low_freq_factor, float high_freq_factor, float original_max_pos,
+                                  float *sin_host, float *cos_host);
 int mllm_hip_mrope_table(float base, int dim, const float *pos3xS_host, int S, const int *section, int n_section,
                          float *sin_host, float *cos_host);
 int mllm_hip_vision_rope_table(int t, int h, int w, int merge, int rot_dim, float *sin_host, float *cos_host);

@@ -778,6 +778,29 @@ extern "C" int mllm_hip_rope_table_hf(float base, int dim, int n_pos, float *sin
     }
     return MLLM_HIP_OK;
 }
+extern "C" int mllm_hip_rope_table_hf_llama3(float base, int dim, int n_pos, float factor, float low_freq_factor, float high_freq_factor, float original_max_pos,
+                                             float *sin_host, float *cos_host) {
+    // CPURoPE.cpp:33-71 (_compute_llama3_theta: Llama-3.x frequency scaling; the blend contracts to one fma in the reference build), then the HF table of :100-128
+    if (dim <= 0 || dim % 2 || n_pos <= 0 || !sin_host || !cos_host || factor == 0.0f || low_freq_factor == 0.0f || high_freq_factor == low_freq_factor) return MLLM_HIP_ERR_ARG;
+    const int half = dim / 2;
+    const float low_freq_wavelen = original_max_pos / low_freq_factor, high_freq_wavelen = original_max_pos / high_freq_factor;
+    for (int i = 0; i < half; ++i) {
+        float theta = (float)(1.0 / pow((double)base, 2.0 * i / dim));
+        const float wavelen = (float)(2 * M_PI / theta);
+        if (wavelen > low_freq_wavelen) {
+            theta /= factor;
+        } else if (wavelen >= high_freq_wavelen && wavelen <= low_freq_wavelen) {
+            const float smooth = (original_max_pos / wavelen - low_freq_factor) / (high_freq_factor - low_freq_factor);
+            theta = fmaf(1 - smooth, theta / factor, smooth * theta);
+        }
+        for (int s = 0; s < n_pos; ++s) {
+            const float v = (float)s * theta;
+            sin_host[(size_t)s * dim + i] = sin_host[(size_t)s * dim + i + half] = sinf(v);
+            cos_host[(size_t)s * dim + i] = cos_host[(size_t)s * dim + i + half] = cosf(v);
+        }
+    }
+    return MLLM_HIP_OK;
+}
 extern "C" int mllm_hip_mrope_table(float base, int dim, const float *pos, int S, const int *section, int n_section, float *sin_host, float *cos_host) {
     // CPUMultimodalRoPE.cpp:26-36 theta, :84-118 per-axis sin/cos, :37-82 stitch by mrope_section; tables [S][dim/2]
     const int half = dim / 2;

@@ -118,6 +118,14 @@ def rope_table_hf(base, dim, n_pos):
     return s, c
 
 
+def rope_table_hf_llama3(base, dim, n_pos, factor, low_freq_factor, high_freq_factor, original_max_pos):
+    s = np.empty((n_pos, dim), dtype=np.float32)
+    c = np.empty((n_pos, dim), dtype=np.float32)
+    check(load().mllm_hip_rope_table_hf_llama3(C.c_float(base), C.c_int(dim), C.c_int(n_pos), C.c_float(factor), C.c_float(low_freq_factor), C.c_float(high_freq_factor),
+                                               C.c_float(original_max_pos), vp(s), vp(c)), "rope_table_hf_llama3")
+    return s, c
+
+
 def mrope_table(base, dim, pos, section=(16, 24, 24)):
     pos = np.ascontiguousarray(pos, dtype=np.float32)
     S = pos.shape[1]

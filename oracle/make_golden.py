@@ -315,6 +315,19 @@ def llava_full(path=None):
     print("llava_7b.npz", tok.tolist(), timing)
 
 
+def rope3_golden():
+    """SURVEY N4 (one representative of the other families' ops): RoPE with llama3 frequency scaling (Layer.hpp:493-531 -> _compute_llama3_theta, CPURoPE.cpp:33-71) run by
+    the reference on 40 positions x 2 heads x 64 dims; theta 500000, factor 8, low / high frequency factors 1 / 4, original context 8192: the 32 frequencies fall into all three
+    regimes (kept, interpolated, divided)."""
+    r = np.random.default_rng(37)
+    q = r.standard_normal((40, 128), dtype=np.float32)
+    pn = quantize_file([("dummy.weight", np.zeros(32, dtype=np.float32))], target="F32")
+    params = (4, 500000.0, 128, 2, 64, 8.0, 1.0, 4.0, 8192)      # HFHUBROPE = 4
+    (y,), _ = run_ops("rope3", pn, [[(q, (1, 1, 40, 128))]], p=params)
+    np.savez_compressed(os.path.join(GOLD, "rope3.npz"), x=q, y=y.reshape(40, 128), params=np.array(params, dtype=np.float64))
+    print("rope3.npz", y[:4])
+
+
 def write_bmp(path, rgb):
     """24-bit uncompressed BMP (bottom-up rows, BGR, rows padded to 4 bytes) of an [H][W][3] uint8 array."""
     import struct
@@ -411,6 +424,9 @@ def configs_full():
 if __name__ == "__main__":
     if "--llava" in sys.argv:
         llava_tiny()
+        sys.exit(0)
+    if "--rope3" in sys.argv:
+        rope3_golden()
         sys.exit(0)
     if "--preprocess" in sys.argv:
         preprocess_images()

@@ -61,6 +61,12 @@ public:
         else if (k == "vrope") l0 = VisionRoPE((int)p(0), (int)p(1), "rot");
         else if (k == "mrope") l0 = MultimodalRoPE(p(0), (int)p(1), {16, 24, 24}, "rope");
         else if (k == "rope") l0 = RoPE((int)p(0), p(1), (int)p(2), "rope");
+        else if (k == "rope3") {   // llama3 frequency scaling (Layer.hpp:493-531 -> CPURoPE.cpp:33-71): p = pose_type, theta, max_pos, heads, D, factor, low, high, original max_pos
+            map<string, std::any> sc = {{"rope_type", std::string("llama3")}, {"factor", p(5)}, {"low_freq_factor", p(6)}, {"high_freq_factor", p(7)},
+                                        {"original_max_position_embeddings", (int)p(8)}};
+            RoPEConfig cfg = {{"rope_theta", p(1)}, {"max_position_embeddings", (int)p(2)}, {"rope_scaling", sc}};
+            l0 = RoPE((int)p(0), cfg, "rope");
+        }
         else if (k == "fa2") {}
         else { fprintf(stderr, "unknown case %s\n", k.c_str()); exit(2); }
     }
@@ -81,7 +87,7 @@ public:
             q = r(q, in[1]);
             return {q.view(-1, 1, -1, (int)(p(2) * p(3)))};
         }
-        if (kind == "rope") {
+        if (kind == "rope" || kind == "rope3") {
             auto q = in[0].view(-1, (int)p(3), -1, (int)p(4));
             RoPE &r = (RoPE &)l0;
             q = r(q);

@@ -382,6 +382,29 @@ void orc_rope_table_hf(float base, int dim, int n_pos, float *sin_t, float *cos_
         }
     }
 }
+/* The same table with llama3 frequency scaling, _compute_llama3_theta (CPURoPE.cpp:33-71): theta_i as above, wavelen = 2 pi / theta_i (double division, stored as float);
+ * wavelen > original/low: theta /= factor; original/high <= wavelen <= original/low: theta = (1 - s) * (theta / factor) + s * theta with s = (original / wavelen - low) /
+ * (high - low), all in float -- the reference binary (g++ -O2 -mfma, default contraction) evaluates the blend as fma(1 - s, theta / factor, s * theta); shorter wavelengths keep
+ * theta.  Pinned by tests/golden/rope3.npz. */
+void orc_rope_table_hf_llama3(float base, int dim, int n_pos, float factor, float low_freq_factor, float high_freq_factor, float original_max_pos, float *sin_t, float *cos_t) {
+    int half = dim / 2;
+    float low_freq_wavelen = original_max_pos / low_freq_factor, high_freq_wavelen = original_max_pos / high_freq_factor;
+    for (int i = 0; i < half; ++i) {
+        float theta = (float)(1.0 / pow((double)base, 2.0 * i / dim));
+        float wavelen = (float)(2 * M_PI / theta);
+        if (wavelen > low_freq_wavelen) {
+            theta /= factor;
+        } else if (wavelen >= high_freq_wavelen && wavelen <= low_freq_wavelen) {
+            float smooth = (original_max_pos / wavelen - low_freq_factor) / (high_freq_factor - low_freq_factor);
+            theta = fmaf(1 - smooth, theta / factor, smooth * theta);
+        }
+        for (int s = 0; s < n_pos; ++s) {
+            float v = (float)s * theta;
+            sin_t[(size_t)s * dim + i] = sin_t[(size_t)s * dim + i + half] = sinf(v);
+            cos_t[(size_t)s * dim + i] = cos_t[(size_t)s * dim + i + half] = cosf(v);
+        }
+    }
+}
 /* CPUMultimodalRoPE.cpp:26-36 (theta), :84-118 (per-axis tables), :37-82 (mrope_section stitch). pos is [3][S] (t,h,w rows);
  * sin/cos out are [S][dim/2]: column c takes axis j where c falls in section j. */
 void orc_mrope_table(float base, int dim, const float *pos, int S, const int *section, int n_section, float *sin_t, float *cos_t) {
