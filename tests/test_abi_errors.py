@@ -86,3 +86,52 @@ def test_engine_create_reports_io_and_argument_errors(L, tmp_path):
         bad.write_bytes(b"\x00" * 64)                               # wrong magic number
         assert L.mllm_hip_qwen2vl_create(C.byref(cfg), str(bad).encode(), C.byref(out)) == ERR_IO
     assert not out.value
+
+
+def test_generic_engine_create_validates_config_and_file(L, tmp_path):
+    """mllm_hip_model_create: nonsense fields -> ERR_ARG, unsupported geometry -> ERR_SHAPE, all before any file or device work; a truncated or corrupt .mllm
+    index -> ERR_IO (nothing in the header is trusted: every length is checked against the mapped size)."""
+    import struct
+    from mllm_amd import synth
+    out = C.c_void_p(0)
+    mk = lambda **kw: _cfg(lib.model_config(synth.qwen2vl_tiny()), **kw)
+
+    def _cfg(c, **kw):
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+    path = b"/nonexistent/model.mllm"
+    assert L.mllm_hip_model_create(NULL, path, C.byref(out)) == ERR_ARG
+    assert L.mllm_hip_model_create(C.byref(mk(arch=9)), path, C.byref(out)) == ERR_ARG
+    assert L.mllm_hip_model_create(C.byref(mk(heads=0)), path, C.byref(out)) == ERR_ARG              # would divide by zero
+    assert L.mllm_hip_model_create(C.byref(mk(kv_heads=0)), path, C.byref(out)) == ERR_ARG
+    assert L.mllm_hip_model_create(C.byref(mk(v_heads=0)), path, C.byref(out)) == ERR_ARG
+    assert L.mllm_hip_model_create(C.byref(mk(hidden=300)), path, C.byref(out)) == ERR_SHAPE         # not a whole number of super-blocks
+    assert L.mllm_hip_model_create(C.byref(mk(hidden=512, heads=16)), path, C.byref(out)) == ERR_SHAPE   # head_dim 32: the decode attention is built for 64 and 128
+    assert L.mllm_hip_model_create(C.byref(mk(kv_heads=3, heads=4, hidden=512)), path, C.byref(out)) == ERR_SHAPE
+    assert L.mllm_hip_model_create(C.byref(mk()), path, C.byref(out)) == ERR_IO                      # valid config, missing file
+    # a header whose index length points past the end of the file; an entry whose name length does; an entry whose data does
+    good_cfg = mk()
+    for i, blob in enumerate((struct.pack("<iQ", 20012, 1 << 40),
+                              struct.pack("<iQ", 20012, 40) + struct.pack("<i", 1 << 20) + b"x" * 36,
+                              struct.pack("<iQ", 20012, 4 + 1 + 20) + struct.pack("<i", 1) + b"a" + struct.pack("<QQi", 1 << 30, 12, 0),
+                              b"\x2c\x4e\x00")):
+        f = tmp_path / f"trunc{i}.mllm"
+        f.write_bytes(blob)
+        assert L.mllm_hip_model_create(C.byref(good_cfg), str(f).encode(), C.byref(out)) == ERR_IO, i
+    assert not out.value
+
+
+def test_sampling_and_preprocess_entry_points_validate(L):
+    assert L.mllm_hip_sort_desc(P, C.c_int(0), P, P, P, C.c_size_t(1 << 20), NULL) == ERR_ARG
+    assert L.mllm_hip_sort_desc(P, C.c_int(16), P, P, NULL, C.c_size_t(0), NULL) == ERR_ARG
+    assert L.mllm_hip_transpose_f32(P, P, C.c_int(4), C.c_int(4), NULL) == ERR_ARG                   # in place is not supported
+    assert L.mllm_hip_transpose_f32(P, C.c_void_p(0x2000), C.c_int(0), C.c_int(4), NULL) == ERR_SHAPE
+    import numpy as np
+    grid = np.zeros(3, dtype=np.int32)
+    assert L.mllm_hip_qwen2vl_preprocess_shape(C.c_int(10), C.c_int(4000), C.c_int(3136), C.c_int(12845056), lib.vp(grid)) == ERR_SHAPE   # aspect ratio above 200
+    assert L.mllm_hip_qwen2vl_preprocess_shape(C.c_int(448), C.c_int(448), C.c_int(3136), C.c_int(12845056), lib.vp(grid)) == OK and grid.tolist() == [1, 32, 32]
+    assert L.mllm_hip_qwen2vl_preprocess(NULL, C.c_int(8), C.c_int(8), C.c_int(3136), C.c_int(12845056), P, lib.vp(grid), NULL) == ERR_ARG
+    assert L.mllm_hip_all_gather_rows(NULL, P, P, C.c_int64(4), C.c_int(8), NULL) == ERR_ARG
+    assert L.mllm_hip_comm_create(NULL, C.c_int(1), C.c_int(0), C.byref(C.c_void_p())) == ERR_ARG
+    assert L.mllm_hip_rope_table_hf_llama3(C.c_float(1e4), C.c_int(63), C.c_int(8), C.c_float(8), C.c_float(1), C.c_float(4), C.c_float(8192), P, P) == ERR_ARG
