@@ -388,6 +388,36 @@ private:
     int b_, h_, s_, d_;
 };
 
+// F_CLIP (op/CPUClipFunc.hpp) on the SEQUENCE axis of a batch-1 BSHD tensor: clip({}, {}, {-1}, {}) = the last position (every causal LM ends with it,
+// modeling_qwen2_vl.hpp:395-397), clip({}, {}, {a, b}, {}) = positions [a, b) (LLaVA drops the class row, modeling_llava.hpp:90).  Rows of a position are contiguous,
+// so the result is a pointer offset into the input: a non-owning view.
+class HIPClipSeqOp final : public Op {
+public:
+    HIPClipSeqOp(Backend *bn, const string &name, int a, int b, bool single) : Op(bn, name), a_(a), b_(b), single_(single) {}
+    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+        const int S = inputs[0]->sequence();
+        lo_ = a_ < 0 ? S + a_ : a_;
+        hi_ = single_ ? lo_ + 1 : (b_ < 0 ? S + b_ : b_);
+        if (inputs[0]->batch() != 1 || lo_ < 0 || hi_ > S || hi_ <= lo_) throw std::runtime_error("HIPClipSeqOp: range outside the sequence");
+        outputs[0]->reshape(1, inputs[0]->head(), hi_ - lo_, inputs[0]->dimension());
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+        outputs[0]->setDtype(inputs[0]->dtype());
+        outputs[0]->setCtype(inputs[0]->ctype());
+        const size_t row = (size_t)inputs[0]->head() * inputs[0]->dimension() * (inputs[0]->dtype() == MLLM_TYPE_F16 ? 2 : 4);
+        DeviceMemory &m = outputs[0]->device_memory();
+        m = inputs[0]->device_memory();
+        m.handle = (char *)m.handle + (size_t)lo_ * row;
+        m.size_in_bytes = (size_t)(hi_ - lo_) * row;
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    int a_, b_, lo_ = 0, hi_ = 0;
+    bool single_;
+};
+
 }  // namespace
 
 // ---- registry: OpType -> creator (Backend::registerOps, mllm/Backend.hpp:104-105; OpDefined.hpp:10-134).  Anything not listed, or a listed Op with parameters the
@@ -438,6 +468,14 @@ void HIPBackend::registerOps() {
     creators_[CONVOLUTION2D] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
         if (geti(p, "kernal_h") != geti(p, "stride_h") || geti(p, "kernal_w") != geti(p, "stride_w") || geti(p, "kernal_h") != geti(p, "kernal_w") || geti(p, "padding") != (int)VALID) return nullptr;
         return new HIPPatchConvOp(b, n, false, geti(p, "in_channel"), geti(p, "out_channel"), 1, geti(p, "kernal_h"), geti(p, "kernal_w"), geti(p, "bias") != 0);
+    };
+    creators_[F_CLIP] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        // SEQUENCE-only clips; anything touching batch / head / dimension goes to the CPU
+        if (geti(p, "b_size") || geti(p, "h_size") || geti(p, "d_size")) return nullptr;
+        const int ss = geti(p, "s_size");
+        if (ss == 1) return new HIPClipSeqOp(b, n, geti(p, "s_0"), 0, true);
+        if (ss == 2) return new HIPClipSeqOp(b, n, geti(p, "s_0"), geti(p, "s_1"), false);
+        return nullptr;
     };
     creators_[F_VIEW] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return new HIPViewOp(b, n, geti(p, "b"), geti(p, "h"), geti(p, "s"), geti(p, "d")); };
 }
