@@ -69,12 +69,14 @@ int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const int8_t *xqs,
                             void *y, int y_dtype, int64_t ldy, const float *residual, int M, int N, int K, void *stream);
 int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, const float *bias, const int8_t *xqs, const uint16_t *xd,
                             float *y, int64_t ldy, int M, int N, int K, void *stream);
-/* Q4_K weights that stay resident and meet M >= 16 rows (prefill, vision tower) are packed ONCE into the operand layout of
- * the matrix-core GEMM (fp16 values nibble*scale per column class of vec_dot_q4_K_q8_K's AVX2 lanes, VecDotQ4.cpp:220-283;
- * 2.16 bytes per weight in HBM): mllm_hip_q4k_prepack -> `out` of mllm_hip_q4k_prepack_bytes(N, K) bytes.  The GEMM packs the
- * Q8_K activation planes the same way into `xpack` (mllm_hip_q4k_prepack_bytes(M, K) bytes of scratch) and gives the same
- * bits as mllm_hip_linear_q4k_q8k, which for M >= 16 on raw blocks does both packs into stream-ordered scratch itself. */
+/* Q4_K weights that stay resident and meet M >= 16 rows (prefill, vision tower) are re-ordered ONCE into the operand order of
+ * the matrix-core GEMM (per column class of vec_dot_q4_K_q8_K's AVX2 lanes, VecDotQ4.cpp:220-283): the nibbles stay nibbles
+ * (0.72 bytes per weight in HBM with the fp16 sub-block scales, the mins operands and (d, dmin)) and become the fp16 operand
+ * nibble * scale in registers inside the GEMM: mllm_hip_q4k_prepack -> `out` of mllm_hip_q4k_wpack_bytes(N, K) bytes.  The GEMM
+ * packs the Q8_K activation planes into fp16 fragments in `xpack` (mllm_hip_q4k_prepack_bytes(M, K) bytes of scratch) and gives
+ * the same bits as mllm_hip_linear_q4k_q8k, which for M >= 16 on raw blocks does both packs into stream-ordered scratch itself. */
 size_t mllm_hip_q4k_prepack_bytes(int rows, int K);
+size_t mllm_hip_q4k_wpack_bytes(int N, int K);
 int mllm_hip_q4k_prepack(const void *W, int N, int K, void *out, void *stream);
 int mllm_hip_linear_q4kp_q8k(const void *Wpacked, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums,
                              void *xpack, void *y, int y_dtype, int64_t ldy, const float *residual, int M, int N, int K,

@@ -41,7 +41,7 @@ public:
         const DataType dt = weight_.dtype();
         if (dt != MLLM_TYPE_Q4_K && dt != MLLM_TYPE_Q4_0 && dt != MLLM_TYPE_F32) throw std::runtime_error("HIPLinearOp: weight dtype not on the hot path: " + name());
         if (dt == MLLM_TYPE_Q4_K) {      // resident Linears are packed once for the M >= 16 GEMM (mllm_hip_q4k_prepack)
-            const size_t pb = mllm_hip_q4k_prepack_bytes(out_, in_);
+            const size_t pb = mllm_hip_q4k_wpack_bytes(out_, in_);
             HIPCHK(mllm_hip_alloc(&packed_, pb));
             HIPCHK(mllm_hip_q4k_prepack(weight_.device_memory().handle, out_, in_, packed_, hb(backend_)->stream()));
         } else if (dt == MLLM_TYPE_Q4_0) {  // 18-byte blocks -> nibble plane + fp16 scale plane (mllm_hip_repack_q40)

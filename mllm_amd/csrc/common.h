@@ -194,12 +194,15 @@ __device__ __forceinline__ int byte_of(const uint32_t v[2], int j) { return (v[j
 // 4x int8 dot with int32 accumulate (v_dot4_i32_i8): a, b hold four signed bytes each.
 __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 
-// ---- packed operand layout of the Q4_K GEMM (kernels_linear.hip): bytes per (32-row tile, super-block) of the three planes
+// ---- packed operand layout of the Q4_K GEMM (kernels_linear.hip): bytes per (32-row tile, super-block) of the three planes of the ACTIVATION side
 constexpr size_t Q4KP_W_PER_BLK = 32 * 512, Q4KP_M_PER_BLK = 32 * 4 * 8, Q4KP_D_PER_BLK = 32 * 8;
 __host__ __device__ static inline size_t q4kp_tile_blocks(int rows, int nb) { return (size_t)((rows + 31) / 32) * nb; }
 static inline size_t q4kp_bytes(int rows, int K) {
     const size_t tb = q4kp_tile_blocks(rows, K / 256);
     return tb * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK + Q4KP_D_PER_BLK);
 }
+// weight side: nibbles (4 KiB), fp16 sub-block scale pairs (512 B), mins operands (1 KiB), (d, dmin) (256 B) per (32-row tile, super-block) = 0.72 B per weight
+constexpr size_t Q4KW_Q_PER_BLK = 4096, Q4KW_S_PER_BLK = 512, Q4KW_M_PER_BLK = 1024, Q4KW_D_PER_BLK = 256;
+static inline size_t q4kw_bytes(int rows, int K) { return q4kp_tile_blocks(rows, K / 256) * (Q4KW_Q_PER_BLK + Q4KW_S_PER_BLK + Q4KW_M_PER_BLK + Q4KW_D_PER_BLK); }
 
 }  // namespace mllm_hip

@@ -277,7 +277,7 @@ static int load_linear_q4k(M *m, const MllmFile &f, const std::vector<std::strin
     EH(m->ld.fence(m->st));
     {
         uint8_t *wp;
-        EH(m->dalloc(&wp, mllm_hip_q4k_prepack_bytes(N, K)));
+        EH(m->dalloc(&wp, mllm_hip_q4k_wpack_bytes(N, K)));
         EH(mllm_hip_q4k_prepack(w, N, K, wp, m->st));
         lw->wp = wp;
     }

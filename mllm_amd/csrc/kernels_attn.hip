@@ -27,7 +27,8 @@ namespace mllm_hip {
 // v_mfma_f32_32x32x2_f32 accumulates C = fma(a1, b1, fma(a0, b0, C)) -- an exact fp32 fma chain in k order (checked on the
 // device: scratch/mfma/test.hip, 0 mismatches against fmaf chains) -- so the reference's chains map onto it unchanged:
 //   scores   chain l of (row, key) takes d = 8 i + l, i ascending: one accumulator tile per l, operands (d = 8(2s+h)+l) for MFMA s;
-//            wave w owns chains 2w and 2w+1; the 8 tiles meet in LDS and are folded ((l0+l4)+(l1+l5)) + ((l2+l6)+(l3+l7));
+//            wave w owns chains w and w+4 and adds them in registers (the fold's first level); the 4 sums meet in LDS and are folded
+//            ((l0+l4)+(l1+l5)) + ((l2+l6)+(l3+l7));
 //   softmax  thread (row, key tile): tile maximum, prefix maximum over the 8 tiles of the chunk (+ the carried maximum),
 //            c = expf((m - m') scale), p = expf((s - m') scale), sum = ((p0+p1)+p2)+p3; logsum = fma(logsum, c, sum) per row;
 //   P V      o[row][d] = fma(p_j, v_j[d], o[row][d]) in key order = MFMAs over key pairs; the rescale o *= c sits between key
@@ -38,8 +39,9 @@ namespace mllm_hip {
 constexpr int FA_R = 32, FA_KCH = 32;
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 
+// (head sizes up to 80 fit 168 registers and 44 KiB of LDS: three workgroups per CU, whose barrier / softmax / fetch phases run under each other's MFMAs)
 template <int D, bool F16, bool VT = false>
-__global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restrict__ Q, int64_t ldq, const void *__restrict__ K, int64_t ldk,
+__global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(const float *__restrict__ Q, int64_t ldq, const void *__restrict__ K, int64_t ldk,
                                                           const void *__restrict__ V, int64_t ldv, float *__restrict__ O, int64_t ldo, int Sq, int Sk,
                                                           int sk_eff, int Hq, int Hkv, int causal) {
     static_assert(D % 16 == 0 && D <= 128, "head dim");
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
     constexpr int KE = FA_KCH * D / 256;    // staged elements per thread and operand
     __shared__ float Ks[FA_KCH * KP];
     __shared__ float Vs[VT ? D * 33 : FA_KCH * D];
-    __shared__ float Part[8 * 32 * 33];
+    __shared__ float Part[4 * 32 * 33];
     __shared__ float P[32 * 33];
     __shared__ float Cc[32 * 8], Sm[32 * 8];
     __shared__ float m_in[32], l_s[32];
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
 #pragma unroll
         for (int l2 = 0; l2 < 2; ++l2)
 #pragma unroll
-            for (int sI = 0; sI < NS; ++sI) qreg[l2][sI] = qrow[8 * (2 * sI + h) + 2 * wid + l2];
+            for (int sI = 0; sI < NS; ++sI) qreg[l2][sI] = qrow[8 * (2 * sI + h) + wid + 4 * l2];
     }
     if (tid < 32) { m_in[tid] = FA_NEG; l_s[tid] = 0.0f; }
     expf_tab_store(etab, expf_tab_fetch());
@@ -159,17 +161,20 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
         if (tid < 8) moved_any[tid] = 0;
         __syncthreads();
         if (chunk0 + FA_KCH < klim) fetch(chunk0 + FA_KCH);
-        // ---- scores: two chains per wave --------------------------------------------------------------------------------------
+        // ---- scores: wave w owns chains w and w + 4 -- the pair the reference's fold adds first -- and hands their sum to the fold ------------------
+        {
+            v16f_t acc[2];
 #pragma unroll
-        for (int l2 = 0; l2 < 2; ++l2) {
-            const int l = 2 * wid + l2;
-            v16f_t acc;
+            for (int l2 = 0; l2 < 2; ++l2)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+                for (int i = 0; i < 16; ++i) acc[l2][i] = 0.0f;
 #pragma unroll
-            for (int sI = 0; sI < NS; ++sI) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[l2][sI], Ks[col * KP + 8 * (2 * sI + h) + l], acc, 0, 0, 0);
+            for (int sI = 0; sI < NS; ++sI)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) Part[(l * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 33 + col] = acc[i];
+                for (int l2 = 0; l2 < 2; ++l2)
+                    acc[l2] = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[l2][sI], Ks[col * KP + 8 * (2 * sI + h) + wid + 4 * l2], acc[l2], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Part[(wid * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 33 + col] = acc[0][i] + acc[1][i];
         }
         __syncthreads();
         // ---- fold the chains, mask, softmax of (row, key tile) ----------------------------------------------------------------------
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void fa2_prefill_kernel(const float *__restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float *pp = Part + row * 33 + 4 * tile + e;
-                float v = ((pp[0 * 1056] + pp[4 * 1056]) + (pp[1 * 1056] + pp[5 * 1056])) + ((pp[2 * 1056] + pp[6 * 1056]) + (pp[3 * 1056] + pp[7 * 1056]));
+                float v = (pp[0 * 1056] + pp[1 * 1056]) + (pp[2 * 1056] + pp[3 * 1056]);     // pp[w] = l_w + l_(w+4)
                 if (diag && e > (row & 3)) v = FA_NEG;
                 s4[e] = v;
             }

@@ -142,7 +142,14 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 
 
-// one thread per (row n, super-block i, chunk j): 4 classes x ... -> writes 8 x 16-byte fragments (t = 0..7) of (p, h) = (j >> 1, j & 1)
+// Weight side of the GEMM: the nibbles stay nibbles in HBM and in LDS (0.72 B per weight) and are expanded to the fp16 MFMA operand nibble * scale in
+// registers (q4_expand below).  Per (32-row tile, super-block i):
+//   Bq [class pair tp = t >> 1][lane = 32 h + n % 32][4 dwords (t & 1, p)]   one dword = the 8 weights of fragment (t, p) of that lane: the bytes
+//        qs[32 j + 4 t .. + 3], j = 2 p + h, nibbles re-ordered so that two masks and one shift split them into fp16 pairs (see q4_expand):
+//        bits 0-3 lo0, 4-7 lo2, 8-11 hi0, 12-15 hi2, 16-19 lo1, 20-23 lo3, 24-27 hi1, 28-31 hi3   (lo_b / hi_b = low / high nibble of byte b)
+//   Bs [lane][p]            fp16 pair (sc[2 j], sc[2 j + 1]), j = 2 p + h
+//   Bm [u][n % 32][4 f16]   (mn[2u], mn[2u], mn[2u+1], mn[2u+1]);   Bd [n % 32] = (d, dmin)
+// one thread per (row n, super-block i, chunk j)
 __global__ __launch_bounds__(256) void q4k_prepack_kernel(const uint8_t *__restrict__ W, uint8_t *__restrict__ out, int N, int nb) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int j = (int)(gid & 3);
@@ -151,9 +158,10 @@ __global__ __launch_bounds__(256) void q4k_prepack_kernel(const uint8_t *__restr
     const int n = (int)(ni / nb);
     if (n >= ((N + 31) / 32) * 32) return;
     const size_t tb = q4kp_tile_blocks(N, nb);
-    v8h *Bw = reinterpret_cast<v8h *>(out);
-    v4h *Bm = reinterpret_cast<v4h *>(out + tb * Q4KP_W_PER_BLK);
-    float2 *Bd = reinterpret_cast<float2 *>(out + tb * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK));
+    uint32_t *Bq = reinterpret_cast<uint32_t *>(out);
+    uint32_t *Bs = reinterpret_cast<uint32_t *>(out + tb * Q4KW_Q_PER_BLK);
+    v4h *Bm = reinterpret_cast<v4h *>(out + tb * (Q4KW_Q_PER_BLK + Q4KW_S_PER_BLK));
+    float2 *Bd = reinterpret_cast<float2 *>(out + tb * (Q4KW_Q_PER_BLK + Q4KW_S_PER_BLK + Q4KW_M_PER_BLK));
     const size_t tile = (size_t)(n >> 5) * nb + i;
     const int nin = n & 31, p = j >> 1, h = j & 1;
     const bool live = n < N;
@@ -161,18 +169,19 @@ __global__ __launch_bounds__(256) void q4k_prepack_kernel(const uint8_t *__restr
     const uint4 hdr = *reinterpret_cast<const uint4 *>(wb);
     uint32_t sc8[2], mn8[2];
     unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
-    const float s_lo = live ? (float)byte_of(sc8, 2 * j) : 0.0f, s_hi = live ? (float)byte_of(sc8, 2 * j + 1) : 0.0f;
     const uint4 qa = *reinterpret_cast<const uint4 *>(wb + 16 + 32 * j), qb = *reinterpret_cast<const uint4 *>(wb + 16 + 32 * j + 16);
     const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        v8h o;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            o[bb] = (_Float16)((float)((qw[t] >> (8 * bb)) & 0xF) * s_lo);
-            o[4 + bb] = (_Float16)((float)((qw[t] >> (8 * bb + 4)) & 0xF) * s_hi);
-        }
-        Bw[((tile * 8 + t) * 2 + p) * 64 + h * 32 + nin] = o;
+        const uint32_t w = live ? qw[t] : 0u;
+        // byte b of w = lo_b | hi_b << 4
+        const uint32_t o = (w & 0xFu) | ((w >> 16) & 0xFu) << 4 | ((w >> 4) & 0xFu) << 8 | ((w >> 20) & 0xFu) << 12 | ((w >> 8) & 0xFu) << 16 |
+                           ((w >> 24) & 0xFu) << 20 | ((w >> 12) & 0xFu) << 24 | ((w >> 28) & 0xFu) << 28;
+        Bq[((tile * 4 + (t >> 1)) * 64 + h * 32 + nin) * 4 + (t & 1) * 2 + p] = o;
+    }
+    {
+        const _Float16 s0 = (_Float16)(live ? (float)byte_of(sc8, 2 * j) : 0.0f), s1 = (_Float16)(live ? (float)byte_of(sc8, 2 * j + 1) : 0.0f);
+        Bs[(tile * 64 + h * 32 + nin) * 2 + p] = (uint32_t)__builtin_bit_cast(uint16_t, s0) | (uint32_t)__builtin_bit_cast(uint16_t, s1) << 16;
     }
     // mins of u = j: (mn[2u], mn[2u], mn[2u+1], mn[2u+1]); scales of the block by j == 0
     v4h mo;
@@ -220,115 +229,135 @@ __global__ __launch_bounds__(256) void q8k_prepack_kernel(const int8_t *__restri
     if (j == 0) Ad[tile * 32 + min_] = live ? xd[(int64_t)m * nb + i] : 0.0f;
 }
 
-// Workgroup = 512 threads = 4 tiles of 32 (m) x 32 (n) (2 m-tiles x 2 n-tiles), TWO waves per tile: the 12 chains of a tile
-// would fill a wave's registers (and spill into AGPRs, which the VALU chain step cannot address), so wave ch of a tile owns
-// classes {2ch, 2ch+1, 4+2ch, 5+2ch} and mins lanes {2ch, 2ch+1} -- 96 accumulation registers, two waves per SIMD -- and
-// the pair meets once, after the K loop, for the reference's final adds ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)), (m0+m2)+(m1+m3).
-// Operands travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: the packed fragments are already lane-linear, one 1-KiB
-// fragment = one wave instruction) into a ring of four half-super-block slots, requested three half-steps ahead of the
-// MFMAs that read them (counted s_waitcnt vmcnt(N), raw s_barrier; the DMA never passes through VGPRs).  A half-step =
-// 4 column classes = 8 A + 8 B fragments per tile; the even half carries the block's scales, the odd half the mins operands.
-// Slot: [A m0: 8 KiB][A m1][B n0][B n1][aux 4 KiB]; aux of an even half = (Ad m0, Ad m1, Bd n0, Bd n1) in 768 B,
-// of an odd half = (Am m0, Am m1, Bm n0, Bm n1), 1 KiB each.
-// MTW = m-tiles per workgroup (2: 64 x 64 tile, 512 threads; 1: 32 x 64, 256 threads -- for small M, where the larger tile leaves CUs idle)
-constexpr int GQ_SLOT = 32768 + 4096, GQ_SLOTS = 4, GQ_LDS = GQ_SLOT * GQ_SLOTS;
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst_in) {
-    unsigned keep;
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);   // wave-uniform by construction; M0 wants an SGPR
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+// Workgroup = 256 threads = one 32 (m) x 64 (n) tile: two 32 x 32 MFMA tiles (nw = wid >> 1), TWO waves per tile -- the 12 chains of a tile would
+// fill a wave's registers (and spill into AGPRs, which the VALU chain step cannot address), so wave ch of a tile owns classes {2ch, 2ch+1, 4+2ch, 5+2ch}
+// and mins lanes {2ch, 2ch+1} (96 accumulation registers), and the pair meets once, after the K loop, for the reference's final adds
+// ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)), (m0+m2)+(m1+m3).  A workgroup keeps one wave per SIMD and 64 KiB of LDS, so TWO workgroups share a CU: they
+// are not in step with each other, and one's LDS reads / VALU chain steps / prologue / epilogue run under the other's MFMAs and operand stream
+// (the 512-thread, 64 x 64 form of round 1 had all eight waves in lock step behind one barrier: every phase of a half-step exposed, 1 workgroup per CU).
+// Operands travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: the packed fragments are already lane-linear, one 1-KiB fragment = one wave
+// instruction) into a ring of four half-super-block slots, requested three half-steps ahead of the MFMAs that read them (counted s_waitcnt vmcnt(N),
+// raw s_barrier; the DMA never passes through VGPRs).  A half-step = 4 column classes; every wave issues exactly four DMAs for it.
+// Slot = 16 fragments of 1 KiB, fragment c written by wave c & 3 as its DMA number c >> 2:
+//   c 0..7    activation fragments (class c >> 1 of the half, k-half p = c & 1), fp16
+//   c 8..11   weight nibbles: n-tile (c - 8) >> 1, class pair (c - 8) & 1        (4 B per lane and fragment; expanded in registers)
+//   c 12..14  even half: [Ad | Bd n0 | Bd n1], [Bs n0 | Bs n1], -- ;   odd half: Am, Bm n0, Bm n1
+//   c 15      unused (keeps the DMA count per wave uniform)
+constexpr int GQ_SLOT = 16384, GQ_SLOTS = 4, GQ_LDS = GQ_SLOT * GQ_SLOTS;
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+// (q & mask) | magic in one VALU instruction (the compiler prefers v_and + v_or with literals; gfx9 VOP3 reads one SGPR, so the magic sits in a VGPR)
+__device__ __forceinline__ uint32_t and_or(uint32_t q, uint32_t mask_s, uint32_t magic_v) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(q), "s"(mask_s), "v"(magic_v));
+    return r;
 }
-// the same with a wave-uniform source base (SGPR pair) and a 32-bit per-lane offset: no 64-bit vector address arithmetic
-__device__ __forceinline__ void glds16s(const void *sbase, unsigned voff, unsigned lds_dst_in) {
-    unsigned keep;
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+// one dword of re-ordered nibbles -> the 8 fp16 values (lo0..lo3) * s[0], (hi0..hi3) * s[1] of an MFMA B fragment.  0x6400 | n = 1024 + n and
+// 0x5400 | n << 4 = 64 + n as fp16; fma(1024 + n, s, -1024 s) = n s exactly (one rounding of an exactly representable value, n s <= 945).
+__device__ __forceinline__ v8h q4_expand(uint32_t q, v2h s, v2h o1024, v2h o64, uint32_t m0f, uint32_t mf0, uint32_t k1024, uint32_t k64) {
+    const uint32_t t = q >> 8;
+    const v2h d0 = __builtin_bit_cast(v2h, and_or(q, m0f, k1024)), d1 = __builtin_bit_cast(v2h, and_or(q, mf0, k64));
+    const v2h d2 = __builtin_bit_cast(v2h, and_or(t, m0f, k1024)), d3 = __builtin_bit_cast(v2h, and_or(t, mf0, k64));
+    const v2h w0 = __builtin_elementwise_fma(d0, (v2h){s[0], s[0]}, (v2h){o1024[0], o1024[0]});
+    const v2h w1 = __builtin_elementwise_fma(d1, (v2h){s[0], s[0]}, (v2h){o64[0], o64[0]});
+    const v2h w2 = __builtin_elementwise_fma(d2, (v2h){s[1], s[1]}, (v2h){o1024[1], o1024[1]});
+    const v2h w3 = __builtin_elementwise_fma(d3, (v2h){s[1], s[1]}, (v2h){o64[1], o64[1]});
+    return (v8h){w0[0], w0[1], w1[0], w1[1], w2[0], w2[1], w3[0], w3[1]};
 }
-template <int MTW>
-__global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__restrict__ Wp, const uint8_t *__restrict__ Xp, const float *__restrict__ bias,
-                                                         void *__restrict__ y, int y_f16, int64_t ldy, const float *__restrict__ residual, int M, int N,
-                                                         int nb) {
+#if defined(MLLM_HIP_STAMPS)   // diagnosis build (scratch/stamps.sh): per-wave shader-clock stamps of the first GQ_ST_HS half-steps, kept in LDS, dumped by every 37th workgroup
+constexpr int GQ_ST_HS = 12, GQ_ST_N = 8, GQ_ST_WG = 64;
+__device__ unsigned long long g_gq_stamps[GQ_ST_WG * (4 * GQ_ST_HS * GQ_ST_N + 8)];
+#define GQS(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && st_hs < GQ_ST_HS) st_lds[(wid * GQ_ST_HS + st_hs) * GQ_ST_N + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GQS(i) do { } while (0)
+#endif
+// diagnosis builds (scratch/gemm_variants.sh): each switch removes one component of the half-step; the results are wrong, only the time is read
+#if defined(GQ_NO_RETIRE)
+constexpr int GQ_RET = 1;
+#else
+constexpr int GQ_RET = 16;
+#endif
+#if defined(GQ_NO_MFMA)
+#define GQ_MFMA(a, b, c) (c)
+#else
+#define GQ_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+#if defined(GQ_NO_EXPAND)
+#define GQ_EXPAND(q, s, o1, o2) __builtin_bit_cast(v8h, (u32x4){q, q, q, q})
+#else
+#define GQ_EXPAND(q, s, o1, o2) q4_expand(q, s, o1, o2, m0f, mf0, k1024, k64)
+#endif
+__global__ __launch_bounds__(256, 2) void gemm_q4k_kernel(const uint8_t *__restrict__ Wp, const uint8_t *__restrict__ Xp, const float *__restrict__ bias,
+                                                          void *__restrict__ y, int y_f16, int64_t ldy, const float *__restrict__ residual, int M, int N,
+                                                          int nb) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the DMA bookkeeping below stays scalar
-    const int col = lane & 31, h = lane >> 5;
-    const int MT = (M + 31) / 32, NT = (N + 31) / 32;
-    constexpr int NW = 4 * MTW, FPW = (8 * MTW + 16) / NW;    // waves; operand fragments copied per wave and half-step
-    const int tile = wid >> 1, ch = wid & 1, mw = tile >> 1, nw = tile & 1;
-    const int mt = blockIdx.y * MTW + mw, nt = blockIdx.x * 2 + nw;
-    const bool active = mt < MT && nt < NT;
-    const size_t tbw = q4kp_tile_blocks(N, nb), tbx = q4kp_tile_blocks(M, nb);
-    // DMA sources (tiles clamped: a workgroup at the edge copies a valid tile twice and does not use the copy)
-    const int mts0 = min((int)blockIdx.y * MTW, MT - 1), mts1 = min((int)blockIdx.y * MTW + MTW - 1, MT - 1);
-#if defined(GQ_DBG_SAME)   // diagnosis build: every workgroup streams tile 0 (operand traffic served by L2 hits only; results are wrong)
-    const int nts0 = 0, nts1 = 0;
-#else
-    const int nts0 = min((int)blockIdx.x * 2, NT - 1), nts1 = min((int)blockIdx.x * 2 + 1, NT - 1);
+#if defined(MLLM_HIP_STAMPS)
+    __shared__ unsigned long long st_lds[4 * GQ_ST_HS * GQ_ST_N];
+    int st_hs = 0;
+    unsigned long long st_rt[6];
+    st_rt[0] = __builtin_amdgcn_s_memrealtime();
+    st_rt[2] = 0;
+    for (int i = threadIdx.x; i < 4 * GQ_ST_HS * GQ_ST_N; i += 256) st_lds[i] = 0;
 #endif
-    const uint8_t *XpM = Xp + tbx * Q4KP_W_PER_BLK, *XpD = Xp + tbx * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK);
-    const uint8_t *WpM = Wp + tbw * Q4KP_W_PER_BLK, *WpD = Wp + tbw * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK);
+#if defined(GQ_STAGGER)   // diagnosis: the second workgroup of every CU starts GQ_STAGGER x 64 cycles late (first wave of 512 workgroups only)
+    if ((((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1) && (blockIdx.x + gridDim.x * blockIdx.y) < 512) {
+#pragma unroll 1
+        for (int i = 0; i < GQ_STAGGER; i += 100) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
+    const int col = lane & 31, h = lane >> 5;
+    const int NT = (N + 31) / 32;
+    const int nw = wid >> 1, ch = wid & 1;
+    const int mt = blockIdx.y, nt = blockIdx.x * 2 + nw;          // mt < ceil(M / 32) by the grid
+    const bool active = nt < NT;
+    const size_t tbw = q4kp_tile_blocks(N, nb), tbx = q4kp_tile_blocks(M, nb);
+    // DMA sources (n-tiles clamped: a workgroup at the edge copies a valid tile twice and does not use the copy)
+    const int nts0 = min((int)blockIdx.x * 2, NT - 1), nts1 = min((int)blockIdx.x * 2 + 1, NT - 1);
+    const uint8_t *XpM = Xp + tbx * Q4KP_W_PER_BLK, *XpD = XpM + tbx * Q4KP_M_PER_BLK;
+    const uint8_t *WpS = Wp + tbw * Q4KW_Q_PER_BLK, *WpM = WpS + tbw * Q4KW_S_PER_BLK, *WpD = WpM + tbw * Q4KW_M_PER_BLK;
     const unsigned ring0 = (unsigned)(size_t)ring;   // LDS byte address of the ring
-    // FPW + 1 DMA instructions per wave and half-step: FPW of the operand fragments + 1 aux (or a dummy into the scratch tail, so the count is
-    // uniform).  A lone wave issues about one instruction per 4-8 cycles whatever its kind, so everything about the stream is set up once:
-    // fragment q of this wave always comes from sb[q] + 8192 * hstep + 16 * lane and lands at slot + 1024 * (q NW + wid); the aux sources are
-    // per-lane pointers that advance by a per-lane stride per block.  One asm block per half-step (M0 saved and restored once).
-    const uint8_t *sb[FPW];
-#pragma unroll
-    for (int q = 0; q < FPW; ++q) {
-        const int c = q * NW + wid, f = c & 7;                  // fragment c of the slot: [A tiles: 8 MTW][B tiles: 16]
-        size_t off;                                             // the (tile, block 0) record inside its operand buffer
-        const uint8_t *base = Wp;
-        if (c < 8) { base = Xp; off = (size_t)mts0 * nb; }
-        else if (c < 8 * MTW) { base = Xp; off = (size_t)mts1 * nb; }
-        else if (c < 8 * MTW + 8) off = (size_t)nts0 * nb;
-        else off = (size_t)nts1 * nb;
-        const uint8_t *ptr = base + off * Q4KP_W_PER_BLK + (size_t)f * 1024;
+    // A lone wave issues about one instruction per 4-8 cycles whatever its kind, so everything about the stream is set up once: this wave's two
+    // activation fragments come from sa0 / sa1 + voffA (8 KiB further per half-step), its nibble fragment from sq + voffB (2 KiB further), its aux
+    // fragment from per-lane pointers that advance by a per-lane stride per block.  One asm block per half-step (M0 saved and restored once).
+    auto uniform_ptr = [](const uint8_t *ptr) __attribute__((always_inline)) {
         const uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)ptr), phi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)ptr >> 32));
-        sb[q] = reinterpret_cast<const uint8_t *>(((uint64_t)phi << 32) | (uint64_t)plo);   // (readfirstlane returns int: no sign extension into the high half)
-    }
-    // aux of an even half (scales): wave 0, lanes < 48; of an odd half (mins operands): waves 0..3.  Everyone else copies 16 dummy bytes.
-    const uint8_t *pe = Xp + lane * 16, *po = Xp + lane * 16;
+        return reinterpret_cast<const uint8_t *>(((uint64_t)phi << 32) | (uint64_t)plo);   // (readfirstlane returns int: no sign extension into the high half)
+    };
+    const uint8_t *sa0 = uniform_ptr(Xp + (size_t)mt * nb * Q4KP_W_PER_BLK + (size_t)wid * 1024);
+    const uint8_t *sa1 = uniform_ptr(Xp + (size_t)mt * nb * Q4KP_W_PER_BLK + (size_t)(4 + wid) * 1024);
+    const uint8_t *sq = uniform_ptr(Wp + (size_t)(nw ? nts1 : nts0) * nb * Q4KW_Q_PER_BLK + (size_t)ch * 1024);
+    const uint8_t *pe = Xp + lane * 16, *po = Xp + lane * 16;     // aux sources: even / odd half (lanes without a job re-read a valid address into an unused KiB)
     unsigned se = 0, so = 0;
-    if (wid == 0 && lane < 48) {
-        pe = lane < 8    ? XpD + (size_t)mts0 * nb * 128 + lane * 16
-             : lane < 16 ? XpD + (size_t)mts1 * nb * 128 + (lane - 8) * 16
-             : lane < 32 ? WpD + (size_t)nts0 * nb * 256 + (lane - 16) * 16
-                         : WpD + (size_t)nts1 * nb * 256 + (lane - 32) * 16;
-        se = lane < 16 ? 128u : 256u;
-    }
-    if (wid < 4) {
-        const int tsel = wid == 0 ? mts0 : (wid == 1 ? mts1 : (wid == 2 ? nts0 : nts1));
-        po = (wid < 2 ? XpM : WpM) + (size_t)tsel * nb * 1024 + lane * 16;
+    if (wid == 0) {
+        pe = lane < 8    ? XpD + (size_t)mt * nb * 128 + lane * 16
+             : lane < 24 ? WpD + (size_t)nts0 * nb * 256 + (lane - 8) * 16
+             : lane < 40 ? WpD + (size_t)nts1 * nb * 256 + (lane - 24) * 16
+                         : Xp + lane * 16;
+        se = lane < 8 ? 128u : (lane < 40 ? 256u : 0u);
+        po = XpM + (size_t)mt * nb * 1024 + lane * 16;
+        so = 1024u;
+    } else if (wid == 1) {
+        pe = WpS + (size_t)(lane < 32 ? nts0 : nts1) * nb * 512 + (lane & 31) * 16;
+        se = 512u;
+        po = WpM + (size_t)nts0 * nb * 1024 + lane * 16;
+        so = 1024u;
+    } else if (wid == 2) {
+        po = WpM + (size_t)nts1 * nb * 1024 + lane * 16;
         so = 1024u;
     }
-    const unsigned scratch = ring0 + (unsigned)GQ_LDS;
-    const unsigned dst_e = wid == 0 ? 32768u : 0xffffffffu, dst_o = wid < 4 ? 32768u + (unsigned)wid * 1024u : 0xffffffffu;   // relative to the slot; ~0 = scratch
-    unsigned voff = (unsigned)lane * 16u;     // + 8192 per half-step issued
+    unsigned voffA = (unsigned)lane * 16u, voffB = (unsigned)lane * 16u;
     unsigned islot = ring0;                   // LDS address of the slot the next issue fills
     auto issue = [&](int hb) __attribute__((always_inline)) {
         const unsigned d0 = __builtin_amdgcn_readfirstlane(islot + (unsigned)wid * 1024u);
-        const unsigned rel = hb == 0 ? dst_e : dst_o;
-        const unsigned da = __builtin_amdgcn_readfirstlane(rel == 0xffffffffu ? scratch : islot + rel);
         const uint8_t *pa = hb == 0 ? pe : po;
         unsigned keep;
-        if constexpr (FPW == 4) {
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
-                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
-                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(d0), "s"(sb[0]), "s"(sb[1]), "s"(sb[2]), "s"(sb[3]), "s"(da), "v"(pa) : "memory", "scc");
-        } else {
-            static_assert(FPW == 6 || FPW == 4, "");
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
-                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
-                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
-                         "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %8\n\t"
-                         "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(d0), "s"(sb[0]), "s"(sb[1]), "s"(sb[2]), "s"(sb[3]), "s"(sb[FPW - 2]), "s"(sb[FPW - 1]), "s"(da), "v"(pa)
-                         : "memory", "scc");
-        }
-        voff += 8192u;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voffA), "v"(voffB), "s"(d0), "s"(sa0), "s"(sa1), "s"(sq), "v"(pa) : "memory", "scc");
+        voffA += 8192u;
+        voffB += 2048u;
         islot = islot + (unsigned)GQ_SLOT == ring0 + (unsigned)GQ_LDS ? ring0 : islot + (unsigned)GQ_SLOT;
         if (hb == 0) pe += se; else po += so;
     };
@@ -337,6 +366,9 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
     issue(1);                 // TS >= 2 always (nb >= 1)
     if (TS > 2) issue(0);
     __builtin_amdgcn_sched_barrier(0);
+#if defined(MLLM_HIP_STAMPS)
+    st_rt[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     v16f acc[4], accm[2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -349,63 +381,109 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
     v16f zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
-    const v8h hz = {0, 0, 0, 0, 0, 0, 0, 0};
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     // Software pipeline over the half-steps: a half-step requests its LDS operands, then *retires the previous half-step's class sums*
-    // (the VALU chain step acc = fma(dd, c, acc), which covers the LDS latency), then issues its own MFMAs, whose results are
+    // (the VALU chain step acc = fma(dd, c, acc), which covers the LDS latency), expands its nibbles, then issues its own MFMAs, whose results are
     // read one barrier later -- no wave waits on an MFMA it has just issued.  dd starts at 0 so the first retire is fma(0, 0, 0).
     float dd[16], dm[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dd[r] = dm[r] = 0.0f;
     v16f cp0 = zero, cp1 = zero;
+    v2h sc[2] = {{0, 0}, {0, 0}}, o1024[2] = {{0, 0}, {0, 0}}, o64[2] = {{0, 0}, {0, 0}};   // this lane's sub-block scale pairs (p = 0, 1) of the block, and -1024 s, -64 s
+    const uint32_t k1024 = 0x64006400u, k64 = 0x54005400u;
+    const uint32_t m0f = __builtin_amdgcn_readfirstlane(0x000F000F), mf0 = __builtin_amdgcn_readfirstlane(0x00F000F0);
     // per-lane LDS read addresses inside slot 0; the compute slot's offset cycles through the ring
-    const unsigned lA = ring0 + (unsigned)(mw * 8192 + ch * 4096 + lane * 16), lB = ring0 + (unsigned)(MTW * 8192 + nw * 8192 + ch * 4096 + lane * 16);
-    const unsigned lW = ring0 + (unsigned)(32768 + 256 + nw * 256 + col * 8), lX = ring0 + (unsigned)(32768 + mw * 128 + 16 * h);
-    const unsigned lAm = ring0 + (unsigned)(32768 + mw * 1024 + col * 8 + 2 * ch * 256), lBm = ring0 + (unsigned)(32768 + 2048 + nw * 1024 + col * 8 + 2 * ch * 256);
+    const unsigned lA = ring0 + (unsigned)(ch * 4096 + lane * 16), lQ = ring0 + (unsigned)((8 + 2 * nw + ch) * 1024 + lane * 16);
+    const unsigned lX = ring0 + (unsigned)(12288 + 16 * h), lW = ring0 + (unsigned)(12288 + 128 + nw * 256 + col * 8), lS = ring0 + (unsigned)(13312 + nw * 512 + lane * 8);
+    const unsigned lAm = ring0 + (unsigned)(12288 + col * 8 + 2 * ch * 256), lBm = ring0 + (unsigned)(13312 + nw * 1024 + col * 8 + 2 * ch * 256);
     unsigned cslot = 0;
     // one half-step; HB = which half of the block, REM = half-steps still to come after this one, clipped to 3 (3 = steady state)
     auto step = [&](auto HB, auto REM) __attribute__((always_inline)) {
         constexpr int hb = decltype(HB)::value, rem = decltype(REM)::value;
-        // this wave's DMA of the half-step has landed when at most the (up to two) younger half-steps are outstanding: FPW + 1 per half-step
-        if (rem >= 2) { if (MTW == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
-        else if (rem == 1) { if (MTW == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+        GQS(0);
+        // this wave's DMA of the half-step has landed when at most the (up to two) younger half-steps are outstanding: 4 per half-step
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if !defined(GQ_DBG_NOBAR)   // diagnosis build: waves free-run (results are wrong)
+        GQS(1);
+#if !defined(GQ_NO_BAR)
         __builtin_amdgcn_s_barrier();      // everyone's part of the slot has landed; everyone is done with the previous slot
 #endif
         asm volatile("" ::: "memory");
-#if !defined(GQ_DBG_NODMA)   // diagnosis build: no operand stream after the first three half-steps (compute + barriers only; results are wrong)
+        GQS(2);
+#if defined(MLLM_HIP_STAMPS)
+        if (st_rt[2] == 0) st_rt[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+#if !defined(GQ_NO_DMA)
         if (rem >= 3) issue(1 - hb);
 #endif
+        GQS(3);
         if (active) {
             typedef __attribute__((address_space(3))) const char *lds_cp;
             const unsigned cs = __builtin_amdgcn_readfirstlane(cslot);
+            // LDS requests in the order of use: the 4 nibble dwords of this wave's fragments (+ the block's scale pairs), its 4 activation fragments
+            // (classes 2ch, 2ch+1 of the half, k-halves 0 / 1), then the block scales (even half) or the mins operands (odd half)
+            const u32x4 qv = *reinterpret_cast<__attribute__((address_space(3))) const u32x4 *>((lds_cp)(size_t)(lQ + cs));
+            u32x2 sraw;
+            if (hb == 0) sraw = *reinterpret_cast<__attribute__((address_space(3))) const u32x2 *>((lds_cp)(size_t)(lS + cs));
+            const __attribute__((address_space(3))) v8h *A = reinterpret_cast<__attribute__((address_space(3))) const v8h *>((lds_cp)(size_t)(lA + cs));
+            const v8h a0 = A[0], a2 = A[128], a1 = A[64], a3 = A[192];
             f32x2 dwv;
             f32x4 dx[4];
+            v4h a4[2], b4[2];                                  // mins operands (k = 0..3 of the fragment; lanes 32..63 carry k = 8..15 = zeros)
             if (hb == 0) {
                 dwv = *reinterpret_cast<__attribute__((address_space(3))) const f32x2 *>((lds_cp)(size_t)(lW + cs));
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) dx[g4] = *reinterpret_cast<__attribute__((address_space(3))) const f32x4 *>((lds_cp)(size_t)(lX + cs) + 32 * g4);   // rows 8 g4 + 4h + (0..3)
-            }
-            // this wave's 4 + 4 fragments: classes 2ch, 2ch+1 of the half
-            const __attribute__((address_space(3))) v8h *A = reinterpret_cast<__attribute__((address_space(3))) const v8h *>((lds_cp)(size_t)(lA + cs));
-            const __attribute__((address_space(3))) v8h *B = reinterpret_cast<__attribute__((address_space(3))) const v8h *>((lds_cp)(size_t)(lB + cs));
-            const v8h a0 = A[0], b0 = B[0], a2 = A[128], b2 = B[128], a1 = A[64], b1 = B[64], a3 = A[192], b3 = B[192];
-            v4h a4[2], b4[2];                                  // mins operands (k = 0..3 of the fragment; lanes 32..63 carry k = 8..15 = zeros)
-            if (hb == 1) {
+            } else {
                 const __attribute__((address_space(3))) v4h *Am = reinterpret_cast<__attribute__((address_space(3))) const v4h *>((lds_cp)(size_t)(lAm + cs));
                 const __attribute__((address_space(3))) v4h *Bm = reinterpret_cast<__attribute__((address_space(3))) const v4h *>((lds_cp)(size_t)(lBm + cs));
 #pragma unroll
                 for (int k = 0; k < 2; ++k) { a4[k] = Am[k * 32]; b4[k] = Bm[k * 32]; }   // all lanes read (no wait under a predicate)
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // retire the previous half-step (hb == 0: the odd half of the previous block, still under that block's dd)
+            GQS(4);
+            // The matrix pipe runs 32 cycles per MFMA and takes 8 of them from the wave's issue; the VALU work of the half-step is spread BETWEEN the MFMAs
+            // (sched_group_barrier below) so that the pipe runs under it: retire cp0 of the previous half-step | expand b0 | MFMA | retire cp1 | expand b2 |
+            // MFMA | expand b1 | MFMA | expand b3 | MFMA | new block scales (even half) or the mins chain step (odd half).
+            // (hb == 0 retires the odd half of the previous block, still under that block's dd.)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[2 * (1 - hb)][r] = __fmaf_rn(dd[r], cp0[r], acc[2 * (1 - hb)][r]);
-                acc[2 * (1 - hb) + 1][r] = __fmaf_rn(dd[r], cp1[r], acc[2 * (1 - hb) + 1][r]);
+            for (int r = 0; r < GQ_RET; ++r) acc[2 * (1 - hb)][r] = __fmaf_rn(dd[r], cp0[r], acc[2 * (1 - hb)][r]);
+            if (hb == 0) {
+                const v2h n1024 = {(_Float16)-1024.0f, (_Float16)-1024.0f}, n64 = {(_Float16)-64.0f, (_Float16)-64.0f};
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const unsigned sv = p == 0 ? sraw.x : sraw.y;    // (bit_cast of a variably indexed vector element miscompiles with this clang: both p read element 0)
+                    sc[p] = __builtin_bit_cast(v2h, sv);
+                    o1024[p] = sc[p] * n1024;                        // exact: 1024 * 63 = 64512 < 65504
+                    o64[p] = sc[p] * n64;
+                }
             }
+            v16f cm0, cm1;
+            if (hb == 1) {
+                v8h am[2], bm[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const u32x2 ua = __builtin_bit_cast(u32x2, a4[k]), ub = __builtin_bit_cast(u32x2, b4[k]);
+                    const u32x4 wa = {h == 0 ? ua[0] : 0u, h == 0 ? ua[1] : 0u, 0u, 0u}, wb = {h == 0 ? ub[0] : 0u, h == 0 ? ub[1] : 0u, 0u, 0u};
+                    am[k] = __builtin_bit_cast(v8h, wa); bm[k] = __builtin_bit_cast(v8h, wb);
+                }
+                cm0 = GQ_MFMA(am[0], bm[0], zero);
+                cm1 = GQ_MFMA(am[1], bm[1], zero);
+            }
+            // fragment order (class k, k-half p): qv = (k0 p0, k0 p1, k1 p0, k1 p1)
+            const v8h b0 = GQ_EXPAND(qv[0], sc[0], o1024[0], o64[0]);
+            cp0 = GQ_MFMA(a0, b0, zero);
+#pragma unroll
+            for (int r = 0; r < GQ_RET; ++r) acc[2 * (1 - hb) + 1][r] = __fmaf_rn(dd[r], cp1[r], acc[2 * (1 - hb) + 1][r]);
+            const v8h b2 = GQ_EXPAND(qv[2], sc[0], o1024[0], o64[0]);
+            cp1 = GQ_MFMA(a2, b2, zero);
+            const v8h b1 = GQ_EXPAND(qv[1], sc[1], o1024[1], o64[1]);
+            cp0 = GQ_MFMA(a1, b1, cp0);
+            const v8h b3 = GQ_EXPAND(qv[3], sc[1], o1024[1], o64[1]);
+            cp1 = GQ_MFMA(a3, b3, cp1);
             if (hb == 0) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
@@ -414,27 +492,7 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
                         dd[4 * g4 + e] = dx[g4][e] * dwv[0];        // y.d * fp16(x.d)
                         dm[4 * g4 + e] = (-dx[g4][e]) * dwv[1];     // -y.d * fp16(x.dmin)
                     }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            v16f cm0, cm1;
-            if (hb == 1) {
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                v8h am[2], bm[2];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const u32x2 ua = __builtin_bit_cast(u32x2, a4[k]), ub = __builtin_bit_cast(u32x2, b4[k]);
-                    const u32x4 wa = {h == 0 ? ua[0] : 0u, h == 0 ? ua[1] : 0u, 0u, 0u}, wb = {h == 0 ? ub[0] : 0u, h == 0 ? ub[1] : 0u, 0u, 0u};
-                    am[k] = __builtin_bit_cast(v8h, wa); bm[k] = __builtin_bit_cast(v8h, wb);
-                }
-                cm0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[0], bm[0], zero, 0, 0, 0);
-                cm1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[1], bm[1], zero, 0, 0, 0);
-            }
-            cp0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0);
-            cp1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b2, zero, 0, 0, 0);
-            cp0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, cp0, 0, 0, 0);
-            cp1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, b3, cp1, 0, 0, 0);
-            if (hb == 1) {
+            } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     accm[0][r] = __fmaf_rn(dm[r], cm0[r], accm[0][r]);
@@ -442,6 +500,10 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
                 }
             }
         }
+        GQS(6);
+#if defined(MLLM_HIP_STAMPS)
+        ++st_hs;
+#endif
         cslot = cslot + (unsigned)GQ_SLOT == (unsigned)GQ_LDS ? 0u : cslot + (unsigned)GQ_SLOT;
     };
     using std::integral_constant;
@@ -466,11 +528,14 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
     // the pair meets through LDS (the ring is free now): wave ch finishes accumulator registers 8 ch .. 8 ch + 7 of the tile and hands the other
     // eight of its partial sums (a0+a4 | a2+a6, a1+a5 | a3+a7, m0 | m2, m1 | m3) to its partner -- IEEE adds commute, so which of the two waves
     // performs (a0+a4)+(a2+a6) does not matter.  Residual rows are requested together, ahead of the adds.
+#if defined(MLLM_HIP_STAMPS)
+    st_rt[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     float x[16], yv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { x[r] = acc[0][r] + acc[2][r]; yv[r] = acc[1][r] + acc[3][r]; }
     __syncthreads();
-    float *xch = reinterpret_cast<float *>(ring) + (size_t)tile * 64 * 64 + lane;
+    float *xch = reinterpret_cast<float *>(ring) + (size_t)nw * 64 * 64 + lane;
     const int n = nt * 32 + col;
     auto finish = [&](auto R0) __attribute__((always_inline)) {
         constexpr int r0 = decltype(R0)::value, p0 = 8 - r0;
@@ -480,6 +545,9 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
             xch[r * 64] = x[r]; xch[(16 + r) * 64] = yv[r]; xch[(32 + r) * 64] = accm[0][r]; xch[(48 + r) * 64] = accm[1][r];
         }
         __syncthreads();
+#if defined(MLLM_HIP_STAMPS)
+        st_rt[4] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (!active || n >= N) return;
         float v[8];
 #pragma unroll
@@ -518,7 +586,28 @@ __global__ __launch_bounds__(256 * MTW) void gemm_q4k_kernel(const uint8_t *__re
         }
     };
     if (ch == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 8>{});
+#if defined(MLLM_HIP_STAMPS)
+    {
+        const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+        if (wg % 37 == 0 && wg / 37 < GQ_ST_WG) {
+            unsigned long long *dst = g_gq_stamps + (size_t)(wg / 37) * (4 * GQ_ST_HS * GQ_ST_N + 8);
+            for (int i = threadIdx.x; i < 4 * GQ_ST_HS * GQ_ST_N; i += 256) dst[i] = st_lds[i];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the output stores have been acknowledged
+            st_rt[5] = __builtin_amdgcn_s_memrealtime();
+            if (threadIdx.x == 0) {
+                unsigned long long *tail = dst + 4 * GQ_ST_HS * GQ_ST_N;
+                for (int i = 0; i < 6; ++i) tail[i] = st_rt[i];
+                tail[6] = __builtin_amdgcn_s_getreg(63492); tail[7] = __builtin_amdgcn_s_getreg(63508);   // HW_ID, XCC_ID
+            }
+        }
+    }
+#endif
 }
+#if defined(MLLM_HIP_STAMPS)
+extern "C" int mllm_hip_debug_read_gemm_stamps(unsigned long long *host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gq_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // fp32 GEMM y = x W^T (+bias) in vec_dot_fp32's order (VecDotFP32.cpp:31-58): 32 fp32 chains per output (chain c takes
@@ -616,7 +705,8 @@ static int launch_gemv_q4k(const void *W, const float *bias, const int8_t *xqs, 
 
 using namespace mllm_hip;
 
-extern "C" size_t mllm_hip_q4k_prepack_bytes(int rows, int K) { return K % 256 ? 0 : q4kp_bytes(rows, K); }
+extern "C" size_t mllm_hip_q4k_prepack_bytes(int rows, int K) { return K % 256 ? 0 : q4kp_bytes(rows, K); }     // activation side (fp16 fragments)
+extern "C" size_t mllm_hip_q4k_wpack_bytes(int N, int K) { return K % 256 ? 0 : q4kw_bytes(N, K); }           // weight side (nibbles + scales)
 extern "C" int mllm_hip_q4k_prepack(const void *W, int N, int K, void *out, void *stream) {
     if (K % 256 != 0 || K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
     const int nb = K / 256;
@@ -627,27 +717,19 @@ extern "C" int mllm_hip_q4k_prepack(const void *W, int N, int K, void *out, void
 static int launch_gemm_packed(const void *Wpacked, const float *bias, const void *xpack, void *y, int y_dtype, int64_t ldy, const float *residual, int M,
                               int N, int K, hipStream_t st) {
     const int nb = K / 256;
-    dim3 grid((N + 63) / 64, (M + 63) / 64);
-    constexpr int lds = GQ_LDS + 1024;   // ring + scratch tail
     // the attribute is per device: one bit per device id, set once (a second mllm_hip_init(device) in the same process must not inherit device 0's flag)
     static std::atomic<uint64_t> attr_done{0};
     int dev = 0;
     MH_CHECK(hipGetDevice(&dev));
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GQ_LDS));
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    // 64 x 64 workgroup tiles; 32 x 64 only for very small problems (measured: at M = 282 the 64 x 64 form is 1.6x faster despite 120-160 workgroups)
-    if ((int)(grid.x * grid.y) >= 48) {
-        hipLaunchKernelGGL(gemm_q4k_kernel<2>, grid, dim3(512), lds, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16, ldy,
-                           residual, M, N, nb);
-    } else {
-        dim3 grid1((N + 63) / 64, (M + 31) / 32);
-        hipLaunchKernelGGL(gemm_q4k_kernel<1>, grid1, dim3(256), lds, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16, ldy,
-                           residual, M, N, nb);
-    }
+    // 32 x 64 workgroup tiles, two workgroups per CU (64 KiB of LDS and one wave per SIMD each)
+    dim3 grid((N + 63) / 64, (M + 31) / 32);
+    hipLaunchKernelGGL(gemm_q4k_kernel, grid, dim3(256), GQ_LDS, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16, ldy,
+                       residual, M, N, nb);
     return MH_LAUNCH_OK("gemm_q4k");
 }
 // GEMM on pre-packed weights and activations already in packed form (mllm_hip_quantize_q8k_packed / _rmsnorm_packed / _layernorm_packed)
@@ -695,7 +777,7 @@ extern "C" int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const i
     // raw Q4_K blocks with M >= 16: pack both sides into stream-ordered scratch, then the packed GEMM (callers that keep the
     // weights resident pre-pack once with mllm_hip_q4k_prepack and call mllm_hip_linear_q4kp_q8k)
     void *wp = nullptr, *xp = nullptr;
-    MH_CHECK(hipMallocAsync(&wp, q4kp_bytes(N, K), st));
+    MH_CHECK(hipMallocAsync(&wp, q4kw_bytes(N, K), st));
     MH_CHECK(hipMallocAsync(&xp, q4kp_bytes(M, K), st));
     int rc = mllm_hip_q4k_prepack(W, N, K, wp, stream);
     if (!rc) rc = mllm_hip_linear_q4kp_q8k(wp, bias, xqs, xd, xbsums, xp, y, y_dtype, ldy, residual, M, N, K, stream);

@@ -60,6 +60,7 @@ def load() -> C.CDLL:
         _lib.mllm_hip_qwen2vl_decode_weight_bytes.restype = C.c_int64
         _lib.mllm_hip_qwen2vl_decode_weight_bytes.argtypes = [C.c_void_p]
         _lib.mllm_hip_q4k_prepack_bytes.restype = C.c_size_t
+        _lib.mllm_hip_q4k_wpack_bytes.restype = C.c_size_t
         _lib.mllm_hip_qwen2vl_stream.restype = C.c_void_p
         _lib.mllm_hip_qwen2vl_stream.argtypes = [C.c_void_p]
         _lib.mllm_hip_qwen2vl_destroy.restype = None

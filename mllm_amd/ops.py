@@ -235,8 +235,9 @@ def linear_q4k_packed_producers(Wq, x, N, mode="quant", w=None, b=None, eps=1e-6
     Wd = _dev(np.asarray(Wq).view(np.uint8))
     lib_ = L.load()
     lib_.mllm_hip_q4k_prepack_bytes.restype = C.c_size_t
+    lib_.mllm_hip_q4k_wpack_bytes.restype = C.c_size_t
     Kw = K // 2 if mode == "silu_mul" else K
-    wp = torch.empty(lib_.mllm_hip_q4k_prepack_bytes(C.c_int(N), C.c_int(Kw)), dtype=torch.uint8, device="cuda")
+    wp = torch.empty(lib_.mllm_hip_q4k_wpack_bytes(C.c_int(N), C.c_int(Kw)), dtype=torch.uint8, device="cuda")
     xp = torch.empty(lib_.mllm_hip_q4k_prepack_bytes(C.c_int(M), C.c_int(Kw)), dtype=torch.uint8, device="cuda")
     check(lib_.mllm_hip_q4k_prepack(vp(Wd), C.c_int(N), C.c_int(Kw), vp(wp), _stream()), "q4k_prepack")
     if mode == "quant":
