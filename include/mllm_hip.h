@@ -163,6 +163,10 @@ int mllm_hip_rope_table_hf(float base, int dim, int n_pos, float *sin_host, floa
  * Llama-3.x family; the rotate itself is the same mllm_hip_rope_apply.  Tables `[n_pos][dim]`, both halves filled. */
 int mllm_hip_rope_table_hf_llama3(float base, int dim, int n_pos, float factor, float low_freq_factor, float high_freq_factor, float original_max_pos,
                                   float *sin_host, float *cos_host);
+/* NTKROPE (MiniCPM3 / Phi-3 LongRoPE; Layer.hpp:1171-1198 -> CPUNTKRoPE.cpp:27-80): tables `[n_pos][dim]` for n_pos = max_position_embeddings
+ * positions; `long_factor` / `short_factor` hold dim / 2 divisors (the long ones apply iff n_pos > original_max_pos); the rotate is mllm_hip_rope_apply. */
+int mllm_hip_rope_table_ntk(float theta, int dim, int n_pos, int original_max_pos, const float *long_factor, const float *short_factor,
+                            float *sin_host, float *cos_host);
 int mllm_hip_mrope_table(float base, int dim, const float *pos3xS_host, int S, const int *section, int n_section,
                          float *sin_host, float *cos_host);
 int mllm_hip_vision_rope_table(int t, int h, int w, int merge, int rot_dim, float *sin_host, float *cos_host);
@@ -315,6 +319,23 @@ int mllm_hip_qwen2vl_vision(mllm_hip_qwen2vl *m, const float *pixel_values_host,
 int64_t mllm_hip_qwen2vl_decode_weight_bytes(const mllm_hip_qwen2vl *m);
 void *mllm_hip_qwen2vl_stream(mllm_hip_qwen2vl *m);
 int mllm_hip_qwen2vl_time_gemv(mllm_hip_qwen2vl *m, int which, int iters, float *ms_per_launch, int64_t *bytes_per_launch);
+
+/* ---- the extra ops of the other model families (kernels_n4.hip).  Index tensors are fp32 on the device, as the reference's functions
+ * receive them (a Tensor of floats); every result is bit-identical to the reference's (tests/golden/n4_ops.npz). ------------------------------------------ */
+/* SLIDINGWINDOWMASK (Layer.hpp:478-488 -> CPUSlidingWindowMask.cpp:30-58): scores `[S][H][keys]`; key d of row s survives iff
+ * s - (window - 1) <= d <= s + (keys - S), everything else becomes std::numeric_limits<float>::lowest(); S == 1 passes through. */
+int mllm_hip_sliding_window_mask(const float *x, float *y, int S, int H, int keys, int window, void *stream);
+/* F_TOPK on DIMENSION (Tensor::topk, CPUTopkFunc.hpp:48-70; the MoE routers): per row the k largest (value, index) pairs in descending pair order -- among
+ * equal values the larger index first; `indices` are written as floats like the reference's second output. */
+int mllm_hip_topk_rows(const float *x, int64_t ldx, float *values, float *indices, int rows, int n, int k, void *stream);
+/* F_BINCOUNT (CPUBinCountFunc.hpp:20-35): counts of the integer parts 0 .. nbins-1 (the reference's output has max + 1 entries; pass the bins wanted) */
+int mllm_hip_bincount(const float *ids, int n, float *counts, int nbins, void *stream);
+/* Tensor::clip(index, SEQUENCE) (CPUClipFunc.hpp:309-323): out[r] = src[idx[r]]; with skip_negative = 1 and out = the word-embedding rows it is
+ * F_FUYU_GATHER_EMBD (CPUFuyuGatherEmbdFunc.hpp:45-62): rows whose index is negative keep their contents. */
+int mllm_hip_gather_rows(const float *src, int64_t lds, const float *idx, float *out, int64_t ldo, int R, int D, int skip_negative, void *stream);
+/* F_SCATTERADD on SEQUENCE (Tensor::scatter_add, CPUScatterAddFunc.hpp:38-52; the MoE combine): dst[idx[r]] += src[r] for r ascending -- a repeated
+ * destination row accumulates in that order. */
+int mllm_hip_scatter_add_rows(float *dst, int64_t ldd, const float *src, int64_t lds, const float *idx, int R, int D, void *stream);
 
 #ifdef __cplusplus
 }

@@ -308,6 +308,58 @@ private:
     bool mul_;
 };
 
+// ---- ops of the other model families -----------------------------------------------------------------------------------------------------------------
+// SLIDINGWINDOWMASK (op/CPUSlidingWindowMask.cpp:30-58) on BSHD scores [1][heads][S][keys]; batch 1 like the rest of the adapter
+class HIPSlidingWindowMaskOp final : public Op {
+public:
+    HIPSlidingWindowMaskOp(Backend *bn, const string &name, int window) : Op(bn, name), window_(window) {}
+    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+        outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+        if (inputs[0]->batch() != 1) throw std::runtime_error("HIPSlidingWindowMaskOp: batch 1 only");
+        HIPCHK(mllm_hip_sliding_window_mask((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), inputs[0]->sequence(), inputs[0]->head(), inputs[0]->dimension(), window_,
+                                            hb(backend_)->stream()));
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    int window_;
+};
+// F_TOPK on DIMENSION (op/CPUTopkFunc.hpp:27-70): outputs[0] = values, outputs[1] = indices (floats), [1][1][S][k]
+class HIPTopkOp final : public Op {
+public:
+    HIPTopkOp(Backend *bn, const string &name, int k) : Op(bn, name), k_(k) {}
+    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+        for (int o = 0; o < 2; ++o) {
+            outputs[o]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), k_);
+            outputs[o]->setDtype(inputs[0]->dtype());
+        }
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+        const int rows = inputs[0]->batch() * inputs[0]->head() * inputs[0]->sequence(), n = inputs[0]->dimension();
+        HIPCHK(mllm_hip_topk_rows((const float *)dptr(inputs[0]), n, (float *)dptr(outputs[0]), (float *)dptr(outputs[1]), rows, n, k_, hb(backend_)->stream()));
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    int k_;
+};
+// F_SCATTERADD on SEQUENCE (op/CPUScatterAddFunc.hpp:27-60): inputs = (dest [1][1][S][D], src [1][1][R][D], indices [1][1][1][R]); dest is updated in place, no outputs
+class HIPScatterAddOp final : public Op {
+public:
+    HIPScatterAddOp(Backend *bn, const string &name) : Op(bn, name) {}
+    ErrorCode reshape(vector<shared_ptr<Tensor>>, vector<shared_ptr<Tensor>>) override { return MLLM_NO_ERROR; }
+    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>>) override {
+        if (inputs[1]->batch() == 0) return MLLM_NO_ERROR;
+        const int D = inputs[0]->dimension();
+        HIPCHK(mllm_hip_scatter_add_rows((float *)dptr(inputs[0]), D, (const float *)dptr(inputs[1]), D, (const float *)dptr(inputs[2]), inputs[2]->dimension(), D, hb(backend_)->stream()));
+        return MLLM_NO_ERROR;
+    }
+};
+
 // ---- SOFTMAX: CPUSoftMax (op/CPUSoftMax.cpp:28-65; axis, do_causal_mask); DIMENSION axis only (the eager-attention form) -----------------------------------------
 class HIPSoftMaxOp final : public Op {
 public:
@@ -468,6 +520,13 @@ void HIPBackend::registerOps() {
     creators_[CONVOLUTION2D] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
         if (geti(p, "kernal_h") != geti(p, "stride_h") || geti(p, "kernal_w") != geti(p, "stride_w") || geti(p, "kernal_h") != geti(p, "kernal_w") || geti(p, "padding") != (int)VALID) return nullptr;
         return new HIPPatchConvOp(b, n, false, geti(p, "in_channel"), geti(p, "out_channel"), 1, geti(p, "kernal_h"), geti(p, "kernal_w"), geti(p, "bias") != 0);
+    };
+    creators_[SLIDINGWINDOWMASK] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return new HIPSlidingWindowMaskOp(b, n, geti(p, "window_size")); };
+    creators_[F_TOPK] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        return (Chl)geti(p, "dim") == DIMENSION ? new HIPTopkOp(b, n, geti(p, "k")) : nullptr;      // the HEAD-axis form stays on the CPU
+    };
+    creators_[F_SCATTERRADD] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        return p.count("dim") && (Chl)geti(p, "dim") != SEQUENCE ? nullptr : new HIPScatterAddOp(b, n);
     };
     creators_[F_CLIP] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
         // SEQUENCE-only clips; anything touching batch / head / dimension goes to the CPU

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libmllm_hip.so")
 HEADER = os.path.join(HERE, "..", "include", "mllm_hip.h")
 
-OK = 0
+OK, ERR_HIP, ERR_SHAPE, ERR_DTYPE, ERR_IO, ERR_ARG = 0, -1, -2, -3, -4, -5          # MLLM_HIP_* of include/mllm_hip.h
 F32, F16, Q4_0, Q8_0, Q4_K, Q8_K = 0, 1, 2, 8, 12, 15
 
 
@@ -124,6 +124,17 @@ def rope_table_hf_llama3(base, dim, n_pos, factor, low_freq_factor, high_freq_fa
     c = np.empty((n_pos, dim), dtype=np.float32)
     check(load().mllm_hip_rope_table_hf_llama3(C.c_float(base), C.c_int(dim), C.c_int(n_pos), C.c_float(factor), C.c_float(low_freq_factor), C.c_float(high_freq_factor),
                                                C.c_float(original_max_pos), vp(s), vp(c)), "rope_table_hf_llama3")
+    return s, c
+
+
+def rope_table_ntk(theta, dim, n_pos, original_max_pos, long_factor, short_factor):
+    """NTKROPE tables (CPUNTKRoPE.cpp:27-80), [n_pos][dim]; rotate with ops.rope_apply."""
+    s = np.empty((n_pos, dim), dtype=np.float32)
+    c = np.empty((n_pos, dim), dtype=np.float32)
+    lf, sf = np.ascontiguousarray(long_factor, dtype=np.float32), np.ascontiguousarray(short_factor, dtype=np.float32)
+    if lf.size != dim // 2 or sf.size != dim // 2:
+        raise ValueError("long_factor / short_factor must hold dim / 2 values")
+    check(load().mllm_hip_rope_table_ntk(C.c_float(theta), C.c_int(dim), C.c_int(n_pos), C.c_int(original_max_pos), vp(lf), vp(sf), vp(s), vp(c)), "rope_table_ntk")
     return s, c
 
 

@@ -305,3 +305,50 @@ def topk_probs(top_val, temperature):
     p = np.empty_like(v)
     check(L.load().mllm_hip_topk_probs_host(vp(v), C.c_int(v.size), C.c_float(temperature), vp(p)), "topk_probs_host")
     return p
+
+
+# ---- the extra ops of the other model families (csrc/kernels_n4.hip); index tensors are fp32 like the reference's ------------------------------
+def sliding_window_mask(x, H, keys, window):
+    x = _dev(x, torch.float32)
+    S = x.numel() // (H * keys)
+    y = torch.empty_like(x)
+    check(L.load().mllm_hip_sliding_window_mask(vp(x), vp(y), C.c_int(S), C.c_int(H), C.c_int(keys), C.c_int(window), _stream()), "sliding_window_mask")
+    return y
+
+
+def topk_rows(x, k):
+    x = _dev(x, torch.float32)
+    rows, n = x.shape
+    v = torch.empty((rows, k), dtype=torch.float32, device="cuda")
+    i = torch.empty((rows, k), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_topk_rows(vp(x), i64(n), vp(v), vp(i), C.c_int(rows), C.c_int(n), C.c_int(k), _stream()), "topk_rows")
+    return v, i
+
+
+def bincount(ids, nbins):
+    ids = _dev(ids, torch.float32)
+    out = torch.empty(nbins, dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_bincount(vp(ids), C.c_int(ids.numel()), vp(out), C.c_int(nbins), _stream()), "bincount")
+    return out
+
+
+def gather_rows(src, idx):
+    src, idx = _dev(src, torch.float32), _dev(idx, torch.float32)
+    D = src.shape[-1]
+    out = torch.empty((idx.numel(), D), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_gather_rows(vp(src), i64(D), vp(idx), vp(out), i64(D), C.c_int(idx.numel()), C.c_int(D), C.c_int(0), _stream()), "gather_rows")
+    return out
+
+
+def fuyu_gather(word, patches, idx):
+    word, patches, idx = _dev(word, torch.float32).clone(), _dev(patches, torch.float32), _dev(idx, torch.float32)
+    D = word.shape[-1]
+    check(L.load().mllm_hip_gather_rows(vp(patches), i64(D), vp(idx), vp(word), i64(D), C.c_int(idx.numel()), C.c_int(D), C.c_int(1), _stream()), "fuyu_gather")
+    return word
+
+
+def scatter_add_rows(dst, src, idx):
+    dst, src, idx = _dev(dst, torch.float32).clone(), _dev(src, torch.float32), _dev(idx, torch.float32)
+    D = dst.shape[-1]
+    check(L.load().mllm_hip_scatter_add_rows(vp(dst), i64(D), vp(src), i64(D), vp(idx), C.c_int(idx.numel()), C.c_int(D), _stream()), "scatter_add_rows")
+    return dst

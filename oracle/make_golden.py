@@ -421,7 +421,63 @@ def configs_full():
     print("configs_full.npz", tok.tolist(), timing, v_timing)
 
 
+def n4_golden():
+    """the extra ops of the other model families, each run by the reference itself (oracle/ref_drivers/ref_ops.cpp cases swmask, ntkrope, topk, bincount,
+    scatter_add, gather_rows, fuyu_gather) on small seeded inputs that exercise their edge cases: window edges on both sides with old keys in the cache, tied scores in
+    the top-k, a repeated destination row in scatter_add, negative (= keep the word embedding) indices in the Fuyu gather, a decode step after the prefill for the rotary op."""
+    r = np.random.default_rng(41)
+    pn = quantize_file([("dummy.weight", np.zeros(32, dtype=np.float32))], target="F32")
+    G = {}
+    # sliding window: 2 heads, 6 new rows over 10 keys (4 old), window 3
+    H, S, KEYS, WIN = 2, 6, 10, 3
+    x = r.standard_normal((S, H * KEYS), dtype=np.float32)
+    (y,), _ = run_ops("swmask", pn, [[(x, (1, 1, S, H * KEYS))]], p=(WIN, H, KEYS))
+    G["swmask_x"], G["swmask_y"], G["swmask_p"] = x, y.reshape(S, H * KEYS), np.array([WIN, H, KEYS])
+    # top-k over 16 experts, k = 4, with ties (rows 1 and 3 hold repeated values, row 4 is constant)
+    E, K = 16, 4
+    sc = r.random((5, E), dtype=np.float32)
+    sc[1, [2, 9, 11]] = sc[1].max() + 0.25
+    sc[3, [0, 15]] = 0.5; sc[3, [5, 6]] = 0.75
+    sc[4, :] = 0.125
+    (tv,), _ = run_ops("topk", pn, [[(sc, (1, 1, 5, E))]], p=(K, 0))
+    (ti,), _ = run_ops("topk", pn, [[(sc, (1, 1, 5, E))]], p=(K, 1))
+    G["topk_x"], G["topk_v"], G["topk_i"] = sc, tv.reshape(5, K), ti.reshape(5, K)
+    # bincount of expert ids
+    ids = np.array([3, 0, 3, 7, 1, 1, 3], dtype=np.float32)
+    (bc,), _ = run_ops("bincount", pn, [[(ids, (1, 1, 1, ids.size))]])
+    G["bincount_x"], G["bincount_y"] = ids, bc
+    # NTK / LongRoPE rotary (MiniCPM3): theta 10000, 64 positions, original 32 (the table is built for 64 > 32 positions: the long factors), 2 heads x 8 dims
+    D, HEADS = 8, 2
+    lf = [1.5, 2.25, 3.0, 4.5]; sf = [1.0, 1.0625, 1.125, 1.25]
+    q0 = r.standard_normal((6, HEADS * D), dtype=np.float32); q1 = r.standard_normal((1, HEADS * D), dtype=np.float32)
+    params = (10000.0, 64, 32, HEADS, D) + tuple(lf) + tuple(sf)
+    (y0, y1), _ = run_ops("ntkrope", pn, [[(q0, (1, 1, 6, HEADS * D))], [(q1, (1, 1, 1, HEADS * D))]], p=params)
+    G["ntk_x0"], G["ntk_y0"], G["ntk_x1"], G["ntk_y1"], G["ntk_p"] = q0, y0.reshape(6, -1), q1, y1.reshape(1, -1), np.array(params, dtype=np.float64)
+    # and with 24 positions < original 32: the short factors
+    params_s = (10000.0, 24, 32, HEADS, D) + tuple(lf) + tuple(sf)
+    (y2,), _ = run_ops("ntkrope", pn, [[(q0, (1, 1, 6, HEADS * D))]], p=params_s)
+    G["ntk_y_short"], G["ntk_p_short"] = y2.reshape(6, -1), np.array(params_s, dtype=np.float64)
+    # scatter_add with a repeated destination row; gather rows; Fuyu gather
+    dst = r.standard_normal((6, 8), dtype=np.float32); src = r.standard_normal((4, 8), dtype=np.float32)
+    idx = np.array([2, 5, 2, 0], dtype=np.float32)
+    (sa,), _ = run_ops("scatter_add", pn, [[(dst, (1, 1, 6, 8)), (src, (1, 1, 4, 8)), (idx, (1, 1, 1, 4))]])
+    G["sa_dst"], G["sa_src"], G["sa_idx"], G["sa_y"] = dst, src, idx, sa.reshape(6, 8)
+    gi = np.array([3, 0, 3], dtype=np.float32)
+    (gr,), _ = run_ops("gather_rows", pn, [[(dst, (1, 1, 6, 8)), (gi, (1, 1, 1, 3))]])
+    G["gr_idx"], G["gr_y"] = gi, gr.reshape(3, 8)
+    patches = r.standard_normal((3, 8), dtype=np.float32)
+    fi = np.array([-1, 0, -1, 2, 1, -1], dtype=np.float32)
+    (fg,), _ = run_ops("fuyu_gather", pn, [[(dst, (1, 1, 6, 8)), (patches, (1, 1, 3, 8)), (fi, (1, 1, 6, 1))]])
+    G["fuyu_patches"], G["fuyu_idx"], G["fuyu_y"] = patches, fi, fg.reshape(6, 8)
+    np.savez_compressed(os.path.join(GOLD, "n4_ops.npz"), **G)
+    for k in ("topk_v", "topk_i", "bincount_y", "gr_y"):
+        print(k, G[k].tolist() if G[k].size < 40 else G[k].shape)
+
+
 if __name__ == "__main__":
+    if "--n4" in sys.argv:
+        n4_golden()
+        sys.exit(0)
     if "--llava" in sys.argv:
         llava_tiny()
         sys.exit(0)

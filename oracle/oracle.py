@@ -168,6 +168,73 @@ def rope_table_hf_llama3(base, dim, n_pos, factor, low_freq_factor, high_freq_fa
     return s, c
 
 
+def rope_table_ntk(theta, dim, n_pos, original_max_pos, long_factor, short_factor):
+    """CPUNTKRoPE.cpp:27-80; tables [n_pos][dim]."""
+    s = np.empty((n_pos, dim), dtype=np.float32)
+    c = np.empty((n_pos, dim), dtype=np.float32)
+    lf, sf = _f32(long_factor), _f32(short_factor)
+    lib().orc_rope_table_ntk(C.c_float(theta), C.c_int(dim), C.c_int(n_pos), C.c_int(original_max_pos), _p(lf), _p(sf), _p(s), _p(c))
+    return s, c
+
+
+# ---- SURVEY N4: the small ops of the other model families, restated in numpy (each pinned by tests/golden/n4_ops.npz) -------------------------------
+def sliding_window_mask(x, H, keys, window):
+    """CPUSlidingWindowMask.cpp:30-58 on scores [S][H][keys]: key d of row s is kept iff s - (window - 1) <= d <= s + (keys - S); S == 1 passes through."""
+    x = _f32(x).reshape(-1, H, keys)
+    S = x.shape[0]
+    if S == 1:
+        return x.reshape(S, H * keys).copy()
+    old = keys - S
+    s = np.arange(S)[:, None, None]
+    d = np.arange(keys)[None, None, :]
+    out = np.where((d > s + old) | (d < s - (window - 1)), np.float32(np.finfo(np.float32).min), x)
+    return out.reshape(S, H * keys).astype(np.float32)
+
+
+def topk_rows(x, k):
+    """CPUTopkFunc.hpp:48-70: a min-heap of (value, index) pairs keeps the k largest pairs; output descending by (value, index) -- among equal values the LARGER index first.
+    Returns (values, indices as float)."""
+    x = _f32(x)
+    R, n = x.shape
+    v = np.empty((R, k), dtype=np.float32)
+    ix = np.empty((R, k), dtype=np.float32)
+    for r in range(R):
+        order = sorted(range(n), key=lambda j: (x[r, j], j), reverse=True)[:k]
+        v[r] = x[r, order]
+        ix[r] = order
+    return v, ix
+
+
+def bincount(ids):
+    """CPUBinCountFunc.hpp:20-35: counts of the non-negative integer parts, length max + 1."""
+    ii = _f32(ids).astype(np.int64)
+    return np.bincount(ii[ii >= 0], minlength=int(ii.max()) + 1 if ii.size else 0).astype(np.float32)
+
+
+def scatter_add_rows(dst, src, idx):
+    """CPUScatterAddFunc.hpp:38-52: dst[idx[r]] += src[r], r ascending (a repeated destination row accumulates in that order)."""
+    out = _f32(dst).copy()
+    src = _f32(src)
+    for r, i in enumerate(_f32(idx).astype(np.int64)):
+        out[i] = out[i] + src[r]
+    return out
+
+
+def gather_rows(src, idx):
+    """Tensor::clip(index, SEQUENCE) (CPUClipFunc.hpp:309-323): out[r] = src[idx[r]]."""
+    return _f32(src)[_f32(idx).astype(np.int64)].copy()
+
+
+def fuyu_gather(word, patches, idx):
+    """CPUFuyuGatherEmbdFunc.hpp:45-62: word[s] = patches[idx[s]] where idx[s] >= 0."""
+    out = _f32(word).copy()
+    patches = _f32(patches)
+    for s, i in enumerate(_f32(idx).astype(np.int64)):
+        if i >= 0:
+            out[s] = patches[i]
+    return out
+
+
 def mrope_table(base, dim, pos, section=(16, 24, 24)):
     pos = _f32(pos)  # [3, S]
     S = pos.shape[1]

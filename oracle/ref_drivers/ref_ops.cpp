@@ -68,6 +68,15 @@ public:
             l0 = RoPE((int)p(0), cfg, "rope");
         }
         else if (k == "fa2") {}
+        // ---- N4: ops of the other model families
+        else if (k == "swmask") l0 = SlidingWindowMask((int)p(0), "mask");                       // p: window, heads, keys
+        else if (k == "ntkrope") {                                                                // p: theta, max_pos, original max_pos, heads, D, then D/2 long and D/2 short factors
+            const int half = (int)p(4) / 2;
+            std::vector<float> lf, sf;
+            for (int i = 0; i < half; ++i) { lf.push_back(p(5 + i)); sf.push_back(p(5 + half + i)); }
+            l0 = NTKRoPE(HFHUBROPE, p(0), (int)p(1), (int)p(2), lf, sf, "rope");
+        }
+        else if (k == "topk" || k == "scatter_add" || k == "fuyu_gather" || k == "gather_rows" || k == "argsort" || k == "bincount") {}
         else { fprintf(stderr, "unknown case %s\n", k.c_str()); exit(2); }
     }
     vector<Tensor> Forward(vector<Tensor> in, vector<std::any> args) override {
@@ -93,6 +102,29 @@ public:
             q = r(q);
             return {q.view(-1, 1, -1, (int)(p(3) * p(4)))};
         }
+        if (kind == "swmask") {      // scores [1, H, S, keys] (CPUSlidingWindowMask.cpp:30-58)
+            auto x = in[0].view(-1, (int)p(1), -1, (int)p(2));
+            return {l0(x).view(-1, 1, -1, (int)(p(1) * p(2)))};
+        }
+        if (kind == "ntkrope") {     // CPUNTKRoPE.cpp:27-80 table, :81-190 rotation
+            auto q = in[0].view(-1, (int)p(3), -1, (int)p(4));
+            NTKRoPE &r = (NTKRoPE &)l0;
+            q = r(q);
+            return {q.view(-1, 1, -1, (int)(p(3) * p(4)))};
+        }
+        if (kind == "topk") {        // CPUTopkFunc.hpp:48-70; p: k, which output (0 values, 1 indices)
+            auto r = Tensor::topk(in[0], (int)p(0), DIMENSION);
+            return {r[(int)p(1)]};
+        }
+        if (kind == "argsort") return {in[0].argsort()};      // CPUArgSortFunc.hpp
+        if (kind == "bincount") return {in[0].bincount()};
+        if (kind == "scatter_add") { // CPUScatterAddFunc.hpp:27-60: dest [1,1,S,D] += src [1,1,R,D] at rows idx [1,1,1,R], in order
+            auto dst = in[0];
+            dst.scatter_add(in[1], in[2]);
+            return {dst};
+        }
+        if (kind == "gather_rows") return {in[0].clip(in[1], SEQUENCE)};       // Tensor.cpp:580 -> CPUClipTensorFunc
+        if (kind == "fuyu_gather") return {Tensor::fuyu_gather_embd(in[0], in[1], in[2])};   // CPUFuyuGatherEmbdFunc.hpp:45-62
         if (kind == "fa2") {
             // in: q [1,1,Sq,Hq*D], k,v [1,1,Sk,Hkv*D] all fp32 (the vision / fp32-KV path, FlashAttention2.hpp:87)
             auto q = in[0].view(-1, (int)p(0), -1, (int)p(2));

@@ -405,6 +405,25 @@ void orc_rope_table_hf_llama3(float base, int dim, int n_pos, float factor, floa
         }
     }
 }
+/* NTKRoPE of the MiniCPM3 / Phi-3 family (CPUNTKRoPE.cpp:27-80, get_sin_cos_emb_hf): the table is built for n_pos = max_position_embeddings positions;
+ * the per-frequency divisors are the long factors when n_pos > original_max_pos, else the short ones; inv_freq[i] = 1 / powf(theta, i / dim) (the reference divides by
+ * dim, not dim / 2 -- kept); angle = (s * (1 / ext[i])) * inv_freq[i] in float; sin / cos scaled by (float)sqrt(1 + logf(n_pos / orig) / log((double)orig)).
+ * Pinned by tests/golden/n4_ops.npz (ntk_*). */
+void orc_rope_table_ntk(float theta, int dim, int n_pos, int original_max_pos, const float *long_factor, const float *short_factor, float *sin_t, float *cos_t) {
+    int half = dim / 2;
+    float scale = (float)n_pos / (float)original_max_pos;
+    float scaling = (float)sqrt(1 + logf(scale) / log((double)original_max_pos));
+    const float *ext = n_pos > original_max_pos ? long_factor : short_factor;
+    for (int i = 0; i < half; ++i) {
+        float inv = 1.f / powf(theta, (float)i / (float)dim);
+        float rcp = 1.0f / ext[i];
+        for (int s = 0; s < n_pos; ++s) {
+            float f = ((float)s * rcp) * inv;
+            sin_t[(size_t)s * dim + i] = sin_t[(size_t)s * dim + i + half] = sinf(f) * scaling;
+            cos_t[(size_t)s * dim + i] = cos_t[(size_t)s * dim + i + half] = cosf(f) * scaling;
+        }
+    }
+}
 /* CPUMultimodalRoPE.cpp:26-36 (theta), :84-118 (per-axis tables), :37-82 (mrope_section stitch). pos is [3][S] (t,h,w rows);
  * sin/cos out are [S][dim/2]: column c takes axis j where c falls in section j. */
 void orc_mrope_table(float base, int dim, const float *pos, int S, const int *section, int n_section, float *sin_t, float *cos_t) {

@@ -1,0 +1,129 @@
+"""the extra ops of the other model families (sliding-window mask, NTK / LongRoPE rotary, MoE top-k / bincount / gather / scatter-add, Fuyu gather).
+
+tests/golden/n4_ops.npz holds the REFERENCE's own outputs for each op (oracle/make_golden.py --n4 drives oracle/_ref/ref_ops, which calls the reference's Layer / Tensor
+API); the numpy / C restatements in oracle/ are pinned against it here on the CPU, and the HIP kernels against both on the GPU -- bit equality everywhere."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "n4_ops.npz"))
+
+
+def eq(a, b):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+    return np.array_equal(a.reshape(-1).view(np.uint32) if a.dtype == np.float32 else a.reshape(-1), np.asarray(b, dtype=a.dtype).reshape(-1).view(np.uint32) if a.dtype == np.float32 else np.asarray(b).reshape(-1))
+
+
+def _ntk(pp):
+    theta, maxp, orig, heads, D = pp[0], int(pp[1]), int(pp[2]), int(pp[3]), int(pp[4])
+    return theta, maxp, orig, heads, D, pp[5:5 + D // 2], pp[5 + D // 2:5 + D]
+
+
+# ---- CPU: the restatements against the reference's outputs ----------------------------------------------------------------------------------------------
+def test_oracle_sliding_window_mask_matches_reference():
+    W, H, K = (int(v) for v in G["swmask_p"])
+    assert eq(orc.sliding_window_mask(G["swmask_x"], H, K, W), G["swmask_y"])
+    one = G["swmask_x"][:1]
+    assert eq(orc.sliding_window_mask(one, H, K, W), one)          # a decode row passes through (CPUSlidingWindowMask.cpp:55-57)
+
+
+def test_oracle_topk_ties_and_bincount_match_reference():
+    v, i = orc.topk_rows(G["topk_x"], G["topk_v"].shape[1])
+    assert eq(v, G["topk_v"]) and eq(i, G["topk_i"])
+    assert G["topk_i"][4].tolist() == [15.0, 14.0, 13.0, 12.0]      # equal values: the larger index first
+    assert eq(orc.bincount(G["bincount_x"]), G["bincount_y"])
+
+
+def test_oracle_gather_scatter_match_reference():
+    assert eq(orc.scatter_add_rows(G["sa_dst"], G["sa_src"], G["sa_idx"]), G["sa_y"])        # row 2 is hit twice, in order
+    assert eq(orc.gather_rows(G["sa_dst"], G["gr_idx"]), G["gr_y"])
+    assert eq(orc.fuyu_gather(G["sa_dst"], G["fuyu_patches"], G["fuyu_idx"]), G["fuyu_y"])
+
+
+def test_oracle_ntk_rope_matches_reference_long_short_and_decode_step():
+    theta, maxp, orig, heads, D, lf, sf = _ntk(G["ntk_p"])
+    s, c = orc.rope_table_ntk(theta, D, maxp, orig, lf, sf)
+    assert eq(orc.rope_apply(G["ntk_x0"], 6, heads, D, s[:6], c[:6]), G["ntk_y0"])
+    assert eq(orc.rope_apply(G["ntk_x1"], 1, heads, D, s[6:7], c[6:7]), G["ntk_y1"])       # the op's position counter moved on by the prefill length
+    theta, maxp, orig, heads, D, lf, sf = _ntk(G["ntk_p_short"])
+    s, c = orc.rope_table_ntk(theta, D, maxp, orig, lf, sf)
+    assert maxp < orig                                                                     # the short factors
+    assert eq(orc.rope_apply(G["ntk_x0"], 6, heads, D, s[:6], c[:6]), G["ntk_y_short"])
+
+
+def test_product_ntk_table_is_host_code_and_matches_the_oracle():
+    from mllm_amd import lib
+    for key in ("ntk_p", "ntk_p_short"):
+        theta, maxp, orig, heads, D, lf, sf = _ntk(G[key])
+        s, c = lib.rope_table_ntk(theta, D, maxp, orig, lf, sf)
+        so, co = orc.rope_table_ntk(theta, D, maxp, orig, lf, sf)
+        assert eq(s, so) and eq(c, co)
+    L = lib.load()
+    buf = np.zeros(64, dtype=np.float32)
+    p = buf.ctypes.data_as(C.c_void_p)
+    assert L.mllm_hip_rope_table_ntk(C.c_float(1e4), C.c_int(7), C.c_int(4), C.c_int(32), p, p, p, p) == lib.ERR_ARG      # odd dim
+    assert L.mllm_hip_rope_table_ntk(C.c_float(1e4), C.c_int(8), C.c_int(4), C.c_int(32), None, p, p, p) == lib.ERR_ARG
+
+
+def test_n4_entry_points_validate_before_any_launch():
+    from mllm_amd import lib
+    L = lib.load()
+    assert L.mllm_hip_sliding_window_mask(None, None, C.c_int(4), C.c_int(2), C.c_int(3), C.c_int(2), None) == lib.ERR_SHAPE      # fewer keys than rows
+    assert L.mllm_hip_sliding_window_mask(None, None, C.c_int(0), C.c_int(2), C.c_int(3), C.c_int(2), None) == lib.OK
+    assert L.mllm_hip_topk_rows(None, C.c_int64(8), None, None, C.c_int(2), C.c_int(8), C.c_int(9), None) == lib.ERR_SHAPE           # k > n
+    assert L.mllm_hip_topk_rows(None, C.c_int64(8), None, None, C.c_int(2), C.c_int(8), C.c_int(2), None) == lib.ERR_ARG
+    assert L.mllm_hip_bincount(None, C.c_int(0), None, C.c_int(4), None) == lib.ERR_ARG
+    assert L.mllm_hip_gather_rows(None, C.c_int64(8), None, None, C.c_int64(8), C.c_int(0), C.c_int(8), C.c_int(0), None) == lib.OK
+    assert L.mllm_hip_scatter_add_rows(None, C.c_int64(8), None, C.c_int64(8), None, C.c_int(3), C.c_int(8), None) == lib.ERR_ARG
+
+
+# ---- GPU: the kernels against the reference's outputs and, at larger sizes, against the restatement ---------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_n4_ops_match_the_reference_outputs():
+    from mllm_amd import lib, ops
+    ops.require_gpu()
+    W, H, K = (int(v) for v in G["swmask_p"])
+    assert eq(ops.sliding_window_mask(G["swmask_x"], H, K, W), G["swmask_y"])
+    assert eq(ops.sliding_window_mask(G["swmask_x"][:1], H, K, W), G["swmask_x"][:1])
+    v, i = ops.topk_rows(G["topk_x"], G["topk_v"].shape[1])
+    assert eq(v, G["topk_v"]) and eq(i, G["topk_i"])
+    assert eq(ops.bincount(G["bincount_x"], G["bincount_y"].size), G["bincount_y"])
+    assert eq(ops.scatter_add_rows(G["sa_dst"], G["sa_src"], G["sa_idx"]), G["sa_y"])
+    assert eq(ops.gather_rows(G["sa_dst"], G["gr_idx"]), G["gr_y"])
+    assert eq(ops.fuyu_gather(G["sa_dst"], G["fuyu_patches"], G["fuyu_idx"]), G["fuyu_y"])
+    theta, maxp, orig, heads, D, lf, sf = _ntk(G["ntk_p"])
+    s, c = lib.rope_table_ntk(theta, D, maxp, orig, lf, sf)
+    assert eq(ops.rope_apply(G["ntk_x0"], 6, heads, D, s[:6], c[:6]), G["ntk_y0"])
+    assert eq(ops.rope_apply(G["ntk_x1"], 1, heads, D, s[6:7], c[6:7]), G["ntk_y1"])
+
+
+@pytest.mark.gpu
+def test_hip_n4_ops_at_model_sizes_match_the_restatement():
+    from mllm_amd import ops
+    ops.require_gpu()
+    r = np.random.default_rng(5)
+    # Mistral-like window over a longer cache: 8 heads, 96 new rows on 160 keys, window 64
+    x = r.standard_normal((96, 8 * 160)).astype(np.float32)
+    assert eq(ops.sliding_window_mask(x, 8, 160, 64), orc.sliding_window_mask(x, 8, 160, 64))
+    # router: 300 tokens x 64 experts (quantised scores: many ties), k = 8; and a ragged n
+    sc = (r.integers(0, 12, size=(300, 64)) / 16.0).astype(np.float32)
+    v, i = ops.topk_rows(sc, 8)
+    vo, io = orc.topk_rows(sc, 8)
+    assert eq(v, vo) and eq(i, io)
+    sc = r.standard_normal((33, 100)).astype(np.float32)
+    v, i = ops.topk_rows(sc, 100)          # k = n: a full descending sort of every row
+    vo, io = orc.topk_rows(sc, 100)
+    assert eq(v, vo) and eq(i, io)
+    ids = io[:, :6].reshape(-1)
+    assert eq(ops.bincount(ids, 100), np.bincount(ids.astype(np.int64), minlength=100).astype(np.float32))
+    # MoE combine at hidden 2048: 500 expert rows into 128 token rows, every token hit several times
+    dst = r.standard_normal((128, 2048)).astype(np.float32); src = r.standard_normal((500, 2048)).astype(np.float32)
+    idx = r.integers(0, 128, size=500).astype(np.float32)
+    assert eq(ops.scatter_add_rows(dst, src, idx), orc.scatter_add_rows(dst, src, idx))
+    assert eq(ops.gather_rows(src, idx[:77]), orc.gather_rows(src, idx[:77]))
+    fi = np.where(r.random(128) < 0.4, r.integers(0, 500, size=128), -1).astype(np.float32)
+    assert eq(ops.fuyu_gather(dst, src, fi), orc.fuyu_gather(dst, src, fi))
