@@ -198,7 +198,7 @@ struct mllm_hip_model {
     void *xpack = nullptr;
     size_t xpack_bytes = 0;
     // vision activations (sized for max_patch tokens)
-    int max_patch = 0;
+    int max_patch = 0, vis_batch = 0;     // tokens per image and images per pass the vision buffers are sized for
     float *vx = nullptr, *vr = nullptr, *vqkv = nullptr, *vattn = nullptr, *vfc = nullptr, *vact = nullptr, *vpix[2] = {nullptr, nullptr}, *vpatch = nullptr, *vsin = nullptr,
           *vcos = nullptr, *vemb = nullptr, *vm0 = nullptr;
     hipEvent_t vup[2] = {nullptr, nullptr}, vfree[2] = {nullptr, nullptr};
@@ -664,37 +664,44 @@ extern "C" int mllm_hip_model_vision_shape(const mllm_hip_model *m, const int32_
 
 // VisionBlock (modeling_qwen2_vl.hpp:116-140) / ViTBlock (modeling_vit.hpp:31-61): LN -> qkv -> [2-D rotary] -> FlashAttention2 (non-causal, fp32 K/V)
 // -> proj + x -> LN -> fc1 -> act (fp16 LUT) -> fc2 + residual.  x in m->vx (N rows), result back in m->vx.
-static int vision_blocks(M *m, int N, float ln_eps, const uint16_t *lut, bool rope) {
+// NB images of N tokens each sit row after row in m->vx: everything row-wise (LayerNorm, quantiser, Linear, activation) runs ONCE over the NB * N rows -- a row's
+// result does not depend on how many rows share its launch, and the GEMMs of a small image (197 rows for ViT-B/16) otherwise leave most CUs idle -- while the
+// rotary and the attention, which see one image at a time, run per image.
+static int vision_blocks(M *m, int N, int NB, float ln_eps, const uint16_t *lut, bool rope) {
     const auto &c = m->c;
-    const int V = c.v_dim, VD = V / c.v_heads;
+    const int V = c.v_dim, VD = V / c.v_heads, R = N * NB;
     hipStream_t st = m->st;
     float *x = m->vx, *r = m->vr;
     for (auto &B : m->vblocks) {
         const int F = B.fc1.N;
-        EH(q_layernorm(m, x, B.n1w, B.n1b, m->vxq, N, V, ln_eps));
-        EH(lin(m, B.qkv, m->vxq, m->vqkv, MLLM_HIP_F32, 3 * V, nullptr, N));
-        // q and k are columns [0, 2V) of the same rows: one launch over 2 * heads heads rotates both in place
-        if (rope) EH(mllm_hip_rope_apply(m->vqkv, 3 * V, m->vsin, m->vcos, VD / 2, m->vqkv, MLLM_HIP_F32, 3 * V, N, 2 * c.v_heads, VD, st));
-        EH(mllm_hip_fa2(m->vqkv, 3 * V, m->vqkv + V, 3 * V, m->vqkv + 2 * V, 3 * V, MLLM_HIP_F32, m->vattn, V, N, N, c.v_heads, c.v_heads, VD, 0,
-                        nullptr, nullptr, st));
-        EH(q_quant(m, m->vattn, m->vxq, N, V));
-        EH(lin(m, B.proj, m->vxq, r, MLLM_HIP_F32, V, x, N));                       // residual = proj(attn) + x
-        EH(q_layernorm(m, r, B.n2w, B.n2b, m->vxq, N, V, ln_eps));
-        EH(lin(m, B.fc1, m->vxq, m->vfc, MLLM_HIP_F32, F, nullptr, N));
-        EH(q_act_quant(m, m->vfc, m->vact, lut, m->vxq2, N, F));
-        EH(lin(m, B.fc2, m->vxq2, x, MLLM_HIP_F32, V, r, N));                        // x = fc2(act) + residual
+        EH(q_layernorm(m, x, B.n1w, B.n1b, m->vxq, R, V, ln_eps));
+        EH(lin(m, B.qkv, m->vxq, m->vqkv, MLLM_HIP_F32, 3 * V, nullptr, R));
+        for (int b = 0; b < NB; ++b) {
+            float *qkv = m->vqkv + (size_t)b * N * 3 * V;
+            // q and k are columns [0, 2V) of the same rows: one launch over 2 * heads heads rotates both in place
+            if (rope) EH(mllm_hip_rope_apply(qkv, 3 * V, m->vsin, m->vcos, VD / 2, qkv, MLLM_HIP_F32, 3 * V, N, 2 * c.v_heads, VD, st));
+            EH(mllm_hip_fa2(qkv, 3 * V, qkv + V, 3 * V, qkv + 2 * V, 3 * V, MLLM_HIP_F32, m->vattn + (size_t)b * N * V, V, N, N, c.v_heads, c.v_heads, VD, 0, nullptr,
+                            nullptr, st));
+        }
+        EH(q_quant(m, m->vattn, m->vxq, R, V));
+        EH(lin(m, B.proj, m->vxq, r, MLLM_HIP_F32, V, x, R));                       // residual = proj(attn) + x
+        EH(q_layernorm(m, r, B.n2w, B.n2b, m->vxq, R, V, ln_eps));
+        EH(lin(m, B.fc1, m->vxq, m->vfc, MLLM_HIP_F32, F, nullptr, R));
+        EH(q_act_quant(m, m->vfc, m->vact, lut, m->vxq2, R, F));
+        EH(lin(m, B.fc2, m->vxq2, x, MLLM_HIP_F32, V, r, R));                        // x = fc2(act) + residual
     }
     return 0;
 }
 
-// One image already resident in `pix` (QWEN2VL: [N][PE] patches; CLIP / VIT: [H][C][W]); writes the tower's output rows to `out` (device)
-static int forward_vision(M *m, const float *pix, const int32_t *meta, float *out) {
+// NB images of the same geometry already resident one after the other in `pix` (QWEN2VL: [N][PE] patches each; CLIP / VIT: [H][C][W] each); writes the tower's output
+// rows, image after image, to `out` (device)
+static int forward_vision(M *m, const float *pix, const int32_t *meta, float *out, int NB = 1) {
     const auto &c = m->c;
     const int V = c.v_dim;
     hipStream_t st = m->st;
     if (m->vkind == V_QWEN2VL) {
         const int N = meta[0] * meta[1] * meta[2], PE = 3 * 2 * c.v_patch * c.v_patch;
-        const int VD = V / c.v_heads, MM = V * c.v_merge * c.v_merge, NT = N / (c.v_merge * c.v_merge);
+        const int VD = V / c.v_heads, MM = V * c.v_merge * c.v_merge, NT = NB * (N / (c.v_merge * c.v_merge)), R = NB * N;
         {   // rotary tables (CPUVisionRoPE): rot_dim = head_dim/2
             std::vector<float> s((size_t)N * (VD / 2)), co((size_t)N * (VD / 2));
             EH(mllm_hip_vision_rope_table(meta[0], meta[1], meta[2], c.v_merge, VD / 2, s.data(), co.data()));
@@ -702,10 +709,10 @@ static int forward_vision(M *m, const float *pix, const int32_t *meta, float *ou
             HH(hipMemcpyAsync(m->vcos, co.data(), co.size() * 4, hipMemcpyHostToDevice, st));
             HH(hipStreamSynchronize(st));
         }
-        EH(mllm_hip_patch_gemm_f32(pix, m->patch_w, nullptr, m->vx, N, PE, V, st));
-        EH(vision_blocks(m, N, 1e-6f, m->lut_qgelu, true));
+        EH(mllm_hip_patch_gemm_f32(pix, m->patch_w, nullptr, m->vx, R, PE, V, st));
+        EH(vision_blocks(m, N, NB, 1e-6f, m->lut_qgelu, true));
         // PatchMerger: ln_q -> view [NT][MM] -> mlp.0 -> GELU -> mlp.2
-        EH(mllm_hip_layernorm(m->vx, m->lnq_w, m->lnq_b, m->vr, nullptr, nullptr, nullptr, N, V, 1e-6f, st));
+        EH(mllm_hip_layernorm(m->vx, m->lnq_w, m->lnq_b, m->vr, nullptr, nullptr, nullptr, R, V, 1e-6f, st));
         EH(q_quant(m, m->vr, m->vxq2, NT, MM));
         EH(lin(m, m->m0, m->vxq2, m->vm0, MLLM_HIP_F32, MM, nullptr, NT));
         EH(q_act_quant(m, m->vm0, m->vfc, m->lut_gelu, m->vxq2, NT, MM));
@@ -714,39 +721,60 @@ static int forward_vision(M *m, const float *pix, const int32_t *meta, float *ou
     }
     // LLaVAVisionEmbedding (modeling_llava.hpp:39-60) / ViTEmbedding (modeling_vit.hpp:63-83): Conv2D patch embedding as im2patch + GEMM over the
     // receptive fields; row 0 = the class token; + position rows (an Embedding over 0..N-1 / a Parameter: both a plain row-wise add)
-    const int g = c.v_img / c.v_patch, NP = g * g, N = NP + 1, KK = 3 * c.v_patch * c.v_patch, F = c.v_ffn;
-    EH(mllm_hip_im2patch_hcw(pix, m->vpatch, c.v_img, 3, c.v_img, c.v_patch, st));
-    EH(mllm_hip_patch_gemm_f32(m->vpatch, m->patch_w, m->patch_b, m->vr + V, NP, KK, V, st));
-    HH(hipMemcpyAsync(m->vr, m->cls_tok, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
-    EH(mllm_hip_add(m->pos_emb, m->vr, m->vx, (int64_t)N * V, st));
+    const int g = c.v_img / c.v_patch, NP = g * g, N = NP + 1, KK = 3 * c.v_patch * c.v_patch, F = c.v_ffn, R = NB * N;
+    const size_t ie = (size_t)c.v_img * 3 * c.v_img;
+    for (int b = 0; b < NB; ++b) {
+        float *vp = m->vpatch + (size_t)b * NP * KK, *rows = m->vr + (size_t)b * N * V;
+        EH(mllm_hip_im2patch_hcw(pix + b * ie, vp, c.v_img, 3, c.v_img, c.v_patch, st));
+        EH(mllm_hip_patch_gemm_f32(vp, m->patch_w, m->patch_b, rows + V, NP, KK, V, st));
+        HH(hipMemcpyAsync(rows, m->cls_tok, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
+        EH(mllm_hip_add(m->pos_emb, rows, m->vx + (size_t)b * N * V, (int64_t)N * V, st));
+    }
     if (m->vkind == V_CLIP) {
-        EH(mllm_hip_layernorm(m->vx, m->pre_w, m->pre_b, m->vr, nullptr, nullptr, nullptr, N, V, 1e-6f, st));       // pre_layrnorm (:69)
-        HH(hipMemcpyAsync(m->vx, m->vr, (size_t)N * V * 4, hipMemcpyDeviceToDevice, st));
-        EH(vision_blocks(m, N, 1e-5f, m->lut_qgelu, false));
+        EH(mllm_hip_layernorm(m->vx, m->pre_w, m->pre_b, m->vr, nullptr, nullptr, nullptr, R, V, 1e-6f, st));       // pre_layrnorm (:69)
+        HH(hipMemcpyAsync(m->vx, m->vr, (size_t)R * V * 4, hipMemcpyDeviceToDevice, st));
+        EH(vision_blocks(m, N, NB, 1e-5f, m->lut_qgelu, false));
         // clip off the class row (:90), multi_modal_projector: linear_1 -> GELU -> linear_2
-        EH(q_quant(m, m->vx + V, m->vxq, NP, V));
-        EH(lin(m, m->m0, m->vxq, m->vfc, MLLM_HIP_F32, F, nullptr, NP));
-        EH(q_act_quant(m, m->vfc, m->vact, m->lut_gelu, m->vxq2, NP, F));
-        EH(lin(m, m->m2, m->vxq2, out, MLLM_HIP_F32, F, nullptr, NP));
+        const float *patches = m->vx + V;
+        if (NB > 1) {     // the patch rows of the images, packed together
+            for (int b = 0; b < NB; ++b)
+                HH(hipMemcpyAsync(m->vattn + (size_t)b * NP * V, m->vx + ((size_t)b * N + 1) * V, (size_t)NP * V * 4, hipMemcpyDeviceToDevice, st));
+            patches = m->vattn;
+        }
+        EH(q_quant(m, patches, m->vxq, NB * NP, V));
+        EH(lin(m, m->m0, m->vxq, m->vfc, MLLM_HIP_F32, F, nullptr, NB * NP));
+        EH(q_act_quant(m, m->vfc, m->vact, m->lut_gelu, m->vxq2, NB * NP, F));
+        EH(lin(m, m->m2, m->vxq2, out, MLLM_HIP_F32, F, nullptr, NB * NP));
         return 0;
     }
     // VIT: the class row alone goes on (clip({0}), modeling_vit.hpp:106): LayerNorm 1e-6, classifier without bias
-    EH(vision_blocks(m, N, 1e-5f, m->lut_gelu, false));
-    EH(mllm_hip_layernorm(m->vx, m->lnq_w, m->lnq_b, nullptr, m->vxq.qs, m->vxq.d, m->vxq.bs, 1, V, 1e-6f, st));
-    EH(lin(m, m->m0, m->vxq, out, MLLM_HIP_F32, c.v_classes, nullptr, 1));
+    EH(vision_blocks(m, N, NB, 1e-5f, m->lut_gelu, false));
+    const float *cls = m->vx;
+    if (NB > 1) {
+        for (int b = 0; b < NB; ++b) HH(hipMemcpyAsync(m->vattn + (size_t)b * V, m->vx + (size_t)b * N * V, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
+        cls = m->vattn;
+    }
+    EH(q_layernorm(m, cls, m->lnq_w, m->lnq_b, m->vxq, NB, V, 1e-6f));
+    EH(lin(m, m->m0, m->vxq, out, MLLM_HIP_F32, c.v_classes, nullptr, NB));
     return 0;
 }
 
-static int ensure_vision_buffers(M *m, const int32_t *meta) {
+static int ensure_vision_buffers(M *m, const int32_t *meta, int NB = 1) {
     const auto &c = m->c;
-    int N, orows, ocols; size_t img_elems;
-    vision_dims(m, meta, &N, &orows, &ocols, &img_elems);
-    if (N <= m->max_patch) return 0;
+    int N1, orows1, ocols; size_t img_elems1;
+    vision_dims(m, meta, &N1, &orows1, &ocols, &img_elems1);
+    if (N1 <= m->max_patch && NB <= m->vis_batch) return 0;
+    NB = std::max(NB, m->vis_batch);
+    const int Ntok = std::max(N1, m->max_patch);                               // tokens of the largest image so far
+    const int N = Ntok * NB;                                                   // rows of one pass
+    // (only the Qwen2-VL tower sees images of different sizes: its output rows and patch elements scale with the tokens)
+    const int orows = (m->vkind == V_QWEN2VL ? Ntok / (c.v_merge * c.v_merge) : orows1) * NB;
+    const size_t img_elems = (m->vkind == V_QWEN2VL ? (size_t)Ntok * 3 * 2 * c.v_patch * c.v_patch : img_elems1) * NB;
     // a larger image than any before: release the previous set (nothing of it is in flight after the sync) and size a new one
     HH(hipStreamSynchronize(m->st));
     for (void *p : m->vis_allocs) HH(hipFree(p));
     m->vis_allocs.clear();
-    m->max_patch = 0;
+    m->max_patch = 0; m->vis_batch = 0;
     auto *L = &m->vis_allocs;
     const int V = c.v_dim;
     const int F = m->vkind == V_QWEN2VL ? 4 * V : c.v_ffn, MM = m->vkind == V_QWEN2VL ? V * c.v_merge * c.v_merge : 0;
@@ -761,7 +789,7 @@ static int ensure_vision_buffers(M *m, const int32_t *meta) {
         EH(m->dalloc(&m->vsin, (size_t)N * (VD / 2) * 4, L)); EH(m->dalloc(&m->vcos, (size_t)N * (VD / 2) * 4, L));
         EH(m->dalloc(&m->vm0, (size_t)orows * MM * 4, L));
     } else {
-        EH(m->dalloc(&m->vpatch, (size_t)(N - 1) * 3 * c.v_patch * c.v_patch * 4, L));
+        EH(m->dalloc(&m->vpatch, (size_t)N * 3 * c.v_patch * c.v_patch * 4, L));
     }
     // Q8_K planes for fewer than 16 rows only (larger row counts go through the packed GEMM operand m->xpack); sized generously for N rows anyway
     EH(alloc_q8(m, &m->vxq, N, V, L)); EH(alloc_q8(m, &m->vxq2, N, Fw, L));
@@ -771,7 +799,7 @@ static int ensure_vision_buffers(M *m, const int32_t *meta) {
         HH(hipHostMalloc((void **)&m->pin_img, 2 * img_elems * 4, hipHostMallocDefault));
         m->pin_img_bytes = img_elems * 4;
     }
-    m->max_patch = N;
+    m->max_patch = Ntok; m->vis_batch = NB;
     return 0;
 }
 
@@ -1039,31 +1067,36 @@ extern "C" int mllm_hip_model_generate_sampled(mllm_hip_model *m, int32_t first_
     return 0;
 }
 
-// n_img images through the tower; the upload of image i+1 (pinned staging, copy on the load stream of the moment) runs while the tower works on image i
+// n_img images through the tower, NB at a time (one pass over NB * tokens rows); the upload of group g+1 (pinned staging, its own copy stream) runs while the tower works on group g
 extern "C" int mllm_hip_model_vision(mllm_hip_model *m, const float *images_host, const int32_t *image_meta, int n_img, float *out_dev, float *elapsed_ms) {
     if (!m || m->vkind == V_NONE || !images_host || !out_dev || n_img <= 0) return MLLM_HIP_ERR_ARG;
     if (m->vkind == V_QWEN2VL && !image_meta) return MLLM_HIP_ERR_ARG;
     int nt, orows, ocols; size_t ie;
     vision_dims(m, image_meta, &nt, &orows, &ocols, &ie);
-    EH(ensure_vision_buffers(m, image_meta));
+    // images per pass: about 4096 token rows (the row-wise kernels then fill the chip even for 197-token images), at most 16
+    int NB = std::max(1, std::min(std::min(16, 4096 / std::max(nt, 1)), n_img));
+    if (const char *e = getenv("MLLM_HIP_VISION_BATCH")) NB = std::max(1, std::min(atoi(e), n_img));
+    EH(ensure_vision_buffers(m, image_meta, NB));
+    const int ngroups = (n_img + NB - 1) / NB;
+    const size_t gstride = ie * (size_t)m->vis_batch;                  // the staging buffers hold vis_batch images each
     hipStream_t cp;
     HH(hipStreamCreateWithFlags(&cp, hipStreamNonBlocking));
-    auto upload = [&](int i) -> int {
-        const int b = i & 1;
-        float *pin = m->pin_img + (size_t)b * ie;
-        if (i >= 2) HH(hipEventSynchronize(m->vfree[b]));          // the tower has finished with image i-2, which sat in this device buffer
-        memcpy(pin, images_host + (size_t)i * ie, ie * 4);           // (its H2D copy was waited for by the compute stream before that)
-        HH(hipMemcpyAsync(m->vpix[b], pin, ie * 4, hipMemcpyHostToDevice, cp));
+    auto upload = [&](int gi) -> int {
+        const int b = gi & 1, cnt = std::min(NB, n_img - gi * NB);
+        float *pin = m->pin_img + (size_t)b * gstride;
+        if (gi >= 2) HH(hipEventSynchronize(m->vfree[b]));          // the tower has finished with group gi-2, which sat in this device buffer
+        memcpy(pin, images_host + (size_t)gi * NB * ie, ie * 4 * cnt);   // (its H2D copy was waited for by the compute stream before that)
+        HH(hipMemcpyAsync(m->vpix[b], pin, ie * 4 * cnt, hipMemcpyHostToDevice, cp));
         HH(hipEventRecord(m->vup[b], cp));
         return 0;
     };
     int rc = upload(0);
     if (!rc) { hipError_t e = hipEventRecord(m->ev0, m->st); if (e != hipSuccess) rc = MLLM_HIP_ERR_HIP; }
-    for (int i = 0; i < n_img && !rc; ++i) {
-        const int b = i & 1;
+    for (int gi = 0; gi < ngroups && !rc; ++gi) {
+        const int b = gi & 1, cnt = std::min(NB, n_img - gi * NB);
         if (hipStreamWaitEvent(m->st, m->vup[b], 0) != hipSuccess) { rc = MLLM_HIP_ERR_HIP; break; }
-        if (i + 1 < n_img) rc = upload(i + 1);
-        if (!rc) rc = forward_vision(m, m->vpix[b], image_meta, out_dev + (size_t)i * orows * ocols);
+        if (gi + 1 < ngroups) rc = upload(gi + 1);
+        if (!rc) rc = forward_vision(m, m->vpix[b], image_meta, out_dev + (size_t)gi * NB * orows * ocols, cnt);
         if (!rc && hipEventRecord(m->vfree[b], m->st) != hipSuccess) rc = MLLM_HIP_ERR_HIP;
     }
     if (!rc) {

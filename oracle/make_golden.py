@@ -421,6 +421,16 @@ def configs_full():
     print("configs_full.npz", tok.tolist(), timing, v_timing)
 
 
+def tinyllama_full():
+    """BASELINE config 2 at its real size: TinyLlama-1.1B geometry (22 layers, 2048 hidden, 32 / 4 heads, untied 32000-row head), Q4_K, 24-token prompt + 12 greedy steps run by
+    the reference; greedy ids, top-64 and every 97th logit of each step."""
+    c = synth.tinyllama_11b(target=mf.Q4_K)
+    ids, tok, log, timing = run_ref_llm(c, 24, 12, threads=8)
+    ti, tv, st = _sampled(log)
+    np.savez_compressed(os.path.join(GOLD, "tinyllama_11b.npz"), ids=ids, tokens=tok, top_idx=ti, top_val=tv, strided=st, timing=np.frombuffer(timing.encode(), dtype=np.uint8))
+    print("tinyllama_11b.npz", tok.tolist(), timing)
+
+
 def n4_golden():
     """the extra ops of the other model families, each run by the reference itself (oracle/ref_drivers/ref_ops.cpp cases swmask, ntkrope, topk, bincount,
     scatter_add, gather_rows, fuyu_gather) on small seeded inputs that exercise their edge cases: window edges on both sides with old keys in the cache, tied scores in
@@ -475,6 +485,9 @@ def n4_golden():
 
 
 if __name__ == "__main__":
+    if "--tinyllama-full" in sys.argv:
+        tinyllama_full()
+        sys.exit(0)
     if "--n4" in sys.argv:
         n4_golden()
         sys.exit(0)

@@ -131,6 +131,24 @@ def test_engine_full_size_qwen15_matches_reference():
 
 
 @pytest.mark.gpu
+def test_engine_full_size_tinyllama_matches_reference():
+    """BASELINE config 2 at its real geometry (22 x 2048, 32 / 4 heads, untied Q4_K head of 32000 rows): 24-token prompt + 12 greedy steps, bit-identical to the reference's run
+    (tests/golden/tinyllama_11b.npz, oracle/make_golden.py --tinyllama-full)."""
+    from mllm_amd import lib
+    g = np.load(os.path.join(GOLD, "tinyllama_11b.npz"))
+    cfg = synth.tinyllama_11b(target=mf.Q4_K)
+    m = lib.Model(cfg, weights.causal_lm_file(cfg, CACHE))
+    toks, logits = m.greedy(g["ids"], len(g["tokens"]))
+    assert toks == g["tokens"].tolist()
+    assert max(_sample_err(g, s, lg) for s, lg in enumerate(logits)) == 0.0
+    m.clear_kvcache()
+    tok, _, _ = m.prefill(g["ids"], want_logits=False)
+    gen, _ = m.generate(tok, len(toks) - 1)          # the captured decode graph gives the same ids
+    assert gen.tolist() == toks[1:]
+    m.close()
+
+
+@pytest.mark.gpu
 def test_engine_full_size_vitb_matches_reference():
     import torch
     from mllm_amd import lib
@@ -165,6 +183,41 @@ def test_engine_llava_7b_geometry_matches_reference():
     toks, logits = m.greedy(ids, len(g["tokens"]), image=img)
     assert toks == g["tokens"].tolist(), (toks, g["tokens"].tolist())
     assert max(_sample_err(g, s, lg) for s, lg in enumerate(logits)) == 0.0
+    m.close()
+
+
+@pytest.mark.gpu
+def test_vision_batches_give_the_single_image_rows(monkeypatch):
+    """mllm_hip_model_vision walks the images several at a time (row-wise kernels once over all their token rows, rotary and attention per image): a batch must give,
+    bit for bit, the rows each image gives alone -- for the CLIP tower + projector (5 images: one full group of 4 rows-budget permitting, plus a ragged tail when the
+    group size is forced to 2) and for the Qwen2-VL tower with its 2-D rotary and patch merger."""
+    import torch
+    from mllm_amd import lib
+    r = np.random.default_rng(3)
+    cfg = synth.llava_tiny()
+    m = lib.Model(cfg, weights.llava_file(cfg, CACHE))
+    rows, cols = m.vision_shape()
+    imgs = r.standard_normal((5, cfg.img, 3, cfg.img)).astype(np.float32)
+    def run(n_batch):
+        if n_batch is None: monkeypatch.delenv("MLLM_HIP_VISION_BATCH", raising=False)
+        else: monkeypatch.setenv("MLLM_HIP_VISION_BATCH", str(n_batch))
+        out = torch.empty((5 * rows, cols), dtype=torch.float32, device="cuda")
+        m.vision(imgs, None, out.data_ptr(), 5)
+        return out.cpu().numpy()
+    single = run(1)
+    assert np.array_equal(run(None), single) and np.array_equal(run(2), single) and np.array_equal(run(5), single)
+    m.close()
+    cfg = synth.qwen2vl_tiny()
+    m = lib.Qwen2VL(cfg, weights.qwen2vl_file(cfg, CACHE))
+    grid = np.array([1, 8, 8], dtype=np.int32)
+    pix = r.standard_normal((3, 64, cfg.patch_elems)).astype(np.float32)
+    outs = []
+    for nb in ("1", "3", "2"):
+        monkeypatch.setenv("MLLM_HIP_VISION_BATCH", nb)
+        out = torch.empty((3 * 16, cfg.hidden), dtype=torch.float32, device="cuda")
+        m.vision(pix, grid, out.data_ptr(), 3)
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     m.close()
 
 
