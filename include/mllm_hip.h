@@ -186,6 +186,11 @@ int mllm_hip_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, const 
                  int64_t ldo, int Sq, int Sk, int Hq, int Hkv, int D, int causal, const int *sk_dev, void *workspace,
                  void *stream);
 size_t mllm_hip_fa2_workspace_bytes(int Sq, int Hq, int D, int max_sk);
+/* nbatch independent attentions of one geometry in one launch (the images of a vision pass): set b uses q / k / v / o at element offsets b*bq / b*bk / b*bv / b*bo.
+ * Same arithmetic as mllm_hip_fa2 per set; Sq >= 4. */
+int mllm_hip_fa2_batch(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *V, int64_t ldv, int kv_dtype, float *O,
+                       int64_t ldo, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int nbatch, int64_t bq, int64_t bk, int64_t bv,
+                       int64_t bo, void *stream);
 /* attention on the engine's KV layout: K fp16 rows `[Sk][Hkv*D]`, V fp16 transposed `[Hkv*D][ldvt]` (mllm_hip_store_f16_t) */
 int mllm_hip_fa2_vt(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *Vt, int64_t ldvt, float *O, int64_t ldo,
                     int Sq, int Sk, int Hq, int Hkv, int D, int causal, void *stream);

@@ -676,12 +676,20 @@ static int vision_blocks(M *m, int N, int NB, float ln_eps, const uint16_t *lut,
         const int F = B.fc1.N;
         EH(q_layernorm(m, x, B.n1w, B.n1b, m->vxq, R, V, ln_eps));
         EH(lin(m, B.qkv, m->vxq, m->vqkv, MLLM_HIP_F32, 3 * V, nullptr, R));
-        for (int b = 0; b < NB; ++b) {
+        // q and k are columns [0, 2V) of the same rows: one launch over 2 * heads heads rotates both in place (per image: the table rows are its token positions)
+        for (int b = 0; rope && b < NB; ++b) {
             float *qkv = m->vqkv + (size_t)b * N * 3 * V;
-            // q and k are columns [0, 2V) of the same rows: one launch over 2 * heads heads rotates both in place
-            if (rope) EH(mllm_hip_rope_apply(qkv, 3 * V, m->vsin, m->vcos, VD / 2, qkv, MLLM_HIP_F32, 3 * V, N, 2 * c.v_heads, VD, st));
-            EH(mllm_hip_fa2(qkv, 3 * V, qkv + V, 3 * V, qkv + 2 * V, 3 * V, MLLM_HIP_F32, m->vattn + (size_t)b * N * V, V, N, N, c.v_heads, c.v_heads, VD, 0, nullptr,
-                            nullptr, st));
+            EH(mllm_hip_rope_apply(qkv, 3 * V, m->vsin, m->vcos, VD / 2, qkv, MLLM_HIP_F32, 3 * V, N, 2 * c.v_heads, VD, st));
+        }
+        if (N >= 4) {
+            EH(mllm_hip_fa2_batch(m->vqkv, 3 * V, m->vqkv + V, 3 * V, m->vqkv + 2 * V, 3 * V, MLLM_HIP_F32, m->vattn, V, N, N, c.v_heads, c.v_heads, VD, 0, NB,
+                                  (int64_t)N * 3 * V, (int64_t)N * 3 * V, (int64_t)N * 3 * V, (int64_t)N * V, st));
+        } else {
+            for (int b = 0; b < NB; ++b) {
+                float *qkv = m->vqkv + (size_t)b * N * 3 * V;
+                EH(mllm_hip_fa2(qkv, 3 * V, qkv + V, 3 * V, qkv + 2 * V, 3 * V, MLLM_HIP_F32, m->vattn + (size_t)b * N * V, V, N, N, c.v_heads, c.v_heads, VD, 0, nullptr,
+                                nullptr, st));
+            }
         }
         EH(q_quant(m, m->vattn, m->vxq, R, V));
         EH(lin(m, B.proj, m->vxq, r, MLLM_HIP_F32, V, x, R));                       // residual = proj(attn) + x

@@ -43,7 +43,12 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 template <int D, bool F16, bool VT = false>
 __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(const float *__restrict__ Q, int64_t ldq, const void *__restrict__ K, int64_t ldk,
                                                           const void *__restrict__ V, int64_t ldv, float *__restrict__ O, int64_t ldo, int Sq, int Sk,
-                                                          int sk_eff, int Hq, int Hkv, int causal) {
+                                                          int sk_eff, int Hq, int Hkv, int causal, int64_t bq, int64_t bk, int64_t bv, int64_t bo) {
+    // blockIdx.z = which of the independent (q, k, v, o) sets of the launch (the images of a vision pass); strides in elements
+    Q += (int64_t)blockIdx.z * bq;
+    O += (int64_t)blockIdx.z * bo;
+    K = reinterpret_cast<const char *>(K) + (int64_t)blockIdx.z * bk * (F16 ? 2 : 4);
+    V = reinterpret_cast<const char *>(V) + (int64_t)blockIdx.z * bv * (F16 ? 2 : 4);
     static_assert(D % 16 == 0 && D <= 128, "head dim");
     constexpr int NS = D / 16;              // MFMAs per score chain
     constexpr int KP = D + 1;               // K row pitch in LDS (odd: the per-key column reads are conflict-free)
@@ -296,7 +301,8 @@ extern "C" size_t mllm_hip_fa2_workspace_bytes(int Sq, int Hq, int D, int max_sk
 
 template <int D, bool F16, bool VT = false>
 static int launch_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *V, int64_t ldv, float *O, int64_t ldo, int Sq, int Sk,
-                      int Hq, int Hkv, int causal, const int *sk_dev, int sk_max, hipStream_t st) {
+                      int Hq, int Hkv, int causal, const int *sk_dev, int sk_max, hipStream_t st, int nbatch = 1, int64_t bq = 0, int64_t bk = 0, int64_t bv = 0,
+                      int64_t bo = 0) {
     constexpr int NT = 1024;
     auto decode_row = [&](const float *q, float *o, int sk, const int *skd, int skm) -> int {
         constexpr int ELT = F16 ? 2 : 4;
@@ -308,6 +314,7 @@ static int launch_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, c
         hipLaunchKernelGGL(kern, dim3(Hq), dim3(NT), lds, st, q, K, ldk, V, ldv, o, sk, skd, skm, nslots, Hq, Hkv);
         return MH_LAUNCH_OK("fa2_decode");
     };
+    if (nbatch > 1 && Sq < 4) return MLLM_HIP_ERR_SHAPE;      // (the batched form is the prefill kernel's)
     if (Sq == 1) return decode_row(Q, O, Sk, sk_dev, sk_dev ? sk_max : Sk);
     if (sk_dev) return MLLM_HIP_ERR_ARG;
     if (Sq < 4) {
@@ -324,8 +331,8 @@ static int launch_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, c
     const int left = F16 ? (Tc ? Sk % Tc : 0) : Sk % 4;
     const int sk_eff = Tc * 4 + left;
     constexpr int R = FA_R;
-    hipLaunchKernelGGL((fa2_prefill_kernel<D, F16, VT>), dim3((Sq + R - 1) / R, Hq), dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, sk_eff, Hq,
-                       Hkv, causal);
+    hipLaunchKernelGGL((fa2_prefill_kernel<D, F16, VT>), dim3((Sq + R - 1) / R, Hq, nbatch), dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, sk_eff, Hq,
+                       Hkv, causal, bq, bk, bv, bo);
     return MH_LAUNCH_OK("fa2_prefill");
 }
 
@@ -342,6 +349,30 @@ extern "C" int mllm_hip_fa2(const float *Q, int64_t ldq, const void *K, int64_t 
     case DD:                                                                                                                                \
         return f16 ? launch_fa2<DD, true>(Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, Hq, Hkv, causal, sk_dev, Sk, st)                          \
                    : launch_fa2<DD, false>(Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, Hq, Hkv, causal, sk_dev, Sk, st);
+    switch (D) {
+        FA2_CASE(16)
+        FA2_CASE(64)
+        FA2_CASE(80)
+        FA2_CASE(128)
+    default: return MLLM_HIP_ERR_SHAPE;
+    }
+#undef FA2_CASE
+}
+
+// nbatch independent attentions of the same geometry in ONE launch (the images of a vision pass: 512 workgroups per 448-pixel image leave the third workgroup slot
+// of a CU empty): set b reads q / k / v / o at element offsets b * bq / bk / bv / bo.  Sq >= 4 (the prefill recurrence), fp32 or fp16 K / V rows.
+extern "C" int mllm_hip_fa2_batch(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *V, int64_t ldv, int kv_dtype, float *O, int64_t ldo, int Sq, int Sk,
+                                  int Hq, int Hkv, int D, int causal, int nbatch, int64_t bq, int64_t bk, int64_t bv, int64_t bo, void *stream) {
+    if (Sq < 4 || Sk <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || nbatch <= 0 || nbatch > 65535) return MLLM_HIP_ERR_SHAPE;
+    if (kv_dtype != MLLM_HIP_F16 && kv_dtype != MLLM_HIP_F32) return MLLM_HIP_ERR_DTYPE;
+    if ((ldk % 8) || (ldv % 8) || (bk % 8) || (bv % 8)) return MLLM_HIP_ERR_SHAPE;
+    if (!Q || !K || !V || !O) return MLLM_HIP_ERR_ARG;
+    hipStream_t st = as_stream(stream);
+    const bool f16 = kv_dtype == MLLM_HIP_F16;
+#define FA2_CASE(DD)                                                                                                                                    \
+    case DD:                                                                                                                                            \
+        return f16 ? launch_fa2<DD, true>(Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, Hq, Hkv, causal, nullptr, Sk, st, nbatch, bq, bk, bv, bo)             \
+                   : launch_fa2<DD, false>(Q, ldq, K, ldk, V, ldv, O, ldo, Sq, Sk, Hq, Hkv, causal, nullptr, Sk, st, nbatch, bq, bk, bv, bo);
     switch (D) {
         FA2_CASE(16)
         FA2_CASE(64)
