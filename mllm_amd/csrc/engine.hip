@@ -1081,9 +1081,11 @@ extern "C" int mllm_hip_model_vision(mllm_hip_model *m, const float *images_host
     if (m->vkind == V_QWEN2VL && !image_meta) return MLLM_HIP_ERR_ARG;
     int nt, orows, ocols; size_t ie;
     vision_dims(m, image_meta, &nt, &orows, &ocols, &ie);
-    // images per pass: about 4096 token rows (the row-wise kernels then fill the chip even for 197-token images), at most 16
-    int NB = std::max(1, std::min(std::min(16, 4096 / std::max(nt, 1)), n_img));
+    // images per pass: up to about 6400 token rows (the row-wise kernels then fill the chip even for 197-token images), at most 32, the images spread evenly over
+    // the passes (8 images at 7 per pass = 4 + 4, not 7 + 1)
+    int NB = std::max(1, std::min(std::min(32, 6400 / std::max(nt, 1)), n_img));
     if (const char *e = getenv("MLLM_HIP_VISION_BATCH")) NB = std::max(1, std::min(atoi(e), n_img));
+    NB = (n_img + (n_img + NB - 1) / NB - 1) / ((n_img + NB - 1) / NB);
     EH(ensure_vision_buffers(m, image_meta, NB));
     const int ngroups = (n_img + NB - 1) / NB;
     const size_t gstride = ie * (size_t)m->vis_batch;                  // the staging buffers hold vis_batch images each
