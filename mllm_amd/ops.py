@@ -227,6 +227,19 @@ def flash_attention2(q, k, v, Sq, Sk, Hq, Hkv, D, causal, sk_dev=None):
     return o
 
 
+def flash_attention2_batch(q, k, v, Sq, Sk, Hq, Hkv, D, causal):
+    """nb independent attentions in one launch (mllm_hip_fa2_batch): q fp32 [nb][Sq][Hq*D]; k, v fp16 or fp32 [nb][Sk][Hkv*D]."""
+    q = _dev(q, torch.float32)
+    k, v = _dev(k), _dev(v)
+    nb = q.shape[0]
+    kv_dt = F16 if k.dtype == torch.float16 else F32
+    o = torch.empty((nb, Sq, Hq * D), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_fa2_batch(vp(q), i64(Hq * D), vp(k), i64(Hkv * D), vp(v), i64(Hkv * D), C.c_int(kv_dt), vp(o), i64(Hq * D), C.c_int(Sq), C.c_int(Sk),
+                                      C.c_int(Hq), C.c_int(Hkv), C.c_int(D), C.c_int(int(causal)), C.c_int(nb), i64(Sq * Hq * D), i64(Sk * Hkv * D), i64(Sk * Hkv * D),
+                                      i64(Sq * Hq * D), _stream()), "fa2_batch")
+    return o
+
+
 def linear_q4k_packed_producers(Wq, x, N, mode="quant", w=None, b=None, eps=1e-6):
     """Prefill path of the resident engine: the producer (quantiser / RMSNorm / LayerNorm) writes the packed activation operand, the
     GEMM consumes it.  Returns y = Linear(producer(x))."""

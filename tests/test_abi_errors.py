@@ -135,3 +135,18 @@ def test_sampling_and_preprocess_entry_points_validate(L):
     assert L.mllm_hip_all_gather_rows(NULL, P, P, C.c_int64(4), C.c_int(8), NULL) == ERR_ARG
     assert L.mllm_hip_comm_create(NULL, C.c_int(1), C.c_int(0), C.byref(C.c_void_p())) == ERR_ARG
     assert L.mllm_hip_rope_table_hf_llama3(C.c_float(1e4), C.c_int(63), C.c_int(8), C.c_float(8), C.c_float(1), C.c_float(4), C.c_float(8192), P, P) == ERR_ARG
+
+
+def test_fa2_batch_validates_before_any_launch(L):
+    i64 = C.c_int64
+    def call(Sq=32, Sk=32, Hq=4, Hkv=2, D=64, nb=2, kvdt=0, ldk=128, bk=32 * 128, q=P, k=P):
+        return L.mllm_hip_fa2_batch(q, i64(256), k, i64(ldk), P, i64(ldk), C.c_int(kvdt), P, i64(256), C.c_int(Sq), C.c_int(Sk), C.c_int(Hq), C.c_int(Hkv), C.c_int(D),
+                                    C.c_int(0), C.c_int(nb), i64(Sq * 256), i64(bk), i64(bk), i64(Sq * 256), NULL)
+    assert call(Sq=2) == ERR_SHAPE               # the batched form is the prefill recurrence's (Sq >= 4)
+    assert call(Hq=3) == ERR_SHAPE               # query heads must be a multiple of the K/V heads
+    assert call(nb=0) == ERR_SHAPE
+    assert call(kvdt=12) == ERR_DTYPE            # K / V are fp32 or fp16 rows
+    assert call(ldk=130) == ERR_SHAPE            # 16-byte loads of the K rows
+    assert call(bk=4100) == ERR_SHAPE
+    assert call(q=NULL) == ERR_ARG
+    assert call(D=48) == ERR_SHAPE               # head sizes 16, 64, 80, 128

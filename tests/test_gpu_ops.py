@@ -328,6 +328,20 @@ def test_fa2_on_the_engine_kv_layout(Sq, Sk, Hq, Hkv, D):
     assert eq(o, ref), md(o, ref)
 
 
+def test_fa2_batch_is_the_per_set_attention():
+    """mllm_hip_fa2_batch (the images of a vision pass in one launch): every set equals its own mllm_hip_fa2 call, for fp32 and fp16 K / V, causal or not, ragged Sq."""
+    r = np.random.default_rng(21)
+    for (nb, Sq, Sk, Hq, Hkv, D, causal, f16) in ((3, 197, 197, 4, 4, 64, False, False), (2, 70, 90, 4, 2, 128, True, True), (5, 33, 33, 2, 2, 80, False, False)):
+        q = r.standard_normal((nb, Sq, Hq * D)).astype(np.float32)
+        k = r.standard_normal((nb, Sk, Hkv * D)).astype(np.float32); v = r.standard_normal((nb, Sk, Hkv * D)).astype(np.float32)
+        kt, vt = torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()
+        if f16: kt, vt = kt.half(), vt.half()
+        got = ops.flash_attention2_batch(q, kt, vt, Sq, Sk, Hq, Hkv, D, causal).cpu().numpy()
+        for b in range(nb):
+            one = ops.flash_attention2(q[b], kt[b].contiguous(), vt[b].contiguous(), Sq, Sk, Hq, Hkv, D, causal).cpu().numpy()
+            assert np.array_equal(got[b], one), (nb, Sq, Sk, D, b)
+
+
 def test_fa2_online_softmax_rescale_is_forced():
     """A spiked late key forces the running max to jump in the last tile (rescale branch of the online softmax)."""
     Sq = Sk = 96
