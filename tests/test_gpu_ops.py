@@ -75,8 +75,8 @@ def test_linear_q4k_gemv_vs_oracle(M, K, N):
     assert eq(y, ref), md(y, ref)
 
 
-# the GEMM's K loop is peeled (first blocks / block nb-2 / last block) and has a 64x64 and a 32x64 workgroup form: nb = 1, 2, 3, 4 in both forms,
-# ragged M and N edges
+# the GEMM's K loop is peeled (first blocks / block nb-2 / last block): nb = 1, 2, 3, 4 and more; ragged M and N edges, an odd number of 32-column tiles (the second
+# tile of a workgroup's 32 x 64 is then idle), weights expanded from nibbles in registers
 @pytest.mark.parametrize("M,K,N", [(16, 256, 128), (64, 1536, 256), (282, 1536, 2048), (100, 8960, 192), (1024, 1280, 384), (33, 512, 96),
                                    (512, 256, 512), (448, 512, 448), (300, 768, 700), (129, 1024, 1100), (20, 768, 100), (47, 1024, 70)])
 def test_linear_q4k_gemm_vs_oracle(M, K, N):
@@ -99,7 +99,7 @@ def test_linear_q4k_fp16_out_and_residual():
     res2 = rng(2).standard_normal((40, 128)).astype(np.float32)
     y2 = ops.linear_q4k(Wq2, x2, 128, residual=res2)
     assert eq(y2, orc.linear(x2, Wq2, orc.Q4_K, 128) + res2)
-    # the 64 x 64 GEMM form: bias + residual on ragged edges, and the fp16 output (the epilogue is split over a wave pair)
+    # bias + residual on ragged edges, and the fp16 output (the epilogue is split over a wave pair)
     Wq3, x3, b3 = _q4k_case(300, 768, 700, 7)
     res3 = rng(3).standard_normal((300, 700)).astype(np.float32)
     y3 = ops.linear_q4k(Wq3, x3, 700, bias=b3, residual=res3)
