@@ -104,6 +104,14 @@ int main() {
         for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, st));
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float msA = 0; CK(hipEventElapsedTime(&msA, e0, e1));
+        // (A') the same launches enqueued on the stream, no graph
+        for (int p = 0; p < phases; ++p) hipLaunchKernelGGL(phase_kernel, dim3(G), dim3(NT), 0, st, (p & 1) ? b : a, (p & 1) ? a : b, G);
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r)
+            for (int p = 0; p < phases; ++p) hipLaunchKernelGGL(phase_kernel, dim3(G), dim3(NT), 0, st, (p & 1) ? b : a, (p & 1) ? a : b, G);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float msS = 0; CK(hipEventElapsedTime(&msS, e0, e1));
         // (B) one persistent launch with in-launch barriers
         float msB = 0; int herr = 0;
         for (int r = 0; r < 3 + reps; ++r) {
@@ -123,6 +131,7 @@ int main() {
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&msC, e0, e1));
         CK(hipMemcpy(&herr2, err, 4, hipMemcpyDeviceToHost));
+        printf("G %3d workgroups: stream launches without a graph %.2f us per phase | ", G, msS * 1e3 / (reps * phases));
         printf("G %3d workgroups: graph of dependent launches %.2f us per phase | persistent, one counter %.2f%s | persistent, per-XCD + global counters %.2f%s\n", G,
                msA * 1e3 / (reps * phases), msB * 1e3 / (reps * phases), herr ? " (TIMED OUT: invalid)" : "", msC * 1e3 / (reps * phases), herr2 ? " (TIMED OUT: invalid)" : "");
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
