@@ -218,6 +218,18 @@ def test_vision_batches_give_the_single_image_rows(monkeypatch):
         m.vision(pix, grid, out.data_ptr(), 3)
         outs.append(out.cpu().numpy())
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    # image sizes and batch sizes that grow and shrink between calls (the buffers are re-sized for the largest of each seen so far)
+    monkeypatch.delenv("MLLM_HIP_VISION_BATCH", raising=False)
+    for (gh, gw, n) in ((8, 8, 3), (16, 8, 2), (8, 8, 5), (16, 16, 1), (8, 16, 4)):
+        grid = np.array([1, gh, gw], dtype=np.int32)
+        pix = r.standard_normal((n, gh * gw, cfg.patch_elems)).astype(np.float32)
+        rows = gh * gw // 4
+        got = torch.empty((n * rows, cfg.hidden), dtype=torch.float32, device="cuda")
+        m.vision(pix, grid, got.data_ptr(), n)
+        for b in range(n):
+            one = torch.empty((rows, cfg.hidden), dtype=torch.float32, device="cuda")
+            m.vision(pix[b], grid, one.data_ptr(), 1)
+            assert np.array_equal(got[b * rows:(b + 1) * rows].cpu().numpy(), one.cpu().numpy()), (gh, gw, n, b)
     m.close()
 
 
