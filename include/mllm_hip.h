@@ -331,7 +331,8 @@ int mllm_hip_qwen2vl_time_gemv(mllm_hip_qwen2vl *m, int which, int iters, float 
  * s - (window - 1) <= d <= s + (keys - S), everything else becomes std::numeric_limits<float>::lowest(); S == 1 passes through. */
 int mllm_hip_sliding_window_mask(const float *x, float *y, int S, int H, int keys, int window, void *stream);
 /* F_TOPK on DIMENSION (Tensor::topk, CPUTopkFunc.hpp:48-70; the MoE routers): per row the k largest (value, index) pairs in descending pair order -- among
- * equal values the larger index first; `indices` are written as floats like the reference's second output. */
+ * equal values the larger index first; `indices` are written as floats like the reference's second output.  The HEAD-axis form of the function (input [1][H][S][1],
+ * output [1][k][S][1]) is the same call: in BSHD memory those are the rows [S][H] -> [S][k] (ldx = H, n = H). */
 int mllm_hip_topk_rows(const float *x, int64_t ldx, float *values, float *indices, int rows, int n, int k, void *stream);
 /* F_BINCOUNT (CPUBinCountFunc.hpp:20-35): counts of the integer parts 0 .. nbins-1 (the reference's output has max + 1 entries; pass the bins wanted) */
 int mllm_hip_bincount(const float *ids, int n, float *counts, int nbins, void *stream);

@@ -452,6 +452,10 @@ def n4_golden():
     (tv,), _ = run_ops("topk", pn, [[(sc, (1, 1, 5, E))]], p=(K, 0))
     (ti,), _ = run_ops("topk", pn, [[(sc, (1, 1, 5, E))]], p=(K, 1))
     G["topk_x"], G["topk_v"], G["topk_i"] = sc, tv.reshape(5, K), ti.reshape(5, K)
+    # the HEAD-axis form of the same function (scores [1, H = 16, S = 5, 1]: in BSHD memory the same [S][H] rows)
+    (hv,), _ = run_ops("topk", pn, [[(sc, (1, 1, 5, E))]], p=(K, 0, 1, E))
+    (hi,), _ = run_ops("topk", pn, [[(sc, (1, 1, 5, E))]], p=(K, 1, 1, E))
+    G["topk_head_v"], G["topk_head_i"] = hv.reshape(5, K), hi.reshape(5, K)
     # bincount of expert ids
     ids = np.array([3, 0, 3, 7, 1, 1, 3], dtype=np.float32)
     (bc,), _ = run_ops("bincount", pn, [[(ids, (1, 1, 1, ids.size))]])

@@ -112,7 +112,12 @@ public:
             q = r(q);
             return {q.view(-1, 1, -1, (int)(p(3) * p(4)))};
         }
-        if (kind == "topk") {        // CPUTopkFunc.hpp:48-70; p: k, which output (0 values, 1 indices)
+        if (kind == "topk") {        // CPUTopkFunc.hpp:48-92; p: k, which output (0 values, 1 indices), axis (0 DIMENSION, 1 HEAD: input [1, H, S, 1])
+            if (p(2) != 0) {
+                auto x = in[0].view(-1, (int)p(3), -1, 1);
+                auto r = Tensor::topk(x, (int)p(0), HEAD);
+                return {r[(int)p(1)].view(-1, 1, -1, (int)p(0))};
+            }
             auto r = Tensor::topk(in[0], (int)p(0), DIMENSION);
             return {r[(int)p(1)]};
         }

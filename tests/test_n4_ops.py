@@ -35,6 +35,8 @@ def test_oracle_topk_ties_and_bincount_match_reference():
     v, i = orc.topk_rows(G["topk_x"], G["topk_v"].shape[1])
     assert eq(v, G["topk_v"]) and eq(i, G["topk_i"])
     assert G["topk_i"][4].tolist() == [15.0, 14.0, 13.0, 12.0]      # equal values: the larger index first
+    # the HEAD-axis form ([1, H, S, 1]: in BSHD memory the same [S][H] rows, output [1, k, S, 1] = [S][k]) is the same selection over the same rows
+    assert eq(G["topk_head_v"], G["topk_v"]) and eq(G["topk_head_i"], G["topk_i"])
     assert eq(orc.bincount(G["bincount_x"]), G["bincount_y"])
 
 
