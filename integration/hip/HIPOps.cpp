@@ -327,25 +327,30 @@ public:
 private:
     int window_;
 };
-// F_TOPK on DIMENSION (op/CPUTopkFunc.hpp:27-70): outputs[0] = values, outputs[1] = indices (floats), [1][1][S][k]
+// F_TOPK (op/CPUTopkFunc.hpp:27-92): outputs[0] = values, outputs[1] = indices (floats).  DIMENSION: [b][h][s][D] -> [b][h][s][k]; HEAD (input [1][H][S][1]) ->
+// [1][k][S][1] -- in BSHD memory the rows [S][H] -> [S][k], the same launch with n = H
 class HIPTopkOp final : public Op {
 public:
-    HIPTopkOp(Backend *bn, const string &name, int k) : Op(bn, name), k_(k) {}
+    HIPTopkOp(Backend *bn, const string &name, int k, bool head_axis) : Op(bn, name), k_(k), head_(head_axis) {}
     ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+        if (head_ && (inputs[0]->dimension() != 1 || inputs[0]->batch() != 1)) throw std::runtime_error("HIPTopkOp: the HEAD axis form takes [1][H][S][1]");
         for (int o = 0; o < 2; ++o) {
-            outputs[o]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), k_);
+            if (head_) outputs[o]->reshape(inputs[0]->batch(), k_, inputs[0]->sequence(), 1);
+            else outputs[o]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), k_);
             outputs[o]->setDtype(inputs[0]->dtype());
         }
         return MLLM_NO_ERROR;
     }
     ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        const int rows = inputs[0]->batch() * inputs[0]->head() * inputs[0]->sequence(), n = inputs[0]->dimension();
+        const int rows = head_ ? inputs[0]->sequence() : inputs[0]->batch() * inputs[0]->head() * inputs[0]->sequence();
+        const int n = head_ ? inputs[0]->head() : inputs[0]->dimension();
         HIPCHK(mllm_hip_topk_rows((const float *)dptr(inputs[0]), n, (float *)dptr(outputs[0]), (float *)dptr(outputs[1]), rows, n, k_, hb(backend_)->stream()));
         return MLLM_NO_ERROR;
     }
 
 private:
     int k_;
+    bool head_;
 };
 // F_SCATTERADD on SEQUENCE (op/CPUScatterAddFunc.hpp:27-60): inputs = (dest [1][1][S][D], src [1][1][R][D], indices [1][1][1][R]); dest is updated in place, no outputs
 class HIPScatterAddOp final : public Op {
@@ -523,7 +528,8 @@ void HIPBackend::registerOps() {
     };
     creators_[SLIDINGWINDOWMASK] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return new HIPSlidingWindowMaskOp(b, n, geti(p, "window_size")); };
     creators_[F_TOPK] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
-        return (Chl)geti(p, "dim") == DIMENSION ? new HIPTopkOp(b, n, geti(p, "k")) : nullptr;      // the HEAD-axis form stays on the CPU
+        const Chl dim = (Chl)geti(p, "dim");
+        return dim == DIMENSION || dim == HEAD ? new HIPTopkOp(b, n, geti(p, "k"), dim == HEAD) : nullptr;
     };
     creators_[F_SCATTERRADD] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
         return p.count("dim") && (Chl)geti(p, "dim") != SEQUENCE ? nullptr : new HIPScatterAddOp(b, n);
