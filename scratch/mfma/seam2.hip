@@ -20,6 +20,34 @@ __global__ __launch_bounds__(NT) void k_full(const float *in, float *out, int G)
     const int per = VEC / G;
     if ((int)threadIdx.x < per) out[blockIdx.x * per + threadIdx.x] = tot * 1e-3f + (float)threadIdx.x;
 }
+// (d) the same as (c) with the vector fetched as two float4 per thread issued together (the form the decode kernels use)
+__global__ __launch_bounds__(NT) void k_full4(const float *in, float *out, int G) {
+    __shared__ float red[4];
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    const float4 v0 = in4[threadIdx.x];
+    const float4 v1 = threadIdx.x < VEC / 4 - NT ? in4[NT + threadIdx.x] : make_float4(0, 0, 0, 0);
+    float s = ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const int per = VEC / G;
+    if ((int)threadIdx.x < per) out[blockIdx.x * per + threadIdx.x] = tot * 1e-3f + (float)threadIdx.x;
+}
+// (e) (d) without the cross-wave part: every wave reads the whole vector itself (six float4 per lane) and reduces it with shuffles only -- no LDS, no barrier
+__global__ __launch_bounds__(NT) void k_wave(const float *in, float *out, int G) {
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    const int lane = threadIdx.x & 63;
+    float s = 0.0f;
+    float4 v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = in4[lane + 64 * i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    const int per = VEC / G;
+    if ((int)threadIdx.x < per) out[blockIdx.x * per + threadIdx.x] = s * 1e-3f + (float)threadIdx.x;
+}
 template <typename K> static int run(K kern, const char *name, float *a, float *b, int G, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const int phases = 140, reps = 20;
     hipGraph_t g; hipGraphExec_t ge;
@@ -47,6 +75,8 @@ int main() {
         if (run(k_empty, "(a) empty kernel", a, b, G, st, e0, e1)) return 1;
         if (run(k_copy, "(b) each workgroup copies its slice", a, b, G == 24 ? 24 : 256, st, e0, e1)) return 1;
         if (run(k_full, "(c) read whole vector, reduce, write slice", a, b, G == 24 ? 24 : 256, st, e0, e1)) return 1;
+        if (run(k_full4, "(d) the same, two float4 per thread at once", a, b, G == 24 ? 24 : 256, st, e0, e1)) return 1;
+        if (run(k_wave, "(e) per-wave read + shuffle reduce, no barrier", a, b, G == 24 ? 24 : 256, st, e0, e1)) return 1;
     }
     return 0;
 }
