@@ -288,8 +288,14 @@ constexpr int GQ_RET = 16;
 #endif
 __global__ __launch_bounds__(256, 2) void gemm_q4k_kernel(const uint8_t *__restrict__ Wp, const uint8_t *__restrict__ Xp, const float *__restrict__ bias,
                                                           void *__restrict__ y, int y_f16, int64_t ldy, const float *__restrict__ residual, int M, int N,
-                                                          int nb) {
+                                                          int nb, int m_fastest) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
+    // Tile of this workgroup.  Workgroups go to the XCDs round-robin by their linear id, and every XCD's L2 has to pull what its workgroups read: with the
+    // n-tile pair as the fastest index an XCD sees 1/8 of the weights and ALL activations, with the m-tile as the fastest 1/8 of the activations and all
+    // weights -- the launcher picks the order that re-reads the smaller operand eight times (FETCH_SIZE of the ViT fc2: 95 MB per launch with its 11 MB of
+    // activations pulled by all eight L2s).
+    const int GXt = (N + 63) / 64, MTt = (M + 31) / 32;
+    const int tile_x = m_fastest ? (int)blockIdx.x / MTt : (int)blockIdx.x % GXt, tile_y = m_fastest ? (int)blockIdx.x % MTt : (int)blockIdx.x / GXt;
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the DMA bookkeeping below stays scalar
 #if defined(MLLM_HIP_STAMPS)
     __shared__ unsigned long long st_lds[4 * GQ_ST_HS * GQ_ST_N];
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q4k_kernel(const uint8_t *__restr
     for (int i = threadIdx.x; i < 4 * GQ_ST_HS * GQ_ST_N; i += 256) st_lds[i] = 0;
 #endif
 #if defined(GQ_STAGGER)   // diagnosis: the second workgroup of every CU starts GQ_STAGGER x 64 cycles late (first wave of 512 workgroups only)
-    if ((((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1) && (blockIdx.x + gridDim.x * blockIdx.y) < 512) {
+    if ((((int)blockIdx.x >> 8) & 1) && (int)blockIdx.x < 512) {
 #pragma unroll 1
         for (int i = 0; i < GQ_STAGGER; i += 100) __builtin_amdgcn_s_sleep(100);
     }
@@ -308,11 +314,11 @@ __global__ __launch_bounds__(256, 2) void gemm_q4k_kernel(const uint8_t *__restr
     const int col = lane & 31, h = lane >> 5;
     const int NT = (N + 31) / 32;
     const int nw = wid >> 1, ch = wid & 1;
-    const int mt = blockIdx.y, nt = blockIdx.x * 2 + nw;          // mt < ceil(M / 32) by the grid
+    const int mt = tile_y, nt = tile_x * 2 + nw;          // mt < ceil(M / 32) by the grid
     const bool active = nt < NT;
     const size_t tbw = q4kp_tile_blocks(N, nb), tbx = q4kp_tile_blocks(M, nb);
     // DMA sources (n-tiles clamped: a workgroup at the edge copies a valid tile twice and does not use the copy)
-    const int nts0 = min((int)blockIdx.x * 2, NT - 1), nts1 = min((int)blockIdx.x * 2 + 1, NT - 1);
+    const int nts0 = min(tile_x * 2, NT - 1), nts1 = min(tile_x * 2 + 1, NT - 1);
     const uint8_t *XpM = Xp + tbx * Q4KP_W_PER_BLK, *XpD = XpM + tbx * Q4KP_M_PER_BLK;
     const uint8_t *WpS = Wp + tbw * Q4KW_Q_PER_BLK, *WpM = WpS + tbw * Q4KW_S_PER_BLK, *WpD = WpM + tbw * Q4KW_M_PER_BLK;
     const unsigned ring0 = (unsigned)(size_t)ring;   // LDS byte address of the ring
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q4k_kernel(const uint8_t *__restr
     if (ch == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 8>{});
 #if defined(MLLM_HIP_STAMPS)
     {
-        const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+        const int wg = blockIdx.x;
         if (wg % 37 == 0 && wg / 37 < GQ_ST_WG) {
             unsigned long long *dst = g_gq_stamps + (size_t)(wg / 37) * (4 * GQ_ST_HS * GQ_ST_N + 8);
             for (int i = threadIdx.x; i < 4 * GQ_ST_HS * GQ_ST_N; i += 256) dst[i] = st_lds[i];
@@ -727,9 +733,13 @@ static int launch_gemm_packed(const void *Wpacked, const float *bias, const void
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     // 32 x 64 workgroup tiles, two workgroups per CU (64 KiB of LDS and one wave per SIMD each)
-    dim3 grid((N + 63) / 64, (M + 31) / 32);
-    hipLaunchKernelGGL(gemm_q4k_kernel, grid, dim3(256), GQ_LDS, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16, ldy,
-                       residual, M, N, nb);
+    const int64_t ntiles = (int64_t)((N + 63) / 64) * ((M + 31) / 32);
+    if (ntiles > 0x7fffffff) return MLLM_HIP_ERR_SHAPE;
+    // the operand that all eight XCD L2s re-read should be the smaller one: activations cost 2.16 B per element (fp16 fragments), weights 0.72 B
+    static const int order_env = getenv("MLLM_HIP_GEMM_ORDER") ? atoi(getenv("MLLM_HIP_GEMM_ORDER")) : -1;      // 0 / 1 force n- / m-fastest (measurement)
+    const int m_fastest = order_env >= 0 ? order_env : (q4kp_bytes(M, K) > q4kw_bytes(N, K) ? 1 : 0);
+    hipLaunchKernelGGL(gemm_q4k_kernel, dim3((unsigned)ntiles), dim3(256), GQ_LDS, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16,
+                       ldy, residual, M, N, nb, m_fastest);
     return MH_LAUNCH_OK("gemm_q4k");
 }
 // GEMM on pre-packed weights and activations already in packed form (mllm_hip_quantize_q8k_packed / _rmsnorm_packed / _layernorm_packed)
