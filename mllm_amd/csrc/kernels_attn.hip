@@ -64,8 +64,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
     __shared__ int moved_any[8];
     __shared__ uint64_t etab[32];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, kvh = head / (Hq / Hkv);
-    const int r0 = blockIdx.x * FA_R;
+    // Workgroups go to the XCDs round-robin by linear id; all row blocks of a head read the same K / V, so with a head count that is a multiple of 8 the head becomes
+    // the fastest index: head h then lives on XCD h % 8 and its K / V are pulled into ONE L2 instead of eight (FETCH_SIZE of the ViT block: 89 MB per launch before)
+    int head = blockIdx.y, rb = blockIdx.x;
+    if ((Hq & 7) == 0) { const int lin = blockIdx.x + gridDim.x * blockIdx.y; head = lin % Hq; rb = lin / Hq; }
+    const int kvh = head / (Hq / Hkv);
+    const int r0 = rb * FA_R;
     const int delta = Sk - Sq;
     const float scale = 1.0f / sqrtf((float)D);
     // this lane's query operands: row r0 + col, dims 8(2s+h) + l for the wave's two chains
