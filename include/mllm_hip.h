@@ -54,6 +54,19 @@ int mllm_hip_free(void *dptr);
 int mllm_hip_h2d(void *dst, const void *src, size_t nbytes, void *stream);
 int mllm_hip_d2h(void *dst, const void *src, size_t nbytes, void *stream);
 int mllm_hip_sync(void *stream);
+/* one in-order stream per backend instance (hipStream_t as void*); the OpenCL backend's command queue, OpenCLBackend.cpp:476-477 */
+int mllm_hip_stream_create(void **stream);
+int mllm_hip_stream_destroy(void *stream);
+/* stream-ordered pool for the per-call Op outputs that Backend::runOp allocates (alloc_device / free_device on the hot path; the reference's
+ * host-side analogue is MemoryPoolManager, mllm/memory/MemoryPoolManager.hpp:15-214): hipMallocAsync / hipFreeAsync on the device's default pool
+ * with the release threshold lifted.  A block freed on `stream` is only safe to reuse by work enqueued later on that same stream. */
+int mllm_hip_pool_alloc(void **dptr, size_t nbytes, void *stream);
+int mllm_hip_pool_free(void *dptr, void *stream);
+/* Backend::load_from_file (mllm/Backend.hpp:118; precedent OpenCLBackend.cpp:928-980): pageable host bytes (the ParamLoader's mmap) -> HBM through
+ * two pinned 32-MiB staging buffers, memcpy of chunk i+1 under the DMA of chunk i.  Returns when `src_host` has been consumed; the tail DMAs may
+ * still be in flight on `stream`.  mllm_hip_upload_release frees the staging buffers (they are created on first use). */
+int mllm_hip_upload(void *dst, const void *src_host, size_t nbytes, void *stream);
+int mllm_hip_upload_release(void);
 
 /* ---- A4: activation quantisation. quantize_row_q8_K_reference (ggml QuantizeQ8.cpp:216-251), quantize_row_q8_0_reference
  *      (:32-55), as called by mat_mul (compute/Matmul.cpp:77-120) ----------------------------------------------------- */
@@ -132,6 +145,12 @@ int mllm_hip_mul(const float *a, const float *b, float *y, int64_t n, void *stre
 int mllm_hip_softmax(const float *x, float *y, int rows, int n, const int *valid, void *stream);
 /* CPUIndexPutFunc (op/CPUIndexPutFunc.hpp:25-92): rows of `value` replace rows idx[i] of `dst` */
 int mllm_hip_index_put_rows(float *dst, const float *value, const int *idx, int n_rows, int dim, void *stream);
+/* the same with the indices as the function receives them, a device tensor of floats (`(int)replace_idx->dataAt<float>`, CPUIndexPutFunc.hpp:85-92);
+ * rows whose destination is outside [0, n_dst_rows) are skipped */
+int mllm_hip_index_put_rows_fidx(float *dst, int n_dst_rows, const float *value, const float *idx, int n_rows, int dim, void *stream);
+/* CPUSplitFunc (op/CPUSplitFunc.hpp:145-172 -> efficient_split, compute/Split.hpp) on DIMENSION, one output at a time: the `[rows][cols]` window of a pitched
+ * fp32 buffer into another (cols, pitches and bases multiples of 4 floats) */
+int mllm_hip_copy_2d_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int rows, int cols, void *stream);
 /* the data-moving case of CPUTransposeFunc (op/CPUTransposeFunc.hpp; most transposes of the graphs are metadata): y[c][r] = x[r][c].  Used by the
  * reference-side Conv2D adapter to hand its `[oh*ow][OC]` rows back in the reference's `[OC][oh][ow]` output order (Convolution.cpp:35-82). */
 int mllm_hip_transpose_f32(const float *x, float *y, int rows, int cols, void *stream);
@@ -170,6 +189,9 @@ int mllm_hip_rope_table_ntk(float theta, int dim, int n_pos, int original_max_po
 int mllm_hip_mrope_table(float base, int dim, const float *pos3xS_host, int S, const int *section, int n_section,
                          float *sin_host, float *cos_host);
 int mllm_hip_vision_rope_table(int t, int h, int w, int merge, int rot_dim, float *sin_host, float *cos_host);
+/* the VISIONROPE layer's own output (CPUVisionRoPE.cpp:19-147): the angle table `[t*h*w][rot_dim]` (h angles, then w angles) whose sin / cos
+ * F_APPLY_VISIOROPE evaluates per use (CPUVisionRoPEFunc.hpp:21-60); mllm_hip_vision_rope_table = sinf / cosf of these */
+int mllm_hip_vision_rope_angles(int t, int h, int w, int merge, int rot_dim, float *angles_host);
 int mllm_hip_rope_apply(const float *x, int64_t ldx, const float *sin_t, const float *cos_t, int ld_tab, void *out,
                         int out_dtype, int64_t ldo, int S, int H, int D, void *stream);
 /* fp32 -> fp16 strided copy: V rows into the cache slab (the fp16 store branch of mat_mul, Matmul.cpp:262-268) */

@@ -1,6 +1,11 @@
 // integration/hip/HIPBackend.cpp -- see HIPBackend.hpp.  Call protocol after mllm/backends/opencl/OpenCLBackend.cpp:990-1097 and mllm/backends/cpu/CPUBackend.cpp:314-405.
 #include "HIPBackend.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstring>
 
@@ -19,22 +24,76 @@ HIPBackend::HIPBackend(int device) {
     type_ = MLLM_HIP_BACKEND_TYPE;
     mem_manager_ = std::make_shared<SystemMemoryManager>();       // host-side alloc/free of Backend (mllm/Backend.hpp:48-58)
     check(mllm_hip_init(device), "mllm_hip_init");
+    check(mllm_hip_stream_create(&stream_), "mllm_hip_stream_create");
     registerOps();
     registerFuncs();
 }
 
+// ---- reference-counted blocks ---------------------------------------------------------------------------------------------------------------------------------
+std::map<uintptr_t, HIPBackend::Block>::iterator HIPBackend::block_of(const void *p) {
+    auto it = blocks_.upper_bound((uintptr_t)p);
+    if (it == blocks_.begin()) return blocks_.end();
+    --it;
+    return (uintptr_t)p < it->first + it->second.size ? it : blocks_.end();
+}
+void HIPBackend::retain(void *p) {
+    auto it = block_of(p);
+    if (it == blocks_.end()) throw std::runtime_error("HIPBackend::retain: pointer is not inside a live device block");
+    ++it->second.refs;
+}
+void HIPBackend::release(const void *p) {
+    auto it = block_of(p);
+    if (it == blocks_.end()) return;      // not ours (or already gone): nothing to do
+    if (--it->second.refs > 0) return;
+    const uintptr_t lo = it->first, hi = lo + it->second.size;
+    auto inside = [&](const void *q) { return (uintptr_t)q >= lo && (uintptr_t)q < hi; };
+    for (auto s = shadows_.begin(); s != shadows_.end();) s = inside(s->first) ? shadows_.erase(s) : std::next(s);
+    for (auto s = vision_.begin(); s != vision_.end();) s = inside(s->first) ? vision_.erase(s) : std::next(s);
+    if (mrope_key_.pos && inside(mrope_key_.pos)) mrope_key_ = MropeKey();
+    if (it->second.pooled) check(mllm_hip_pool_free((void *)lo, stream_), "mllm_hip_pool_free");
+    else check(mllm_hip_free((void *)lo), "mllm_hip_free");
+    blocks_.erase(it);
+}
 void HIPBackend::alloc_device(DeviceMemory &mem, DataType) {
     mem.type = MEM_TYPE_GENERIC;
-    check(mllm_hip_alloc(&mem.handle, mem.size_in_bytes), "mllm_hip_alloc");
+    mem.handle = nullptr;
+    if (mem.size_in_bytes == 0) return;      // the trace pass allocates shapeless placeholders (CPUBackend.cpp:318-349): nothing behind them
+    check(mllm_hip_pool_alloc(&mem.handle, mem.size_in_bytes, stream_), "mllm_hip_pool_alloc");
+    blocks_[(uintptr_t)mem.handle] = Block{mem.size_in_bytes, 1, true};
 }
 void HIPBackend::free_device(DeviceMemory &mem) {
-    if (mem.handle) check(mllm_hip_free(mem.handle), "mllm_hip_free");
+    if (mem.handle) release(mem.handle);
     mem.handle = nullptr;
 }
-void HIPBackend::copy_from_host(const DeviceMemory &dest, const void *src) { check(mllm_hip_h2d(dest.handle, src, dest.size_in_bytes, stream_), "mllm_hip_h2d"); }
+void *HIPBackend::dev_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    check(mllm_hip_alloc(&p, bytes), "mllm_hip_alloc");
+    blocks_[(uintptr_t)p] = Block{bytes, 1, false};
+    return p;
+}
+void HIPBackend::dev_release(void *p) {
+    if (p) release(p);
+}
+void HIPBackend::view_of(const std::shared_ptr<Tensor> &view, void *handle, size_t bytes) {
+    DeviceMemory &m = view->device_memory();
+    if (m.handle == handle) { m.size_in_bytes = bytes; return; }      // already this view (a second setUp on the same shell)
+    if (m.handle) free_device(m);
+    if (handle) retain(handle);
+    m.handle = handle;
+    m.type = MEM_TYPE_GENERIC;
+    m.size_in_bytes = bytes;
+}
+
+void HIPBackend::upload(void *dst, const void *src, size_t bytes) { check(mllm_hip_upload(dst, src, bytes, stream_), "mllm_hip_upload"); }
+void HIPBackend::copy_from_host(const DeviceMemory &dest, const void *src) {
+    if (!dest.handle || !src || dest.size_in_bytes == 0) return;
+    upload(dest.handle, src, dest.size_in_bytes);
+    if (dest.size_in_bytes <= (64u << 10) && dest.size_in_bytes % 4 == 0) remember_host(dest.handle, (const float *)src, dest.size_in_bytes / 4);      // fact 3
+}
 void HIPBackend::copy_to_host(void *dest, const DeviceMemory &src) {
-    check(mllm_hip_d2h(dest, src.handle, src.size_in_bytes, stream_), "mllm_hip_d2h");
-    sync();
+    if (!dest || !src.handle || src.size_in_bytes == 0) return;
+    check(mllm_hip_d2h(dest, src.handle, src.size_in_bytes, stream_), "mllm_hip_d2h");      // synchronises
 }
 void HIPBackend::convert_fp_data(Tensor *, Tensor *) {
     // the HIP path keeps activations fp32 (the reference CPU backend's arithmetic type): nothing to convert
@@ -43,9 +102,10 @@ void HIPBackend::sync() { check(mllm_hip_sync(stream_), "mllm_hip_sync"); }
 
 void *HIPBackend::scratch(int slot, size_t bytes) {
     if (bytes > scratch_bytes_[slot]) {
-        sync();
-        if (scratch_[slot]) check(mllm_hip_free(scratch_[slot]), "mllm_hip_free");
-        check(mllm_hip_alloc(&scratch_[slot], bytes), "mllm_hip_alloc");
+        // in-order stream: the old block is freed behind the work that still reads it
+        if (scratch_[slot]) check(mllm_hip_pool_free(scratch_[slot], stream_), "mllm_hip_pool_free");
+        bytes += bytes / 4;
+        check(mllm_hip_pool_alloc(&scratch_[slot], bytes, stream_), "mllm_hip_pool_alloc");
         scratch_bytes_[slot] = bytes;
     }
     return scratch_[slot];
@@ -53,53 +113,138 @@ void *HIPBackend::scratch(int slot, size_t bytes) {
 static void upload_luts(HIPBackend *b, void **g, void **q) {
     std::vector<uint16_t> hg(65536), hq(65536);
     HIPBackend::check(mllm_hip_build_act_luts(hg.data(), hq.data()), "mllm_hip_build_act_luts");
-    HIPBackend::check(mllm_hip_alloc(g, 65536 * 2), "mllm_hip_alloc");
-    HIPBackend::check(mllm_hip_alloc(q, 65536 * 2), "mllm_hip_alloc");
-    HIPBackend::check(mllm_hip_h2d(*g, hg.data(), 65536 * 2, b->stream()), "mllm_hip_h2d");
-    HIPBackend::check(mllm_hip_h2d(*q, hq.data(), 65536 * 2, b->stream()), "mllm_hip_h2d");
-    b->sync();
+    *g = b->dev_alloc(65536 * 2);
+    *q = b->dev_alloc(65536 * 2);
+    b->upload(*g, hg.data(), 65536 * 2);
+    b->upload(*q, hq.data(), 65536 * 2);
 }
 const uint16_t *HIPBackend::gelu_lut() { if (!lut_gelu_) upload_luts(this, &lut_gelu_, &lut_qgelu_); return (const uint16_t *)lut_gelu_; }
 const uint16_t *HIPBackend::quickgelu_lut() { if (!lut_qgelu_) upload_luts(this, &lut_gelu_, &lut_qgelu_); return (const uint16_t *)lut_qgelu_; }
 
-// Weights go file -> pinned-free host staging -> HBM without a host tensor staying alive (precedent OpenCLBackend.cpp:928-980: map, fread, unmap)
+// ---- host shadows ---------------------------------------------------------------------------------------------------------------------------------------------
+void HIPBackend::remember_host(void *handle, const float *v, size_t n) { shadows_[handle].assign(v, v + n); }
+const std::vector<float> &HIPBackend::host_floats(const std::shared_ptr<Tensor> &t) {
+    const void *h = t->device_memory().handle;
+    auto it = shadows_.find(h);
+    if (it != shadows_.end() && it->second.size() >= (size_t)t->count()) return it->second;
+    if (t->dtype() != MLLM_TYPE_F32) throw std::runtime_error("HIPBackend::host_floats: fp32 tensors only: " + t->name());
+    std::vector<float> v((size_t)t->count());
+    if (!v.empty()) check(mllm_hip_d2h(v.data(), h, v.size() * 4, stream_), "mllm_hip_d2h");
+    return shadows_[h] = std::move(v);
+}
+
+// ---- shared Q4_0 tables and rotary tables -----------------------------------------------------------------------------------------------------------------------
+std::shared_ptr<HIPQ40Table> HIPBackend::q40_table(AbstructLoader &loader, const std::string &name, int rows, int cols) {
+    auto it = q40_by_name_.find(name);
+    if (it != q40_by_name_.end()) return it->second;
+    auto t = std::make_shared<HIPQ40Table>();
+    t->rows = rows; t->cols = cols;
+    t->raw.setName(name);
+    t->raw.setBackend(this);
+    t->raw.reshape(1, 1, rows, cols);
+    t->raw.setDtype(MLLM_TYPE_Q4_0);
+    t->raw.alloc();
+    loader.load(&t->raw);
+    const int64_t nblk = (int64_t)rows * (cols / 32);
+    t->qs = dev_alloc((size_t)nblk * 16);
+    t->d = dev_alloc((size_t)nblk * 2);
+    check(mllm_hip_repack_q40(t->raw.device_memory().handle, (uint8_t *)t->qs, (uint16_t *)t->d, nblk, stream_), "mllm_hip_repack_q40");
+    q40_by_name_[name] = t;
+    q40_by_handle_[t->raw.device_memory().handle] = t;
+    return t;
+}
+std::shared_ptr<HIPQ40Table> HIPBackend::q40_table_at(const void *raw_handle) const {
+    auto it = q40_by_handle_.find(raw_handle);
+    return it == q40_by_handle_.end() ? nullptr : it->second;
+}
+
+HIPBackend::RopeTables HIPBackend::mrope_tables(const std::shared_ptr<Tensor> &position_ids, float theta, int D, const std::vector<int> &section) {
+    const void *h = position_ids->device_memory().handle;
+    const int S = position_ids->dimension(), half = D / 2;
+    if (mrope_key_.pos == h && mrope_key_.serial == forward_serial_ && mrope_key_.theta == theta && mrope_key_.D == D && mrope_key_.section == section && mrope_.S == S) return mrope_;
+    const std::vector<float> &pos = host_floats(position_ids);      // [3][1][1][S] in BSHD memory = 3 rows of S
+    if ((int)pos.size() < 3 * S) throw std::runtime_error("MULTIMODALROPE: position_ids must be [3,1,1,S]");
+    std::vector<float> s((size_t)S * half), c((size_t)S * half);
+    check(mllm_hip_mrope_table(theta, D, pos.data(), S, section.data(), (int)section.size(), s.data(), c.data()), "mllm_hip_mrope_table");
+    const size_t bytes = (size_t)2 * S * half * 4;
+    if (bytes > mrope_bytes_) {
+        if (mrope_dev_) check(mllm_hip_pool_free(mrope_dev_, stream_), "mllm_hip_pool_free");
+        mrope_bytes_ = bytes * 2;
+        check(mllm_hip_pool_alloc(&mrope_dev_, mrope_bytes_, stream_), "mllm_hip_pool_alloc");
+    }
+    float *ds = (float *)mrope_dev_, *dc = ds + (size_t)S * half;
+    upload(ds, s.data(), s.size() * 4);
+    upload(dc, c.data(), c.size() * 4);
+    mrope_key_.pos = h; mrope_key_.serial = forward_serial_; mrope_key_.theta = theta; mrope_key_.D = D; mrope_key_.section = section;
+    mrope_ = RopeTables{ds, dc, S, half};
+    return mrope_;
+}
+void HIPBackend::set_vision_tables(void *angles_handle, const float *sin, const float *cos, int N, int half) { vision_[angles_handle] = RopeTables{sin, cos, N, half}; }
+bool HIPBackend::vision_tables(const void *angles_handle, RopeTables *out) const {
+    auto it = vision_.find(angles_handle);
+    if (it == vision_.end()) return false;
+    *out = it->second;
+    return true;
+}
+
+// Weights go file -> the library's pinned double buffer -> HBM (mllm_hip_upload) straight from a read-only map of the .mllm; no host tensor stays alive
+// (precedent OpenCLBackend.cpp:928-980: map the buffer, fread into it, unmap)
 bool HIPBackend::load_from_file(Tensor *tensor, ParamLoader *loader) {
-    ParamMetadata md = loader->getParamMetadata(tensor->name());
-    if (md.size == 0) return true;
     if (tensor->device_memory().handle == nullptr) return false;      // load() before alloc(): let ParamLoader take its default path
-    FILE *fp = loader->getInputStream();
-    if (!fp) return false;
-    std::vector<uint8_t> buf((size_t)md.size);
-    fseek(fp, (long)md.offset, SEEK_SET);
-    if (fread(buf.data(), 1, buf.size(), fp) != buf.size()) return false;
-    check(mllm_hip_h2d(tensor->device_memory().handle, buf.data(), buf.size(), stream_), "mllm_hip_h2d");
-    sync();
+    ParamMetadata md{0, 0};
+    try { md = loader->getParamMetadata(tensor->name()); } catch (const std::exception &) { return false; }
+    if (md.size == 0) return true;
+    if (md.size != tensor->cntSize()) throw std::runtime_error("HIPBackend::load_from_file: size of '" + tensor->name() + "' in the file differs from what the Op expects");
+    const std::string path = loader->getParamPath();
+    auto it = maps_.find(path);
+    if (it == maps_.end()) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); return false; }
+        void *p = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) return false;
+        it = maps_.emplace(path, std::make_pair(p, (size_t)st.st_size)).first;
+    }
+    if (md.offset + md.size > it->second.second) throw std::runtime_error("HIPBackend::load_from_file: '" + tensor->name() + "' lies outside the file");
+    upload(tensor->device_memory().handle, (const char *)it->second.first + md.offset, (size_t)md.size);
     tensor->forceResetHostPointer(nullptr);
     return true;
 }
 
 Op *HIPBackend::opCreate(const OpParam &op_param, std::string name, int) {
-    auto it = creators_.find((OpType)(int)op_param.at("type"));
-    return it == creators_.end() ? nullptr : it->second(this, op_param, name);
+    const OpType type = (OpType)(int)op_param.at("type");
+    auto it = creators_.find(type);
+    Op *op = it == creators_.end() ? nullptr : it->second(this, op_param, name);
+    if (!op) {
+        bool seen = false;
+        for (auto &r : refused_) seen = seen || (r.first == (int)type && r.second == name);
+        if (!seen) refused_.emplace_back((int)type, name);
+    }
+    return op;
 }
 TensorFunction *HIPBackend::funcCreate(TensorFuncType) { throw std::runtime_error("HIPBackend: the legacy TensorFunction path is not used (OpenCLBackend throws too)"); }
 std::vector<Tensor> HIPBackend::runLayer(Layer *, std::vector<Tensor>, int) { throw std::runtime_error("runLayer is the QNN path"); }
 
 std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::vector<std::string> out_names, bool in_place) {
     Module *module = inputs.empty() ? Module::llm_model_ptr : inputs[0].module();
+    // fact 2: host-side scalar inputs go back to the CPU backend before anything reads them (the caller's Tensor shares the impl, so the model's own
+    // `dataAt` on it works again); done in the trace passes too, where the model code runs on the dummy inputs
+    if (auto *hop = dynamic_cast<HIPOp *>(op); hop && hop->host_inputs())
+        for (auto &input : inputs)
+            if (input.backend() && input.backend()->type() != MLLM_CPU) input.to(MLLM_CPU);
     static map<string, shared_ptr<Tensor>> empty_activation_tensors;
     map<string, shared_ptr<Tensor>> &activation_tensors = module ? module->activation_tensors : empty_activation_tensors;
-    if (module && module->doTrace) {      // trace / load pass: named activation tensors, setUp only (CPUBackend.cpp:318-349)
-        if (module->tracedFlag) {
-            vector<Tensor> results = {};
-            for (auto &name : out_names) results.push_back(*activation_tensors[name]);
-            return results;
-        }
-        for (auto &input : inputs) {
-            if (input.shouldInGraphs() && activation_tensors.find(input.name()) == activation_tensors.end()) {
-                activation_tensors[input.name()] = std::make_shared<Tensor>(op->backend());
-                activation_tensors[input.name()]->setName(input.name());
-                activation_tensors[input.name()]->setModule(module);
+    if (module && module->doTrace) {      // trace / load pass (CPUBackend.cpp:318-349): named placeholder tensors flow through the model code, nothing is computed.
+        // Device Ops plan nothing ahead of time (outputs come from the stream-ordered pool per call), so setUp is not called on the placeholders.
+        vector<Tensor> results = {};
+        if (!module->tracedFlag) {
+            for (auto &input : inputs) {
+                if (input.shouldInGraphs() && activation_tensors.find(input.name()) == activation_tensors.end()) {
+                    activation_tensors[input.name()] = std::make_shared<Tensor>(op->backend());
+                    activation_tensors[input.name()]->setName(input.name());
+                    activation_tensors[input.name()]->setModule(module);
+                }
             }
         }
         for (const auto &out_name : out_names) {
@@ -108,18 +253,11 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
                 activation_tensors[out_name]->setName(out_name);
                 activation_tensors[out_name]->setModule(module);
             }
+            results.push_back(*activation_tensors[out_name]);
         }
-        vector<shared_ptr<Tensor>> inPtrs;
-        for (auto &input : inputs)
-            inPtrs.push_back(input.shouldInGraphs() ? activation_tensors[input.name()] : std::shared_ptr<Tensor>(&input, [](Tensor *) {}));
-        vector<shared_ptr<Tensor>> outPtrs = {};
-        for (auto &name : out_names) outPtrs.push_back(activation_tensors[name]);
-        op->setUp(inPtrs, outPtrs);
-        vector<Tensor> results = {};
-        for (auto &name : out_names) results.push_back(*activation_tensors[name]);
         return results;
     }
-    // run pass: non-owning input handles, fresh output shells named out-<opname>, reshape -> setUp (allocates on the device) -> execute
+    // run pass: non-owning input handles, fresh output shells named as the caller asks, reshape -> setUp (allocates from the pool / makes views) -> execute
     vector<shared_ptr<Tensor>> input_tensors;
     for (auto &input : inputs) input_tensors.push_back(std::shared_ptr<Tensor>(&input, [](Tensor *) {}));
     vector<shared_ptr<Tensor>> out_tensors;
@@ -127,6 +265,7 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
         for (const auto &out_name : out_names) {
             auto out_tensor = std::make_shared<Tensor>(op->backend());
             out_tensor->setName(out_name);
+            out_tensor->setModule(module);
             out_tensors.push_back(out_tensor);
         }
     } else {
@@ -138,6 +277,7 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
     op->reshape(input_tensors, out_tensors);
     op->setUp(input_tensors, out_tensors);
     op->execute(input_tensors, out_tensors);
+    ++ops_run_;
     vector<Tensor> results;
     for (const auto &out_tensor : out_tensors) results.push_back(*out_tensor);
     return results;
@@ -155,6 +295,7 @@ std::vector<Tensor> HIPBackend::runForward(Module *module, std::vector<Tensor> i
         Module::llm_model_ptr = module;
         if (module->prefilling_token_size_ == 0) module->prefilling_token_size_ = inputs[0].sequence() * inputs[0].batch();
         else if (module->decoding_token_size_ == 0) module->decoding_token_size_ = inputs[0].sequence() * inputs[0].batch();
+        ++forward_serial_;
         time_start = mllm_time_us();
     }
     auto output = module->Forward(inputs, args);
@@ -165,7 +306,11 @@ std::vector<Tensor> HIPBackend::runForward(Module *module, std::vector<Tensor> i
     return output;
 }
 
-class HIPBackendCreatorReg {};
 void registerHIPBackendCreator() { InsertBackendCreatorMap(MLLM_HIP_BACKEND_TYPE, std::make_shared<HIPBackendCreator>()); }
+HIPBackend *installHIPBackend(int device) {
+    auto &slot = Backend::global_backends[MLLM_HIP_BACKEND_TYPE];
+    if (!slot) slot = std::make_unique<HIPBackend>(device);
+    return static_cast<HIPBackend *>(slot.get());
+}
 
 }  // namespace mllm

@@ -2,12 +2,23 @@
 //
 // This is what a maintainer of yirongjie/mllm adds as mllm/backends/hip/ (structural twin of mllm/backends/opencl/OpenCLBackend.{hpp,cpp}).  It includes only
 // the reference's own headers (mllm/Backend.hpp:32-130, mllm/Op.hpp:20-148, mllm/Tensor.hpp, mllm/Module.hpp) and include/mllm_hip.h, and is compiled in this
-// repository ONLY as test infrastructure: oracle/Makefile.ref builds it against /root/reference/mllm where that tree exists (tests/test_integration_build.py),
-// to prove that every signature below matches the interface it plugs into.  Nothing reference-built enters the product library.
+// repository ONLY as test infrastructure: oracle/Makefile.ref builds it against /root/reference/mllm where that tree exists, links it with drivers that run the
+// reference's own Module graphs on it (oracle/ref_drivers/ref_hip_*.cpp) and the GPU suite executes those (tests/test_gpu_adapter.py).  Nothing reference-built
+// enters the product library.
 //
 // BackendType: the enum (mllm/Types.hpp:34-39) has no free value at this snapshot and the core gates device tensors on MLLM_OPENCL (mllm/TensorImpl.hpp:88,106).
 // Upstream, a maintainer adds MLLM_HIP and widens the two tests; compiled out of tree the adapter takes its slot from MLLM_HIP_BACKEND_TYPE (default: the
 // OpenCL slot, the one the core already treats as "on device").
+//
+// Three facts about the frontend shape this file (all verified in the reference's source):
+//  1. TensorImpl::to(CPU) calls Backend::free_device on whatever handle the tensor holds, owner or view (mllm/TensorImpl.hpp:171-189), and the destructor frees
+//     what it "owns" (:134-144).  Device blocks are therefore reference-counted here: every TensorImpl that points into a block holds one reference (views are
+//     handed out through view_of(), which retains), every Op that keeps a raw pointer holds one, and free_device() is "release".
+//  2. Layer::run migrates every input to the layer's backend before runOp sees it (mllm/Layer.hpp:159-163), and the models read some of those tensors on the
+//     host afterwards (`inputs[1].dataAt<float>` right behind `rot_pos_emb(inputs[1])`, models/qwen2_vl/modeling_qwen2_vl.hpp:179-182).  Ops whose inputs are such
+//     host-side scalars say so through HIPOp::host_inputs(); runOp hands those tensors back to the CPU backend before anything else.
+//  3. Small host-made tensors (token ids, position ids, grids) reach the device through copy_from_host; the backend keeps a host shadow of every small upload so an
+//     Op that needs the values on the host (the rotary tables are libm sinf / cosf, F_WHERE's output shape depends on the data) reads them without a D2H sync.
 #ifndef MLLM_HIP_BACKEND_HPP
 #define MLLM_HIP_BACKEND_HPP
 
@@ -17,6 +28,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "Backend.hpp"
@@ -34,6 +46,25 @@ namespace mllm {
 
 class Module;
 class Layer;
+class HIPBackend;
+
+// base of every HIP Op: the backend accessor and the "my inputs are host-side scalars" flag (fact 2 above)
+class HIPOp : public Op {
+public:
+    HIPOp(Backend *bn, const std::string &name) : Op(bn, name) {}
+    virtual bool host_inputs() const { return false; }
+
+protected:
+    HIPBackend *hb() const;
+};
+
+// a Q4_0 table that two Ops share (EMBEDDING and the PARAMETER of the tied lm_head read the same `*.embed_tokens.weight`): the file's 18-byte blocks (`raw`, what a
+// view of the Parameter points at) and the nibble / scale planes the kernels read (mllm_hip_repack_q40)
+struct HIPQ40Table {
+    Tensor raw;
+    void *qs = nullptr, *d = nullptr;
+    int rows = 0, cols = 0;
+};
 
 class HIPBackend final : public Backend {
 public:
@@ -42,9 +73,9 @@ public:
     explicit HIPBackend(int device = 0);
     ~HIPBackend() override = default;
 
-    // ---- device memory (mllm/Backend.hpp:60-73): DeviceMemory{handle, MEM_TYPE_GENERIC, size_in_bytes} (mllm/TensorImpl.hpp:23-45) ----
+    // ---- device memory (mllm/Backend.hpp:60-73): DeviceMemory{handle, MEM_TYPE_GENERIC, size_in_bytes} (mllm/TensorImpl.hpp:23-45) on a stream-ordered pool ----
     void alloc_device(DeviceMemory &mem, DataType dtype) override;
-    void free_device(DeviceMemory &mem) override;
+    void free_device(DeviceMemory &mem) override;      // releases ONE reference to the block `mem.handle` points into
     void copy_from_host(const DeviceMemory &dest, const void *src) override;
     void copy_to_host(void *dest, const DeviceMemory &src) override;
     void convert_fp_data(Tensor *src, Tensor *dest) override;
@@ -61,20 +92,68 @@ public:
 
     void *stream() const { return stream_; }        // one in-order stream; synchronised only at the end of the outermost forward and in copy_to_host
     void sync();
+
+    // ---- reference-counted device blocks (fact 1) ----
+    void *dev_alloc(size_t bytes);                   // Op-owned memory (weights' repacks, KV slabs, tables): one reference, dropped by dev_release
+    void dev_release(void *p);
+    void retain(void *p);                            // one more holder of the block p points into
+    // makes `view` a tensor on this backend that points at `handle` (somewhere inside a live block) and holds its own reference
+    void view_of(const std::shared_ptr<Tensor> &view, void *handle, size_t bytes);
+
     // device scratch that grows on demand (activation quantisation planes, packed GEMM operands); valid until the next call on the same slot
     void *scratch(int slot, size_t bytes);
     const uint16_t *gelu_lut();
     const uint16_t *quickgelu_lut();
+    // host bytes -> device through the library's pinned staging (returns when `src` may be reused)
+    void upload(void *dst, const void *src, size_t bytes);
+
+    // ---- host shadows of small device tensors (fact 3) ----
+    // the fp32 values of a small tensor that lives on this backend: the shadow of its upload, else one D2H (which synchronises)
+    const std::vector<float> &host_floats(const std::shared_ptr<Tensor> &t);
+    void remember_host(void *handle, const float *v, size_t n);
+
+    // ---- state shared between Ops ----
+    std::shared_ptr<HIPQ40Table> q40_table(AbstructLoader &loader, const std::string &name, int rows, int cols);
+    std::shared_ptr<HIPQ40Table> q40_table_at(const void *raw_handle) const;
+    // sin / cos device tables of the current M-RoPE position ids, built once per forward and shared by every MULTIMODALROPE Op (2 per layer)
+    struct RopeTables { const float *sin = nullptr, *cos = nullptr; int S = 0, half = 0; };
+    RopeTables mrope_tables(const std::shared_ptr<Tensor> &position_ids, float theta, int D, const std::vector<int> &section);
+    // sin / cos of a VISIONROPE angle table, keyed by the table's device handle (set by the VISIONROPE Op that made it)
+    void set_vision_tables(void *angles_handle, const float *sin, const float *cos, int N, int half);
+    bool vision_tables(const void *angles_handle, RopeTables *out) const;
+
+    // ---- bookkeeping the drivers print: which creators refused (=> CPU fallback), how many Ops ran here ----
+    const std::vector<std::pair<int, std::string>> &refused() const { return refused_; }
+    long ops_run() const { return ops_run_; }
+    size_t live_blocks() const { return blocks_.size(); }
 
     static void check(int rc, const char *what);
 
 private:
+    struct Block { size_t size; int refs; bool pooled; };
+    std::map<uintptr_t, Block>::iterator block_of(const void *p);
+    void release(const void *p);
+
     std::map<OpType, OpCreator> creators_;
     void *stream_ = nullptr;
-    void *scratch_[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes_[4] = {0, 0, 0, 0};
+    std::map<uintptr_t, Block> blocks_;
+    void *scratch_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes_[6] = {0, 0, 0, 0, 0, 0};
     void *lut_gelu_ = nullptr, *lut_qgelu_ = nullptr;
+    std::unordered_map<const void *, std::vector<float>> shadows_;
+    std::map<std::string, std::shared_ptr<HIPQ40Table>> q40_by_name_;
+    std::unordered_map<const void *, std::shared_ptr<HIPQ40Table>> q40_by_handle_;
+    struct MropeKey { const void *pos = nullptr; long serial = -1; float theta = 0; int D = 0; std::vector<int> section; } mrope_key_;
+    void *mrope_dev_ = nullptr;
+    size_t mrope_bytes_ = 0;
+    RopeTables mrope_;
+    std::unordered_map<const void *, RopeTables> vision_;
+    std::unordered_map<std::string, std::pair<void *, size_t>> maps_;      // .mllm path -> read-only mmap (load_from_file)
+    long forward_serial_ = 0, ops_run_ = 0;
+    std::vector<std::pair<int, std::string>> refused_;
 };
+
+inline HIPBackend *HIPOp::hb() const { return static_cast<HIPBackend *>(backend_); }
 
 class HIPBackendCreator : public BackendCreator {
 public:
@@ -82,6 +161,9 @@ public:
 };
 // InsertBackendCreatorMap(<slot>, HIPBackendCreator) -- precedent registerOpenCLBackendCreator, mllm/backends/opencl/OpenCLBackend.cpp:982-984
 void registerHIPBackendCreator();
+// what Module::initBackend's new `case MLLM_HIP` does (mllm/Module.hpp:158-188): put the singleton into Backend::global_backends; the out-of-tree drivers call it
+// before model.to(<slot>) because initBackend's switch cannot be extended from outside
+HIPBackend *installHIPBackend(int device = 0);
 
 // raw device pointer of a tensor that lives on this backend
 inline void *dptr(const std::shared_ptr<Tensor> &t) { return t->device_memory().handle; }

@@ -1,6 +1,9 @@
-// integration/hip/HIPOps.cpp -- the HIP*Op classes: mllm::Op subclasses whose execute() is one call into the C ABI (include/mllm_hip.h).
-// Each class names the CPU Op it stands in for (mllm/backends/cpu/op/...) and the Layer that creates it with its OpParam keys (mllm/Layer.hpp).
-// Shapes a launcher does not cover are refused at opCreate time (nullptr => CPU fallback, mllm/Layer.hpp:214-218), never at execute.
+// integration/hip/HIPOps.cpp -- the HIP*Op classes: mllm::Op subclasses whose execute() is one or two calls into the C ABI (include/mllm_hip.h).
+// Each class names the CPU Op it stands in for (mllm/backends/cpu/op/...) and the Layer / Tensor function that creates it with its OpParam keys (mllm/Layer.hpp,
+// mllm/Tensor.cpp).  Shapes a launcher does not cover are refused at opCreate time (nullptr => CPU fallback, mllm/Layer.hpp:214-218) or, for what is only known
+// with the tensors in hand, thrown from reshape() before anything is launched -- never at execute.
+// Device layout: every activation is the reference's BSHD tensor in memory order [batch][sequence][head][dimension], contiguous, fp32 (fp16 for the KV slabs);
+// Tensor views (F_VIEW, F_CLIP, F_TRANPOSE, KVCACHE, PARAMETER outputs) are reference-counted aliases of their producer's block (HIPBackend::view_of).
 // Compiled against the reference's headers by oracle/Makefile.ref (test infrastructure; see HIPBackend.hpp).
 #include <cmath>
 #include <cstring>
@@ -12,64 +15,75 @@ namespace mllm {
 
 namespace {
 
-inline HIPBackend *hb(Backend *b) { return static_cast<HIPBackend *>(b); }
+using TensorList = vector<shared_ptr<Tensor>>;
+
 inline int geti(const OpParam &p, const char *k, int def = 0) { auto it = p.find(k); return it == p.end() ? def : (int)it->second; }
 inline float getf(const OpParam &p, const char *k, float def = 0.f) { auto it = p.find(k); return it == p.end() ? def : it->second; }
 inline int rows_of(const shared_ptr<Tensor> &t) { return t->batch() * t->sequence() * t->head(); }       // BSHD: rows of `dimension()` values
+inline size_t elem_bytes(DataType dt) { return dt == MLLM_TYPE_F16 ? 2 : 4; }
+inline void need(bool ok, const char *what) { if (!ok) throw std::runtime_error(std::string("mllm_hip adapter: ") + what); }
 #define HIPCHK(call) HIPBackend::check((call), #call)
 
 // loads `<op>.weight` / `<op>.bias` onto the device in the file's storage dtype (ParamLoader::load -> Backend::load_from_file fast path)
 void load_tensor(Tensor &t, Backend *bn, AbstructLoader &loader, const string &name, int rows, int cols) {
+    const DataType dt = loader.getDataType(name);
+    if (dt == MLLM_TYPE_COUNT) throw std::runtime_error("mllm_hip adapter: tensor '" + name + "' is not in the weight file");
     t.setName(name);
     t.setBackend(bn);
     t.reshape(1, 1, rows, cols);
-    t.setDtype(loader.getDataType(name));
+    t.setDtype(dt);
     t.alloc();
-    loader.load(&t);
+    if (!loader.load(&t)) throw std::runtime_error("mllm_hip adapter: loading '" + name + "' failed");
+}
+// output = fp32 BSHD tensor of the given shape, allocated from the pool (what Op::setUp does, mllm/Op.hpp:63-70, spelled out so that 5-D inputs do not leak their ctype)
+void alloc_f32(const shared_ptr<Tensor> &out) {
+    out->setDtype(MLLM_TYPE_F32);
+    out->alloc();
 }
 
 // ---- LINEAR: CPULinear (op/CPULinear.cpp:23-234); params in_features, out_features, bias (Layer.hpp:230-234) -----------------------------------------------
-class HIPLinearOp final : public Op {
+class HIPLinearOp final : public HIPOp {
 public:
-    HIPLinearOp(Backend *bn, const string &name, int in, int out, bool bias) : Op(bn, name), in_(in), out_(out), has_bias_(bias) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    HIPLinearOp(Backend *bn, const string &name, int in, int out, bool bias) : HIPOp(bn, name), in_(in), out_(out), has_bias_(bias) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs[0]->dimension() == in_, "LINEAR: input width differs from in_features");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), out_);
         return MLLM_NO_ERROR;
     }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode load(AbstructLoader &loader) override {
         load_tensor(weight_, backend_, loader, name() + ".weight", out_, in_);
         const DataType dt = weight_.dtype();
-        if (dt != MLLM_TYPE_Q4_K && dt != MLLM_TYPE_Q4_0 && dt != MLLM_TYPE_F32) throw std::runtime_error("HIPLinearOp: weight dtype not on the hot path: " + name());
+        if (dt != MLLM_TYPE_Q4_K && dt != MLLM_TYPE_Q4_0 && dt != MLLM_TYPE_F32) throw std::runtime_error("HIPLinearOp: weight dtype not on the hot path: " + name());      // precedent OpenCLLinearOp.cpp:26-52
         if (dt == MLLM_TYPE_Q4_K) {      // resident Linears are packed once for the M >= 16 GEMM (mllm_hip_q4k_prepack)
-            const size_t pb = mllm_hip_q4k_wpack_bytes(out_, in_);
-            HIPCHK(mllm_hip_alloc(&packed_, pb));
-            HIPCHK(mllm_hip_q4k_prepack(weight_.device_memory().handle, out_, in_, packed_, hb(backend_)->stream()));
+            packed_ = hb()->dev_alloc(mllm_hip_q4k_wpack_bytes(out_, in_));
+            HIPCHK(mllm_hip_q4k_prepack(weight_.device_memory().handle, out_, in_, packed_, hb()->stream()));
         } else if (dt == MLLM_TYPE_Q4_0) {  // 18-byte blocks -> nibble plane + fp16 scale plane (mllm_hip_repack_q40)
             const int64_t nblk = (int64_t)out_ * (in_ / 32);
-            HIPCHK(mllm_hip_alloc(&q40_qs_, (size_t)nblk * 16));
-            HIPCHK(mllm_hip_alloc(&q40_d_, (size_t)nblk * 2));
-            HIPCHK(mllm_hip_repack_q40(weight_.device_memory().handle, (uint8_t *)q40_qs_, (uint16_t *)q40_d_, nblk, hb(backend_)->stream()));
+            q40_qs_ = hb()->dev_alloc((size_t)nblk * 16);
+            q40_d_ = hb()->dev_alloc((size_t)nblk * 2);
+            HIPCHK(mllm_hip_repack_q40(weight_.device_memory().handle, (uint8_t *)q40_qs_, (uint16_t *)q40_d_, nblk, hb()->stream()));
         }
         if (has_bias_) load_tensor(bias_, backend_, loader, name() + ".bias", 1, out_);
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        auto *b = hb(backend_);
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        auto *b = hb();
         const int M = rows_of(inputs[0]);
+        if (M == 0) return MLLM_NO_ERROR;
         const float *bias = has_bias_ ? (const float *)bias_.device_memory().handle : nullptr;
         const float *x = (const float *)dptr(inputs[0]);
         void *y = dptr(outputs[0]);
-        const int ydt = outputs[0]->dtype() == MLLM_TYPE_F16 ? MLLM_HIP_F16 : MLLM_HIP_F32;      // fp16 when the output aliases the KV slab (Matmul.cpp:262-268)
         switch (weight_.dtype()) {
         case MLLM_TYPE_Q4_K: {
-            // activations to Q8_K planes (quantize_row_q8_K_reference), then vec_dot_q4_K_q8_K per (row, output): GEMV below 16 rows, packed GEMM from 16 on
-            uint8_t *ws = (uint8_t *)b->scratch(0, mllm_hip_linear_workspace_bytes(MLLM_HIP_Q4_K, M, in_));
+            // activations to Q8_K (quantize_row_q8_K_reference), then vec_dot_q4_K_q8_K per (row, output): GEMV below 16 rows, packed GEMM from 16 on
             if (M < 16) {
-                HIPCHK(mllm_hip_linear(weight_.device_memory().handle, MLLM_HIP_Q4_K, bias, x, y, ydt, out_, M, out_, in_, ws, b->stream()));
+                uint8_t *ws = (uint8_t *)b->scratch(0, mllm_hip_linear_workspace_bytes(MLLM_HIP_Q4_K, M, in_));
+                HIPCHK(mllm_hip_linear(weight_.device_memory().handle, MLLM_HIP_Q4_K, bias, x, y, MLLM_HIP_F32, out_, M, out_, in_, ws, b->stream()));
             } else {
                 void *xpack = b->scratch(1, mllm_hip_q4k_prepack_bytes(M, in_));
                 HIPCHK(mllm_hip_quantize_q8k_packed(x, xpack, M, in_, b->stream()));
-                HIPCHK(mllm_hip_linear_q4kp_packed(packed_, bias, xpack, y, ydt, out_, nullptr, M, out_, in_, b->stream()));
+                HIPCHK(mllm_hip_linear_q4kp_packed(packed_, bias, xpack, y, MLLM_HIP_F32, out_, nullptr, M, out_, in_, b->stream()));
             }
             break;
         }
@@ -86,10 +100,10 @@ public:
         }
         return MLLM_NO_ERROR;
     }
-    ErrorCode free(vector<shared_ptr<Tensor>>, vector<shared_ptr<Tensor>>) override {
+    ErrorCode free(TensorList, TensorList) override {
         weight_.free();
         if (has_bias_) bias_.free();
-        for (void **p : {&packed_, &q40_qs_, &q40_d_}) if (*p) { mllm_hip_free(*p); *p = nullptr; }
+        for (void **p : {&packed_, &q40_qs_, &q40_d_}) if (*p) { hb()->dev_release(*p); *p = nullptr; }
         return MLLM_NO_ERROR;
     }
 
@@ -101,57 +115,87 @@ private:
 };
 
 // ---- EMBEDDING: CPUEmbedding (op/CPUEmbedding.cpp:38-80); hidden_size, vocab_size (Layer.hpp:434-435); ids are fp32 ------------------------------------------
-class HIPEmbeddingOp final : public Op {
+class HIPEmbeddingOp final : public HIPOp {
 public:
-    HIPEmbeddingOp(Backend *bn, const string &name, int hidden, int vocab) : Op(bn, name), hidden_(hidden), vocab_(vocab) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    HIPEmbeddingOp(Backend *bn, const string &name, int hidden, int vocab) : HIPOp(bn, name), hidden_(hidden), vocab_(vocab) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
         outputs[0]->reshape(inputs[0]->batch(), 1, inputs[0]->sequence(), hidden_);
         return MLLM_NO_ERROR;
     }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode load(AbstructLoader &loader) override {
-        load_tensor(weight_, backend_, loader, name() + ".weight", vocab_, hidden_);
-        if (weight_.dtype() != MLLM_TYPE_Q4_0) throw std::runtime_error("HIPEmbeddingOp: only the Q4_0 table of *-q4_k.mllm files");
-        const int64_t nblk = (int64_t)vocab_ * (hidden_ / 32);
-        HIPCHK(mllm_hip_alloc(&qs_, (size_t)nblk * 16));
-        HIPCHK(mllm_hip_alloc(&d_, (size_t)nblk * 2));
-        HIPCHK(mllm_hip_repack_q40(weight_.device_memory().handle, (uint8_t *)qs_, (uint16_t *)d_, nblk, hb(backend_)->stream()));
+        if (loader.getDataType(name() + ".weight") != MLLM_TYPE_Q4_0) throw std::runtime_error("HIPEmbeddingOp: only the Q4_0 table of *-q4_k.mllm files: " + name());
+        table_ = hb()->q40_table(loader, name() + ".weight", vocab_, hidden_);      // shared with the tied lm_head's PARAMETER
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        HIPCHK(mllm_hip_embedding_q40((const float *)dptr(inputs[0]), (const uint8_t *)qs_, (const uint16_t *)d_, (float *)dptr(outputs[0]),
-                                      inputs[0]->batch() * inputs[0]->sequence(), hidden_, vocab_, hb(backend_)->stream()));
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        const int S = inputs[0]->batch() * inputs[0]->sequence();
+        if (S) HIPCHK(mllm_hip_embedding_q40((const float *)dptr(inputs[0]), (const uint8_t *)table_->qs, (const uint16_t *)table_->d, (float *)dptr(outputs[0]), S, hidden_, vocab_, hb()->stream()));
         return MLLM_NO_ERROR;
     }
-    // the planes also serve the tied lm_head (Tensor::mm with the transposed table, CPUMatmulFunc.hpp:86-181)
-    const void *qs() const { return qs_; }
-    const void *d() const { return d_; }
 
 private:
     int hidden_, vocab_;
+    std::shared_ptr<HIPQ40Table> table_;
+};
+
+// ---- PARAMETER: CPUParameter (op/CPUParameter.cpp; batch, seq, head, dim, Layer.hpp:904-918): hands out its weight.  The one on the hot path is the tied lm_head,
+// `lm_head()` = the Q4_0 embedding table (modeling_qwen2_vl.hpp:376,399; modeling_qwen.hpp:148-159): a view of the shared table's raw blocks -----------------------
+class HIPParameterOp final : public HIPOp {
+public:
+    HIPParameterOp(Backend *bn, const string &name, int b, int h, int s, int d) : HIPOp(bn, name), b_(b), h_(h), s_(s), d_(d) {}
+    ErrorCode reshape(TensorList, TensorList outputs) override {
+        outputs[0]->reshape(b_, h_, s_, d_);
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode load(AbstructLoader &loader) override {
+        const DataType dt = loader.getDataType(name());
+        if (dt == MLLM_TYPE_Q4_0 && b_ == 1 && h_ == 1) { table_ = hb()->q40_table(loader, name(), s_, d_); return MLLM_NO_ERROR; }
+        if (dt != MLLM_TYPE_F32) throw std::runtime_error("HIPParameterOp: Q4_0 tables and fp32 parameters only: " + name());
+        weight_.setName(name());
+        weight_.setBackend(backend_);
+        weight_.reshape(b_, h_, s_, d_);
+        weight_.setDtype(dt);
+        weight_.alloc();
+        loader.load(&weight_);
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList outputs) override {
+        Tensor &w = table_ ? table_->raw : weight_;
+        outputs[0]->setDtype(w.dtype());
+        hb()->view_of(outputs[0], w.device_memory().handle, w.cntSize());
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    int b_, h_, s_, d_;
+    std::shared_ptr<HIPQ40Table> table_;
     Tensor weight_;
-    void *qs_ = nullptr, *d_ = nullptr;
 };
 
 // ---- RMSNORM / LAYERNORM: CPURMSNorm (op/CPURMSNorm.cpp:31-136; norm_size, epsilon, add_unit_offset), CPULayerNorm (op/CPULayerNorm.cpp:49-88; norm_size, epsilon, bias) ----
-class HIPNormOp final : public Op {
+class HIPNormOp final : public HIPOp {
 public:
     HIPNormOp(Backend *bn, const string &name, bool layer, int dim, float eps, bool bias, bool unit_offset) :
-        Op(bn, name), layer_(layer), dim_(dim), eps_(eps), has_bias_(bias), unit_offset_(unit_offset) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+        HIPOp(bn, name), layer_(layer), dim_(dim), eps_(eps), has_bias_(bias), unit_offset_(unit_offset) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs[0]->dimension() == dim_, "norm: input width differs from norm_size");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode load(AbstructLoader &loader) override {
         load_tensor(weight_, backend_, loader, name() + ".weight", 1, dim_);
         if (layer_ && has_bias_) load_tensor(bias_, backend_, loader, name() + ".bias", 1, dim_);
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
         const int M = rows_of(inputs[0]);
+        if (M == 0) return MLLM_NO_ERROR;
         const float *w = (const float *)weight_.device_memory().handle;
         if (layer_) HIPCHK(mllm_hip_layernorm((const float *)dptr(inputs[0]), w, has_bias_ ? (const float *)bias_.device_memory().handle : nullptr, (float *)dptr(outputs[0]), nullptr,
-                                              nullptr, nullptr, M, dim_, eps_, hb(backend_)->stream()));
-        else HIPCHK(mllm_hip_rmsnorm((const float *)dptr(inputs[0]), w, (float *)dptr(outputs[0]), nullptr, nullptr, nullptr, M, dim_, eps_, unit_offset_ ? 1 : 0, hb(backend_)->stream()));
+                                              nullptr, nullptr, M, dim_, eps_, hb()->stream()));
+        else HIPCHK(mllm_hip_rmsnorm((const float *)dptr(inputs[0]), w, (float *)dptr(outputs[0]), nullptr, nullptr, nullptr, M, dim_, eps_, unit_offset_ ? 1 : 0, hb()->stream()));
         return MLLM_NO_ERROR;
     }
 
@@ -164,42 +208,45 @@ private:
 };
 
 // ---- ROPE (HF half-split table, CPURoPE.cpp:100-128,200-232; pose_type, rope_theta, max_position_embeddings) and MULTIMODALROPE (CPUMultimodalRoPE.cpp:84-264) ----
-// input / output [B, H, S, D] in BSHD memory order = rows of H*D per position.  The position counter h_cnt_ lives in the op (CPURoPE.cpp:510-513) and
-// clearCache() resets it; the multimodal form takes its positions from the second input, a host-side [3,1,1,S] tensor (such scalars stay on the host).
-class HIPRoPEOp final : public Op {
+// input / output [B, H, S, D] in BSHD memory order = rows of H*D per position.  The position counter h_cnt_ lives in the op (CPURoPE.cpp:510-513) and clearCache()
+// resets it; the multimodal form takes its positions from the second input, [3,1,1,S] (the host shadow of its upload, HIPBackend fact 3): the sin / cos tables of a
+// forward are built once on the host (libm sinf / cosf, as the reference) and shared by all the MULTIMODALROPE Ops of the model (HIPBackend::mrope_tables).
+class HIPRoPEOp final : public HIPOp {
 public:
     HIPRoPEOp(Backend *bn, const string &name, bool multimodal, float theta, int max_pos, std::vector<int> section) :
-        Op(bn, name), multimodal_(multimodal), theta_(theta), max_pos_(max_pos), section_(std::move(section)) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+        HIPOp(bn, name), multimodal_(multimodal), theta_(theta), max_pos_(max_pos), section_(std::move(section)) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        if (!multimodal_ && h_cnt_ + inputs[0]->sequence() > max_pos_) throw std::runtime_error("HIPRoPEOp: position beyond max_position_embeddings");
+        need(inputs[0]->batch() <= 1, "ROPE: batch 1");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        auto *b = hb(backend_);
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        auto *b = hb();
         const int S = inputs[0]->sequence(), H = inputs[0]->head(), D = inputs[0]->dimension(), half = D / 2;
-        std::vector<float> s((size_t)S * half), c((size_t)S * half);
+        if (S == 0) return MLLM_NO_ERROR;
+        const float *ds, *dc;
+        int ld_tab = half;
         if (multimodal_) {
-            std::vector<float> pos((size_t)3 * S);
-            for (int a = 0; a < 3; ++a) for (int j = 0; j < S; ++j) pos[(size_t)a * S + j] = inputs[1]->dataAt<float>(a, 0, 0, j);
-            HIPCHK(mllm_hip_mrope_table(theta_, D, pos.data(), S, section_.data(), (int)section_.size(), s.data(), c.data()));
+            const HIPBackend::RopeTables t = b->mrope_tables(inputs[1], theta_, D, section_);
+            need(t.S == S, "MULTIMODALROPE: position_ids hold a different number of positions than the input");
+            ds = t.sin; dc = t.cos;
         } else {
-            if (h_cnt_ + S > max_pos_) throw std::runtime_error("HIPRoPEOp: position beyond max_position_embeddings");
-            if (table_dim_ != D) {      // CPURoPE's static table, built once per head size
-                sin_.assign((size_t)max_pos_ * D, 0.f); cos_.assign((size_t)max_pos_ * D, 0.f);
-                HIPCHK(mllm_hip_rope_table_hf(theta_, D, max_pos_, sin_.data(), cos_.data()));
+            if (table_dim_ != D) {      // CPURoPE's static table, built once per head size and kept on the device: [max_pos][D]
+                std::vector<float> s((size_t)max_pos_ * D), c((size_t)max_pos_ * D);
+                HIPCHK(mllm_hip_rope_table_hf(theta_, D, max_pos_, s.data(), c.data()));
+                if (tab_) b->dev_release(tab_);
+                tab_ = (float *)b->dev_alloc((size_t)2 * max_pos_ * D * 4);
+                b->upload(tab_, s.data(), s.size() * 4);
+                b->upload(tab_ + (size_t)max_pos_ * D, c.data(), c.size() * 4);
                 table_dim_ = D;
             }
-            for (int j = 0; j < S; ++j) {
-                memcpy(&s[(size_t)j * half], &sin_[(size_t)(h_cnt_ + j) * D], (size_t)half * 4);
-                memcpy(&c[(size_t)j * half], &cos_[(size_t)(h_cnt_ + j) * D], (size_t)half * 4);
-            }
+            ds = tab_ + (size_t)h_cnt_ * D;
+            dc = tab_ + (size_t)max_pos_ * D + (size_t)h_cnt_ * D;
+            ld_tab = D;
         }
-        float *ds = (float *)b->scratch(2, (size_t)2 * S * half * 4), *dc = ds + (size_t)S * half;
-        HIPCHK(mllm_hip_h2d(ds, s.data(), s.size() * 4, b->stream()));
-        HIPCHK(mllm_hip_h2d(dc, c.data(), c.size() * 4, b->stream()));
-        b->sync();      // the host vectors go out of scope
-        const int odt = outputs[0]->dtype() == MLLM_TYPE_F16 ? MLLM_HIP_F16 : MLLM_HIP_F32;      // K straight into the fp16 cache slab
-        HIPCHK(mllm_hip_rope_apply((const float *)dptr(inputs[0]), (int64_t)H * D, ds, dc, half, dptr(outputs[0]), odt, (int64_t)H * D, S, H, D, b->stream()));
+        HIPCHK(mllm_hip_rope_apply((const float *)dptr(inputs[0]), (int64_t)H * D, ds, dc, ld_tab, dptr(outputs[0]), MLLM_HIP_F32, (int64_t)H * D, S, H, D, b->stream()));
         if (!multimodal_) h_cnt_ += S;
         return MLLM_NO_ERROR;
     }
@@ -211,34 +258,106 @@ private:
     int max_pos_;
     std::vector<int> section_;
     int h_cnt_ = 0, table_dim_ = 0;
-    std::vector<float> sin_, cos_;
+    float *tab_ = nullptr;
 };
 
-// ---- KVCACHE: CPUKVCache (op/CPUKVCache.cpp:10-131,253-275; head, hidden, n_rep, cache_max, fa2).  FlashAttention2 mode: fp16 slab, n_rep = 1 -----------------
-// The slab [cache_max][H*D] fp16 is the op's; execute() appends the S new rows at cache_seq_len_ (fp32 -> fp16 like the fp16 store of mat_mul) and hands out a
-// non-owning view of rows [0, T + S) (TensorImpl::owns_device_memory_ = false keeps the view from freeing the slab, mllm/TensorImpl.hpp:51,137).
-class HIPKVCacheOp final : public Op {
+// ---- VISIONROPE: CPUVisionRoPE (op/CPUVisionRoPE.cpp:12-147; dim, spatial_merge_size): grid (t, h, w) -> the angle table [1,1,N,dim].  The grid is a host-side
+// scalar tensor the model reads again right behind this layer (modeling_qwen2_vl.hpp:179-182) => host_inputs().  Besides the angles (the layer's contract) the Op
+// uploads their libm sin / cos, which is what F_APPLY_VISIOROPE evaluates per use (CPUVisionRoPEFunc.hpp:21-60), and files them under the output's handle ----------
+class HIPVisionRoPEOp final : public HIPOp {
 public:
-    HIPKVCacheOp(Backend *bn, const string &name, int cache_max) : Op(bn, name), cache_max_(cache_max) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        if (cache_seq_len_ + inputs[0]->sequence() > cache_max_) { fprintf(stderr, "KVCache overflow: %d + %d > %d\n", cache_seq_len_, inputs[0]->sequence(), cache_max_); exit(1); }      // CPUKVCache.cpp:121-126
+    HIPVisionRoPEOp(Backend *bn, const string &name, int dim, int merge) : HIPOp(bn, name), dim_(dim), merge_(merge) {}
+    bool host_inputs() const override { return true; }
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        for (int i = 0; i < 3; ++i) g_[i] = (int)inputs[0]->dataAt<float>(0, 0, 0, i);
+        need(g_[0] > 0 && g_[1] > 0 && g_[2] > 0 && g_[1] % merge_ == 0 && g_[2] % merge_ == 0, "VISIONROPE: grid_thw must be positive multiples of the merge size");
+        outputs[0]->reshape(1, 1, g_[0] * g_[1] * g_[2], 2 * (dim_ / 2));
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList, TensorList outputs) override {
+        auto *b = hb();
+        const int N = g_[0] * g_[1] * g_[2], rd = 2 * (dim_ / 2);
+        std::vector<float> ang((size_t)N * rd), s((size_t)N * rd), c((size_t)N * rd);
+        HIPCHK(mllm_hip_vision_rope_angles(g_[0], g_[1], g_[2], merge_, rd, ang.data()));
+        HIPCHK(mllm_hip_vision_rope_table(g_[0], g_[1], g_[2], merge_, rd, s.data(), c.data()));
+        if ((size_t)N * rd > cap_) {
+            if (tab_) b->dev_release(tab_);
+            cap_ = (size_t)N * rd;
+            tab_ = (float *)b->dev_alloc(2 * cap_ * 4);
+        }
+        b->upload(dptr(outputs[0]), ang.data(), ang.size() * 4);
+        b->upload(tab_, s.data(), s.size() * 4);
+        b->upload(tab_ + cap_, c.data(), c.size() * 4);
+        b->set_vision_tables(dptr(outputs[0]), tab_, tab_ + cap_, N, rd);
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    int dim_, merge_, g_[3] = {0, 0, 0};
+    float *tab_ = nullptr;
+    size_t cap_ = 0;
+};
+// F_APPLY_VISIOROPE: CPUVisionRoPEFuncFunction (op/CPUVisionRoPEFunc.hpp): x [1,H,N,D], angles [1,1,N,D/2] -> rotate-half with sin / cos of the angles
+class HIPApplyVisionRoPEOp final : public HIPOp {
+public:
+    HIPApplyVisionRoPEOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs[0]->batch() == 1 && inputs[1]->sequence() == inputs[0]->sequence() && inputs[1]->dimension() == inputs[0]->dimension() / 2 && inputs[0]->dtype() == MLLM_TYPE_F32,
+             "F_APPLY_VISIOROPE: x [1,H,N,D] fp32 with angles [1,1,N,D/2]");
+        outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        auto *b = hb();
+        const int S = inputs[0]->sequence(), H = inputs[0]->head(), D = inputs[0]->dimension(), half = D / 2;
+        HIPBackend::RopeTables t;
+        if (!b->vision_tables(dptr(inputs[1]), &t) || t.S != S || t.half != half) {      // angles that did not come from the VISIONROPE Op: sin / cos on the host, once per call
+            const std::vector<float> &ang = b->host_floats(inputs[1]);
+            std::vector<float> s(ang.size()), c(ang.size());
+            for (size_t i = 0; i < ang.size(); ++i) { s[i] = std::sin(ang[i]); c[i] = std::cos(ang[i]); }
+            float *ds = (float *)b->scratch(4, ang.size() * 8), *dc = ds + ang.size();
+            b->upload(ds, s.data(), s.size() * 4);
+            b->upload(dc, c.data(), c.size() * 4);
+            t = HIPBackend::RopeTables{ds, dc, S, half};
+        }
+        HIPCHK(mllm_hip_rope_apply((const float *)dptr(inputs[0]), (int64_t)H * D, t.sin, t.cos, half, dptr(outputs[0]), MLLM_HIP_F32, (int64_t)H * D, S, H, D, b->stream()));
+        return MLLM_NO_ERROR;
+    }
+};
+
+// ---- KVCACHE: CPUKVCache (op/CPUKVCache.cpp:10-131,253-275; head, hidden, n_rep, cache_max, fa2).  FlashAttention2 mode: n_rep is forced to 1 (:41-43) and the
+// slab is fp16 (KVCache_TYPE = 16, Types.hpp:26) -----------------------------------------------------------------------------------------------------------------
+// The slab [cache_max][H*D] fp16 is the op's; execute() appends the S new rows at cache_seq_len_ (fp32 -> fp16, the rounding of the reference's fp16 stores into the
+// slab: RoPE's MLLM_FP32_TO_FP16 and mat_mul's fp16 branch, Matmul.cpp:262-268) and the output is a view of rows [0, T + S) -- never a copy of the cache.
+class HIPKVCacheOp final : public HIPOp {
+public:
+    HIPKVCacheOp(Backend *bn, const string &name, int cache_max) : HIPOp(bn, name), cache_max_(cache_max) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs[0]->batch() == 1 && inputs[0]->dtype() == MLLM_TYPE_F32, "KVCACHE: batch 1, fp32 producer");
+        if (cache_seq_len_ + inputs[0]->sequence() > cache_max_) {      // CPUKVCache.cpp:121-126
+            fprintf(stderr, "\n[ERROR]: Current tokens exceed cache limit: %d>%d;\n         Please set args `--limits` >%d\n", cache_seq_len_ + inputs[0]->sequence(), cache_max_, cache_max_);
+            exit(1);
+        }
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), cache_seq_len_ + inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
         const size_t row = (size_t)inputs[0]->head() * inputs[0]->dimension();
-        if (!slab_) HIPCHK(mllm_hip_alloc(&slab_, (size_t)cache_max_ * row * 2));
+        if (!slab_ || row != row_) {
+            need(cache_seq_len_ == 0, "KVCACHE: the row width changed with tokens in the cache");
+            if (slab_) hb()->dev_release(slab_);
+            slab_ = hb()->dev_alloc((size_t)cache_max_ * row * 2);
+            row_ = row;
+        }
         outputs[0]->setDtype(MLLM_TYPE_F16);
-        outputs[0]->setCtype(inputs[0]->ctype());
-        DeviceMemory &m = outputs[0]->device_memory();
-        m.handle = slab_; m.type = MEM_TYPE_GENERIC; m.size_in_bytes = (size_t)outputs[0]->sequence() * row * 2;
+        hb()->view_of(outputs[0], slab_, (size_t)outputs[0]->sequence() * row * 2);
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        const int S = inputs[0]->sequence(), n = inputs[0]->head() * inputs[0]->dimension();
-        if (inputs[0]->dtype() == MLLM_TYPE_F32)
-            HIPCHK(mllm_hip_store_f16((const float *)dptr(inputs[0]), n, (uint16_t *)slab_ + (size_t)cache_seq_len_ * n, n, S, n, hb(backend_)->stream()));
-        // an fp16 producer (RoPE writing K rows) was pointed at the slab row by the model adapter and has appended in place already
+    ErrorCode execute(TensorList inputs, TensorList) override {
+        const int S = inputs[0]->sequence(), n = (int)row_;
+        if (S) HIPCHK(mllm_hip_store_f16((const float *)dptr(inputs[0]), n, (uint16_t *)slab_ + (size_t)cache_seq_len_ * n, n, S, n, hb()->stream()));
         cache_seq_len_ += S;
         return MLLM_NO_ERROR;
     }
@@ -248,22 +367,28 @@ public:
 private:
     int cache_max_, cache_seq_len_ = 0;
     void *slab_ = nullptr;
+    size_t row_ = 0;
 };
 
 // ---- F_FA2: CPUFlashAttention2Func (op/CPUFlashAttention2Func.hpp:29-125; causal_mask) -> flash_attention_2_forward (compute/FlashAttention2.hpp:2236-2284) -------
-class HIPFlashAttention2Op final : public Op {
+class HIPFlashAttention2Op final : public HIPOp {
 public:
-    HIPFlashAttention2Op(Backend *bn, const string &name, bool causal) : Op(bn, name), causal_(causal) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
+    HIPFlashAttention2Op(Backend *bn, const string &name, bool causal) : HIPOp(bn, name), causal_(causal) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        auto &q = inputs[0], &k = inputs[1], &v = inputs[2];
+        need(q->batch() == 1 && q->dtype() == MLLM_TYPE_F32 && k->dtype() == v->dtype() && (k->dtype() == MLLM_TYPE_F16 || k->dtype() == MLLM_TYPE_F32), "F_FA2: batch 1, fp32 q, fp16 or fp32 k / v");
+        need(k->head() == v->head() && k->head() > 0 && q->head() % k->head() == 0 && k->sequence() == v->sequence() && k->dimension() == q->dimension() && v->dimension() == q->dimension(), "F_FA2: head / length mismatch");
+        outputs[0]->reshape(q->batch(), q->head(), q->sequence(), q->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
         auto &q = inputs[0], &k = inputs[1], &v = inputs[2];
         const int Hq = q->head(), Hkv = k->head(), D = q->dimension();
+        if (q->sequence() == 0) return MLLM_NO_ERROR;
         const int kvdt = k->dtype() == MLLM_TYPE_F16 ? MLLM_HIP_F16 : MLLM_HIP_F32;
         HIPCHK(mllm_hip_fa2((const float *)dptr(q), (int64_t)Hq * D, dptr(k), (int64_t)Hkv * D, dptr(v), (int64_t)Hkv * D, kvdt, (float *)dptr(outputs[0]), (int64_t)Hq * D, q->sequence(),
-                            k->sequence(), Hq, Hkv, D, causal_ ? 1 : 0, nullptr, nullptr, hb(backend_)->stream()));
+                            k->sequence(), Hq, Hkv, D, causal_ ? 1 : 0, nullptr, nullptr, hb()->stream()));
         return MLLM_NO_ERROR;
     }
 
@@ -272,17 +397,19 @@ private:
 };
 
 // ---- elementwise: CPUSiLU (op/CPUSiLU.cpp:24-52), CPUGELU / CPUQuickGELU through the fp16 LUTs (op/CPUGELU.cpp:24-46, op/CPUQuickGELU.cpp:22-43), F_TTADD / F_TTMUL (op/CPUBinaryFunc.hpp) ----
-class HIPUnaryOp final : public Op {
+class HIPUnaryOp final : public HIPOp {
 public:
     enum Kind { SILU_K, GELU_K, QUICKGELU_K };
-    HIPUnaryOp(Backend *bn, const string &name, Kind k) : Op(bn, name), kind_(k) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    HIPUnaryOp(Backend *bn, const string &name, Kind k) : HIPOp(bn, name), kind_(k) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        auto *b = hb(backend_);
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        auto *b = hb();
         const int64_t n = inputs[0]->count();
+        if (n == 0) return MLLM_NO_ERROR;
         if (kind_ == SILU_K) HIPCHK(mllm_hip_silu((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), n, b->stream()));
         else HIPCHK(mllm_hip_act_lut((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), n, kind_ == GELU_K ? b->gelu_lut() : b->quickgelu_lut(), b->stream()));
         return MLLM_NO_ERROR;
@@ -291,16 +418,18 @@ public:
 private:
     Kind kind_;
 };
-class HIPBinaryOp final : public Op {
+class HIPBinaryOp final : public HIPOp {
 public:
-    HIPBinaryOp(Backend *bn, const string &name, bool mul) : Op(bn, name), mul_(mul) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    HIPBinaryOp(Backend *bn, const string &name, bool mul) : HIPOp(bn, name), mul_(mul) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs[0]->count() == inputs[1]->count(), "F_TTADD / F_TTMUL: operands of one shape (no broadcast on this path)");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
         auto fn = mul_ ? mllm_hip_mul : mllm_hip_add;
-        HIPCHK(fn((const float *)dptr(inputs[0]), (const float *)dptr(inputs[1]), (float *)dptr(outputs[0]), (int64_t)inputs[0]->count(), hb(backend_)->stream()));
+        if (inputs[0]->count()) HIPCHK(fn((const float *)dptr(inputs[0]), (const float *)dptr(inputs[1]), (float *)dptr(outputs[0]), (int64_t)inputs[0]->count(), hb()->stream()));
         return MLLM_NO_ERROR;
     }
 
@@ -310,17 +439,18 @@ private:
 
 // ---- ops of the other model families -----------------------------------------------------------------------------------------------------------------
 // SLIDINGWINDOWMASK (op/CPUSlidingWindowMask.cpp:30-58) on BSHD scores [1][heads][S][keys]; batch 1 like the rest of the adapter
-class HIPSlidingWindowMaskOp final : public Op {
+class HIPSlidingWindowMaskOp final : public HIPOp {
 public:
-    HIPSlidingWindowMaskOp(Backend *bn, const string &name, int window) : Op(bn, name), window_(window) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    HIPSlidingWindowMaskOp(Backend *bn, const string &name, int window) : HIPOp(bn, name), window_(window) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs[0]->batch() == 1, "SLIDINGWINDOWMASK: batch 1");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        if (inputs[0]->batch() != 1) throw std::runtime_error("HIPSlidingWindowMaskOp: batch 1 only");
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
         HIPCHK(mllm_hip_sliding_window_mask((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), inputs[0]->sequence(), inputs[0]->head(), inputs[0]->dimension(), window_,
-                                            hb(backend_)->stream()));
+                                            hb()->stream()));
         return MLLM_NO_ERROR;
     }
 
@@ -329,22 +459,22 @@ private:
 };
 // F_TOPK (op/CPUTopkFunc.hpp:27-92): outputs[0] = values, outputs[1] = indices (floats).  DIMENSION: [b][h][s][D] -> [b][h][s][k]; HEAD (input [1][H][S][1]) ->
 // [1][k][S][1] -- in BSHD memory the rows [S][H] -> [S][k], the same launch with n = H
-class HIPTopkOp final : public Op {
+class HIPTopkOp final : public HIPOp {
 public:
-    HIPTopkOp(Backend *bn, const string &name, int k, bool head_axis) : Op(bn, name), k_(k), head_(head_axis) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    HIPTopkOp(Backend *bn, const string &name, int k, bool head_axis) : HIPOp(bn, name), k_(k), head_(head_axis) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
         if (head_ && (inputs[0]->dimension() != 1 || inputs[0]->batch() != 1)) throw std::runtime_error("HIPTopkOp: the HEAD axis form takes [1][H][S][1]");
         for (int o = 0; o < 2; ++o) {
             if (head_) outputs[o]->reshape(inputs[0]->batch(), k_, inputs[0]->sequence(), 1);
             else outputs[o]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), k_);
-            outputs[o]->setDtype(inputs[0]->dtype());
         }
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); alloc_f32(outputs[1]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
         const int rows = head_ ? inputs[0]->sequence() : inputs[0]->batch() * inputs[0]->head() * inputs[0]->sequence();
         const int n = head_ ? inputs[0]->head() : inputs[0]->dimension();
-        HIPCHK(mllm_hip_topk_rows((const float *)dptr(inputs[0]), n, (float *)dptr(outputs[0]), (float *)dptr(outputs[1]), rows, n, k_, hb(backend_)->stream()));
+        HIPCHK(mllm_hip_topk_rows((const float *)dptr(inputs[0]), n, (float *)dptr(outputs[0]), (float *)dptr(outputs[1]), rows, n, k_, hb()->stream()));
         return MLLM_NO_ERROR;
     }
 
@@ -353,54 +483,82 @@ private:
     bool head_;
 };
 // F_SCATTERADD on SEQUENCE (op/CPUScatterAddFunc.hpp:27-60): inputs = (dest [1][1][S][D], src [1][1][R][D], indices [1][1][1][R]); dest is updated in place, no outputs
-class HIPScatterAddOp final : public Op {
+class HIPScatterAddOp final : public HIPOp {
 public:
-    HIPScatterAddOp(Backend *bn, const string &name) : Op(bn, name) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>>, vector<shared_ptr<Tensor>>) override { return MLLM_NO_ERROR; }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>>) override {
+    HIPScatterAddOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
+    ErrorCode reshape(TensorList, TensorList) override { return MLLM_NO_ERROR; }
+    ErrorCode setUp(TensorList, TensorList) override { return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList) override {
         if (inputs[1]->batch() == 0) return MLLM_NO_ERROR;
         const int D = inputs[0]->dimension();
-        HIPCHK(mllm_hip_scatter_add_rows((float *)dptr(inputs[0]), D, (const float *)dptr(inputs[1]), D, (const float *)dptr(inputs[2]), inputs[2]->dimension(), D, hb(backend_)->stream()));
+        HIPCHK(mllm_hip_scatter_add_rows((float *)dptr(inputs[0]), D, (const float *)dptr(inputs[1]), D, (const float *)dptr(inputs[2]), inputs[2]->dimension(), D, hb()->stream()));
         return MLLM_NO_ERROR;
     }
 };
 
-// ---- SOFTMAX: CPUSoftMax (op/CPUSoftMax.cpp:28-65; axis, do_causal_mask); DIMENSION axis only (the eager-attention form) -----------------------------------------
-class HIPSoftMaxOp final : public Op {
+// ---- SOFTMAX: CPUSoftMax (op/CPUSoftMax.cpp:28-65; axis, do_causal_mask); DIMENSION axis.  With do_causal_mask and more than one query row, row s keeps its first
+// s + 1 + old_dim columns (old_dim = columns - rows, or the cache length passed as a second input minus the rows, :35-46) and the rest of the output row is zero -------
+class HIPSoftMaxOp final : public HIPOp {
 public:
-    HIPSoftMaxOp(Backend *bn, const string &name) : Op(bn, name) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    HIPSoftMaxOp(Backend *bn, const string &name, bool causal) : HIPOp(bn, name), causal_(causal) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs[0]->ctype() == BSHD, "SOFTMAX: BSHD scores");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        HIPCHK(mllm_hip_softmax((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), rows_of(inputs[0]), inputs[0]->dimension(), nullptr, hb(backend_)->stream()));
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        auto *b = hb();
+        const int rows = rows_of(inputs[0]), n = inputs[0]->dimension(), S = inputs[0]->sequence(), H = inputs[0]->head();
+        if (rows == 0) return MLLM_NO_ERROR;
+        int classes = n, old_dim = n - S;
+        if (inputs.size() > 1) { classes = (int)b->host_floats(inputs[1])[0]; old_dim = classes - S; }
+        const int *valid = nullptr;
+        if ((causal_ && S > 1) || classes != n) {
+            std::vector<int> v((size_t)rows);
+            for (int r = 0; r < rows; ++r) v[r] = causal_ && S > 1 ? std::min(n, (r / H) % S + 1 + old_dim) : std::min(n, classes);      // BSHD rows: r = (b*S + s)*H + h
+            int *dv = (int *)b->scratch(5, v.size() * 4);
+            b->upload(dv, v.data(), v.size() * 4);
+            valid = dv;
+        }
+        HIPCHK(mllm_hip_softmax((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), rows, n, valid, b->stream()));
         return MLLM_NO_ERROR;
     }
+
+private:
+    bool causal_;
 };
 
 // ---- CONVOLUTION3D (Qwen2-VL patch embed, kernel == stride, VALID, no bias: op/CPUConvolution3D.cpp:56-100) and CONVOLUTION2D (ViT / CLIP patch embed,
 // kernel == stride, VALID: op/CPUConvolution2D.cpp:29-149) as GEMMs over the flattened receptive fields (compute/Convolution.cpp:35-82,179-235) ---------------------
-class HIPPatchConvOp final : public Op {
+class HIPPatchConvOp final : public HIPOp {
 public:
     HIPPatchConvOp(Backend *bn, const string &name, bool is3d, int in_ch, int out_ch, int kt, int kh, int kw, bool bias) :
-        Op(bn, name), is3d_(is3d), in_ch_(in_ch), out_ch_(out_ch), kt_(kt), kh_(kh), kw_(kw), has_bias_(bias) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        if (is3d_) outputs[0]->reshape(inputs[0]->batch(), out_ch_, 1, 1, 1);            // [N, OC, 1, 1, 1], viewed [1,1,N,OC] by the model (modeling_qwen2_vl.hpp:31-35)
-        else outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head() / kh_, out_ch_, inputs[0]->dimension() / kw_);      // image [B, H, C, W] -> [B, H/p, OC, W/p]
+        HIPOp(bn, name), is3d_(is3d), in_ch_(in_ch), out_ch_(out_ch), kt_(kt), kh_(kh), kw_(kw), has_bias_(bias) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        if (is3d_) {
+            need(inputs[0]->ctype() == BCTHW && inputs[0]->channel() == in_ch_ && inputs[0]->time() == kt_ && inputs[0]->height() == kh_ && inputs[0]->width() == kw_,
+                 "CONVOLUTION3D: one receptive field per batch entry, [N, C, kt, kh, kw]");
+            outputs[0]->reshape(inputs[0]->batch(), out_ch_, 1, 1, 1);            // [N, OC, 1, 1, 1], viewed [1,1,N,OC] by the model (modeling_qwen2_vl.hpp:31-35)
+        } else {
+            need(inputs[0]->batch() == 1 && inputs[0]->sequence() == in_ch_ && inputs[0]->head() % kh_ == 0 && inputs[0]->dimension() % kw_ == 0, "CONVOLUTION2D: image [1, H, C, W], H and W multiples of the patch");
+            outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head() / kh_, out_ch_, inputs[0]->dimension() / kw_);      // image [B, H, C, W] -> [B, H/p, OC, W/p]
+        }
         return MLLM_NO_ERROR;
     }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode load(AbstructLoader &loader) override {
         load_tensor(weight_, backend_, loader, name() + ".weight", out_ch_, in_ch_ * kt_ * kh_ * kw_);
+        need(weight_.dtype() == MLLM_TYPE_F32, "patch-embedding convolutions are fp32 in *-q4_k.mllm files");
         if (has_bias_) load_tensor(bias_, backend_, loader, name() + ".bias", 1, out_ch_);
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        auto *b = hb(backend_);
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        auto *b = hb();
         const float *w = (const float *)weight_.device_memory().handle, *bias = has_bias_ ? (const float *)bias_.device_memory().handle : nullptr;
         const int KK = in_ch_ * kt_ * kh_ * kw_;
         if (is3d_) {
-            HIPCHK(mllm_hip_patch_gemm_f32((const float *)dptr(inputs[0]), w, bias, (float *)dptr(outputs[0]), inputs[0]->batch(), KK, out_ch_, b->stream()));
+            if (inputs[0]->batch()) HIPCHK(mllm_hip_patch_gemm_f32((const float *)dptr(inputs[0]), w, bias, (float *)dptr(outputs[0]), inputs[0]->batch(), KK, out_ch_, b->stream()));
         } else {
             const int H = inputs[0]->head(), W = inputs[0]->dimension(), N = (H / kh_) * (W / kw_);
             float *patches = (float *)b->scratch(3, (size_t)N * KK * 4), *rows = (float *)b->scratch(2, (size_t)N * out_ch_ * 4);
@@ -419,25 +577,48 @@ private:
     Tensor weight_, bias_;
 };
 
-// ---- metadata functions: F_VIEW (op/CPUViewFunc.hpp:30-139) is a shape change on the contiguous BSHD buffer, F_CLIP {-1} (op/CPUClipFunc.hpp) a
-// pointer offset to the last row; both hand out non-owning views ---------------------------------------------------------------------------------------------------
-class HIPViewOp final : public Op {
+// ---- metadata functions: no kernel, the output aliases the input's block ------------------------------------------------------------------------
+// F_VIEW (Tensor::view, op/CPUViewFunc.hpp:30-139): in each accepted pattern -1 means "this axis keeps its extent" and the two named axes regroup; every pattern is a
+// reinterpretation of the contiguous BSHD (or BCTHW) buffer.  Patterns the reference rejects with exit(-2) are rejected here with an exception.
+class HIPViewOp final : public HIPOp {
 public:
-    HIPViewOp(Backend *bn, const string &name, int b, int h, int s, int d) : Op(bn, name), b_(b), h_(h), s_(s), d_(d) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
-        const int64_t n = inputs[0]->count();
-        int dims[4] = {b_, h_, s_, d_};
-        int64_t known = 1;
-        for (int v : dims) if (v > 0) known *= v;
-        for (int &v : dims) if (v <= 0) v = (int)(n / known);      // one axis may be -1 (CPUViewFunc.hpp:34-50)
-        outputs[0]->reshape(dims[0], dims[1], dims[2], dims[3]);
+    HIPViewOp(Backend *bn, const string &name, int b, int h, int s, int d) : HIPOp(bn, name), b_(b), h_(h), s_(s), d_(d) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        auto &in = inputs[0];
+        const bool five = in->ctype() == BCTHW;
+        const int64_t n = in->count();
+        int B = in->batch(), H = five ? 1 : in->head(), S = five ? 1 : in->sequence(), D = five ? 1 : in->dimension();
+        auto pick = [&](int want, int other, int64_t prod) -> int {      // one of two regrouped axes: given, or what the other leaves (ANYDIM)
+            return want != ANYDIM ? want : (int)(prod / other);
+        };
+        if (b_ == -1 && h_ == 1 && s_ == 1 && d_ == -1 && !five) { D = S * H * D; S = 1; H = 1; }
+        else if (b_ == -1 && h_ == -1 && s_ == 1 && d_ == 1 && !five) { S = S * H * D; H = 1; D = 1; }
+        else if (b_ == 1 && h_ == 1 && s_ == -1 && d_ > 0) { B = 1; H = 1; D = d_; S = (int)(n / d_); }      // everything but the row width folds into the sequence (also the BCTHW patch rows)
+        else if (b_ == -1 && h_ != -1 && s_ == -1 && d_ != -1 && !five) {      // head & dimension
+            const int64_t hd = (int64_t)H * D;
+            need(h_ != ANYDIM || d_ != ANYDIM, "F_VIEW: head and dimension both open");
+            H = pick(h_, d_, hd); D = pick(d_, h_, hd);
+            need((int64_t)H * D == hd, "F_VIEW: head * dimension must be kept");
+        } else if (b_ == -1 && h_ != -1 && s_ != -1 && d_ == -1 && !five) {    // head & sequence
+            const int64_t hs = (int64_t)H * S;
+            need(h_ != ANYDIM || s_ != ANYDIM, "F_VIEW: head and sequence both open");
+            H = pick(h_, s_, hs); S = pick(s_, h_, hs);
+            need((int64_t)H * S == hs, "F_VIEW: head * sequence must be kept");
+        } else if (b_ != -1 && h_ == -1 && s_ != -1 && d_ == -1 && !five) {    // batch & sequence
+            const int64_t bs = (int64_t)B * S;
+            need(b_ != ANYDIM || s_ != ANYDIM, "F_VIEW: batch and sequence both open");
+            B = pick(b_, s_, bs); S = pick(s_, b_, bs);
+            need((int64_t)B * S == bs, "F_VIEW: batch * sequence must be kept");
+        } else {
+            throw std::runtime_error("F_VIEW [" + std::to_string(b_) + ", " + std::to_string(h_) + ", " + std::to_string(s_) + ", " + std::to_string(d_) + "] is not one of the reference's patterns");
+        }
+        need((int64_t)B * H * S * D == n, "F_VIEW: element count must be kept");
+        outputs[0]->reshape(B, H, S, D);      // a fresh shell: BSHD
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
         outputs[0]->setDtype(inputs[0]->dtype());
-        outputs[0]->setCtype(inputs[0]->ctype());
-        DeviceMemory &m = outputs[0]->device_memory();
-        m = inputs[0]->device_memory();
+        hb()->view_of(outputs[0], dptr(inputs[0]), inputs[0]->device_memory().size_in_bytes);
         return MLLM_NO_ERROR;
     }
 
@@ -447,11 +628,11 @@ private:
 
 // F_CLIP (op/CPUClipFunc.hpp) on the SEQUENCE axis of a batch-1 BSHD tensor: clip({}, {}, {-1}, {}) = the last position (every causal LM ends with it,
 // modeling_qwen2_vl.hpp:395-397), clip({}, {}, {a, b}, {}) = positions [a, b) (LLaVA drops the class row, modeling_llava.hpp:90).  Rows of a position are contiguous,
-// so the result is a pointer offset into the input: a non-owning view.
-class HIPClipSeqOp final : public Op {
+// so the result is a pointer offset into the input.
+class HIPClipSeqOp final : public HIPOp {
 public:
-    HIPClipSeqOp(Backend *bn, const string &name, int a, int b, bool single) : Op(bn, name), a_(a), b_(b), single_(single) {}
-    ErrorCode reshape(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    HIPClipSeqOp(Backend *bn, const string &name, int a, int b, bool single) : HIPOp(bn, name), a_(a), b_(b), single_(single) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
         const int S = inputs[0]->sequence();
         lo_ = a_ < 0 ? S + a_ : a_;
         hi_ = single_ ? lo_ + 1 : (b_ < 0 ? S + b_ : b_);
@@ -459,14 +640,10 @@ public:
         outputs[0]->reshape(1, inputs[0]->head(), hi_ - lo_, inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(vector<shared_ptr<Tensor>> inputs, vector<shared_ptr<Tensor>> outputs) override {
+    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
         outputs[0]->setDtype(inputs[0]->dtype());
-        outputs[0]->setCtype(inputs[0]->ctype());
-        const size_t row = (size_t)inputs[0]->head() * inputs[0]->dimension() * (inputs[0]->dtype() == MLLM_TYPE_F16 ? 2 : 4);
-        DeviceMemory &m = outputs[0]->device_memory();
-        m = inputs[0]->device_memory();
-        m.handle = (char *)m.handle + (size_t)lo_ * row;
-        m.size_in_bytes = (size_t)(hi_ - lo_) * row;
+        const size_t row = (size_t)inputs[0]->head() * inputs[0]->dimension() * elem_bytes(inputs[0]->dtype());
+        hb()->view_of(outputs[0], (char *)dptr(inputs[0]) + (size_t)lo_ * row, (size_t)(hi_ - lo_) * row);
         return MLLM_NO_ERROR;
     }
 
@@ -475,10 +652,158 @@ private:
     bool single_;
 };
 
+// F_TRANPOSE (Tensor::transpose, op/CPUTransposeFunc.hpp): the (SEQUENCE, DIMENSION) swap is a flip of the axis map on shared memory in the reference too
+// (:31-84 -- the producer is re-pointed, nothing moves); it is how a weight becomes the right operand of Tensor::mm (`lm_head().transpose(SEQUENCE, DIMENSION)`).
+class HIPTransposeOp final : public HIPOp {
+public:
+    HIPTransposeOp(Backend *bn, const string &name, Chl a, Chl b) : HIPOp(bn, name), a_(a), b_(b) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs[0]->ctype() == BSHD, "F_TRANPOSE: BSHD input");
+        outputs[0]->transCopyShape(inputs[0]->shape());
+        outputs[0]->chls() = inputs[0]->chls();
+        std::swap(outputs[0]->chls()[a_], outputs[0]->chls()[b_]);
+        outputs[0]->changeCtype((int)inputs[0]->shape().size());
+        outputs[0]->undiffusion() = true;
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
+        outputs[0]->setDtype(inputs[0]->dtype());
+        hb()->view_of(outputs[0], dptr(inputs[0]), inputs[0]->device_memory().size_in_bytes);
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    Chl a_, b_;
+};
+
+// F_SPLIT on DIMENSION (Tensor::split, op/CPUSplitFunc.hpp:32-172): the reference scatters the producer straight into the parts ("aggregated" children) or runs
+// efficient_split; here one pitched copy per part (precedent opencl/kernel/split.cl).
+class HIPSplitOp final : public HIPOp {
+public:
+    HIPSplitOp(Backend *bn, const string &name, std::vector<int> each) : HIPOp(bn, name), each_(std::move(each)) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        int total = 0;
+        for (int e : each_) total += e;
+        need(outputs.size() == each_.size() && total == inputs[0]->dimension() && inputs[0]->dtype() == MLLM_TYPE_F32, "F_SPLIT: the parts must add up to the fp32 input's dimension");
+        for (size_t i = 0; i < each_.size(); ++i) {
+            need(each_[i] % 4 == 0, "F_SPLIT: parts of a multiple of 4 columns");
+            outputs[i]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), each_[i]);
+        }
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList outputs) override { for (auto &o : outputs) alloc_f32(o); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        const int rows = rows_of(inputs[0]), ld = inputs[0]->dimension();
+        int off = 0;
+        for (size_t i = 0; i < each_.size(); ++i) {
+            if (rows) HIPCHK(mllm_hip_copy_2d_f32((const float *)dptr(inputs[0]) + off, ld, (float *)dptr(outputs[i]), each_[i], rows, each_[i], hb()->stream()));
+            off += each_[i];
+        }
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    std::vector<int> each_;
+};
+
+// ---- F_MM: CPUmmFunction (op/CPUMatmulFunc.hpp:86-181).  The form on the hot path: activations [1,1,M,K] times a transposed weight view (axis map flipped by
+// F_TRANPOSE, chls[SEQUENCE] == 3) = the tied lm_head `Tensor::mm(x, lm_head().transpose(SEQUENCE, DIMENSION))` (modeling_qwen2_vl.hpp:399): mat_mul with a Q4_0
+// right operand quantises x to Q8_0 and runs vec_dot_q4_0_q8_0 (Matmul.cpp:77-120,219-276); an fp32 table runs vec_dot_fp32 -----------------------------------------
+class HIPMatmulOp final : public HIPOp {
+public:
+    HIPMatmulOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        auto &x = inputs[0], &w = inputs[1];
+        need(x->ctype() == BSHD && x->dtype() == MLLM_TYPE_F32 && x->head() == 1, "F_MM: fp32 BSHD activations [b,1,s,K]");
+        need(w->chls()[SEQUENCE] == 3 && w->batch() == 1 && w->head() == 1 && (w->dtype() == MLLM_TYPE_Q4_0 || w->dtype() == MLLM_TYPE_F32),
+             "F_MM: the right operand must be a transposed [1,1,K,N] view of a Q4_0 or fp32 weight (the eager-attention forms are not on this backend)");
+        need(x->dimension() == w->sequence(), "F_MM: inner extents differ");
+        if (w->dtype() == MLLM_TYPE_Q4_0) need(hb()->q40_table_at(dptr(w)) != nullptr, "F_MM: Q4_0 operand that is not a PARAMETER's table");
+        outputs[0]->reshape(x->batch(), x->head(), x->sequence(), w->dimension());
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        auto *b = hb();
+        auto &x = inputs[0], &w = inputs[1];
+        const int M = rows_of(x), K = x->dimension(), N = w->dimension();
+        if (M == 0) return MLLM_NO_ERROR;
+        if (w->dtype() == MLLM_TYPE_Q4_0) {
+            auto t = b->q40_table_at(dptr(w));
+            uint8_t *ws = (uint8_t *)b->scratch(0, mllm_hip_linear_workspace_bytes(MLLM_HIP_Q4_0, M, K));
+            int8_t *qs = (int8_t *)ws;
+            uint16_t *d = (uint16_t *)(ws + (((size_t)M * K + 255) & ~(size_t)255));
+            HIPCHK(mllm_hip_quantize_q80((const float *)dptr(x), qs, d, M, K, b->stream()));
+            HIPCHK(mllm_hip_linear_q40_q80((const uint8_t *)t->qs, (const uint16_t *)t->d, nullptr, qs, d, (float *)dptr(outputs[0]), N, M, N, K, b->stream()));
+        } else {
+            HIPCHK(mllm_hip_linear_f32((const float *)dptr(w), nullptr, (const float *)dptr(x), (float *)dptr(outputs[0]), N, M, N, K, b->stream()));
+        }
+        return MLLM_NO_ERROR;
+    }
+};
+
+// ---- F_WHERE (Tensor::where, op/CPUWhereFunc.hpp; value, axis) + F_INDEX_PUT (Tensor::index_put, op/CPUIndexPutFunc.hpp:25-92; accumulate = false): the splice of
+// the visual rows into the text embeddings (modeling_qwen2_vl.hpp:386-389).  The count of matches shapes the output, so the ids are read on the host (their upload's
+// shadow; no device round trip) and the index tensor goes up as floats, which is what index_put receives in the reference too --------------------------------------
+class HIPWhereOp final : public HIPOp {
+public:
+    HIPWhereOp(Backend *bn, const string &name, float value, int axis) : HIPOp(bn, name), value_(value), axis_(axis) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        auto &in = inputs[0];
+        const std::vector<float> &v = hb()->host_floats(in);
+        for (auto &x : idx_) x.clear();
+        const int B = in->batch(), S = in->sequence(), H = in->head(), D = in->dimension();
+        size_t i = 0;      // BSHD memory order, which is also the reference's visiting order (b, s, h, d)
+        for (int b = 0; b < B; ++b) for (int s = 0; s < S; ++s) for (int h = 0; h < H; ++h) for (int d = 0; d < D; ++d, ++i)
+            if (v[i] == value_) { idx_[0].push_back((float)b); idx_[1].push_back((float)h); idx_[2].push_back((float)s); idx_[3].push_back((float)d); }
+        const int num = (int)idx_[0].size();
+        if (axis_ == -1) outputs[0]->reshape(1, 1, 4, num);
+        else outputs[0]->reshape(1, 1, 1, num);
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList, TensorList outputs) override {
+        const size_t num = idx_[0].size();
+        if (num == 0) return MLLM_NO_ERROR;
+        std::vector<float> flat;
+        if (axis_ == -1) for (auto &x : idx_) flat.insert(flat.end(), x.begin(), x.end());      // rows b, h, s, d
+        else flat = idx_[axis_ == BATCH ? 0 : axis_ == HEAD ? 1 : axis_ == SEQUENCE ? 2 : 3];
+        hb()->upload(dptr(outputs[0]), flat.data(), flat.size() * 4);
+        hb()->remember_host(dptr(outputs[0]), flat.data(), flat.size());
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    float value_;
+    int axis_;
+    std::vector<float> idx_[4];
+};
+class HIPIndexPutOp final : public HIPOp {
+public:
+    HIPIndexPutOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        if (inputs.size() > 1 && inputs[1]->batch() == 0) return MLLM_NO_ERROR;      // no image: the destination passes through (:44-53)
+        need(inputs.size() == 3 && outputs[0].get() == inputs[0].get(), "F_INDEX_PUT: (dest, value, indices), in place");
+        auto &dst = inputs[0], &src = inputs[1], &idx = inputs[2];
+        need(dst->batch() == 1 && dst->head() == 1 && src->head() == 1 && dst->dimension() == src->dimension() && dst->dtype() == MLLM_TYPE_F32 && src->dtype() == MLLM_TYPE_F32,
+             "F_INDEX_PUT: fp32 rows of one width, batch 1, one head");
+        need(idx->dimension() <= src->batch() * src->sequence(), "F_INDEX_PUT: more indices than value rows");
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList) override { return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList) override {
+        if (inputs.size() > 1 && inputs[1]->batch() == 0) return MLLM_NO_ERROR;
+        HIPCHK(mllm_hip_index_put_rows_fidx((float *)dptr(inputs[0]), inputs[0]->sequence(), (const float *)dptr(inputs[1]), (const float *)dptr(inputs[2]), inputs[2]->dimension(),
+                                            inputs[0]->dimension(), hb()->stream()));
+        return MLLM_NO_ERROR;
+    }
+};
+
 }  // namespace
 
 // ---- registry: OpType -> creator (Backend::registerOps, mllm/Backend.hpp:104-105; OpDefined.hpp:10-134).  Anything not listed, or a listed Op with parameters the
-// launchers do not cover, makes opCreate return nullptr and the framework run that Op on the CPU backend with automatic tensor migration (Layer.hpp:128-135,159-163) ----
+// launchers do not cover, makes opCreate return nullptr: a Layer then runs on the CPU backend with automatic tensor migration (Layer.hpp:128-135,159-163); a Tensor
+// function has no such migration in the reference (Tensor.cpp:402-406 only swaps the Op), so every function the five configs call on device tensors is listed ----
 void HIPBackend::registerOps() {
     creators_[LINEAR] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
         const int in = geti(p, "in_features"), out = geti(p, "out_features");
@@ -488,6 +813,9 @@ void HIPBackend::registerOps() {
     creators_[EMBEDDING] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
         const int h = geti(p, "hidden_size");
         return h % 32 ? nullptr : new HIPEmbeddingOp(b, n, h, geti(p, "vocab_size"));
+    };
+    creators_[PARAMETER] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        return new HIPParameterOp(b, n, geti(p, "batch"), geti(p, "head"), geti(p, "seq"), geti(p, "dim"));
     };
     creators_[RMSNORM] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
         return new HIPNormOp(b, n, false, geti(p, "norm_size"), getf(p, "epsilon", 1e-6f), false, geti(p, "add_unit_offset") != 0);
@@ -505,8 +833,13 @@ void HIPBackend::registerOps() {
         if (sec.empty()) sec = {16, 24, 24};
         return new HIPRoPEOp(b, n, true, getf(p, "rope_theta", 1000000.f), geti(p, "max_position_embeddings", 32768), sec);
     };
+    creators_[VISIONROPE] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        const int dim = geti(p, "dim"), merge = geti(p, "spatial_merge_size");
+        return dim < 2 || merge < 1 ? nullptr : new HIPVisionRoPEOp(b, n, dim, merge);
+    };
+    creators_[F_APPLY_VISIOROPE] = [](HIPBackend *b, const OpParam &, const std::string &n) -> Op * { return new HIPApplyVisionRoPEOp(b, n); };
     creators_[KVCACHE] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
-        if (geti(p, "n_rep", 1) != 1 || !geti(p, "fa2")) return nullptr;      // FlashAttention2 mode only (n_rep = 1, fp16): the default attn_implementation
+        if (!geti(p, "fa2") || geti(p, "for_xnn")) return nullptr;      // FlashAttention2 mode (the default attn_implementation): fp16 slab, no head repeat whatever n_rep says (CPUKVCache.cpp:41-43)
         return new HIPKVCacheOp(b, n, geti(p, "cache_max", 100));
     };
     creators_[F_FA2] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return new HIPFlashAttention2Op(b, n, geti(p, "causal_mask") != 0); };
@@ -516,7 +849,7 @@ void HIPBackend::registerOps() {
     creators_[F_TTADD] = [](HIPBackend *b, const OpParam &, const std::string &n) -> Op * { return new HIPBinaryOp(b, n, false); };
     creators_[F_TTMUL] = [](HIPBackend *b, const OpParam &, const std::string &n) -> Op * { return new HIPBinaryOp(b, n, true); };
     creators_[SOFTMAX] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
-        return geti(p, "axis") != (int)DIMENSION || geti(p, "do_causal_mask") ? nullptr : new HIPSoftMaxOp(b, n);
+        return geti(p, "axis") != (int)DIMENSION ? nullptr : new HIPSoftMaxOp(b, n, geti(p, "do_causal_mask") != 0);
     };
     creators_[CONVOLUTION3D] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
         if (geti(p, "kernal_t") != geti(p, "stride_t") || geti(p, "kernal_h") != geti(p, "stride_h") || geti(p, "kernal_w") != geti(p, "stride_w") || geti(p, "padding") != (int)VALID) return nullptr;
@@ -535,7 +868,7 @@ void HIPBackend::registerOps() {
         return p.count("dim") && (Chl)geti(p, "dim") != SEQUENCE ? nullptr : new HIPScatterAddOp(b, n);
     };
     creators_[F_CLIP] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
-        // SEQUENCE-only clips; anything touching batch / head / dimension goes to the CPU
+        // SEQUENCE-only clips; anything touching batch / head / dimension is not on this backend
         if (geti(p, "b_size") || geti(p, "h_size") || geti(p, "d_size")) return nullptr;
         const int ss = geti(p, "s_size");
         if (ss == 1) return new HIPClipSeqOp(b, n, geti(p, "s_0"), 0, true);
@@ -543,6 +876,21 @@ void HIPBackend::registerOps() {
         return nullptr;
     };
     creators_[F_VIEW] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return new HIPViewOp(b, n, geti(p, "b"), geti(p, "h"), geti(p, "s"), geti(p, "d")); };
+    creators_[F_TRANPOSE] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        if (geti(p, "num_pairs") != 1) return nullptr;
+        const Chl a = (Chl)geti(p, "axis1_0"), c = (Chl)geti(p, "axis2_0");
+        const bool sd = (a == SEQUENCE && c == DIMENSION) || (a == DIMENSION && c == SEQUENCE);
+        return sd ? new HIPTransposeOp(b, n, a, c) : nullptr;      // the (HEAD, SEQUENCE) transposes of the eager-attention branch move data: not on this backend
+    };
+    creators_[F_SPLIT] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        if ((Chl)geti(p, "split_dim") != DIMENSION) return nullptr;      // HD / D_HD splits of fused in_proj layouts (Chl::HD, Types.hpp:139-140): not on the five configs' path
+        std::vector<int> each;
+        for (int i = 0; i < geti(p, "num_splits"); ++i) each.push_back(geti(p, ("dim_" + std::to_string(i)).c_str()));
+        return each.empty() ? nullptr : new HIPSplitOp(b, n, each);
+    };
+    creators_[F_MM] = [](HIPBackend *b, const OpParam &, const std::string &n) -> Op * { return new HIPMatmulOp(b, n); };
+    creators_[F_WHERE] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return new HIPWhereOp(b, n, getf(p, "value"), geti(p, "axis", -1)); };
+    creators_[F_INDEX_PUT] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return geti(p, "accumulate") ? nullptr : new HIPIndexPutOp(b, n); };
 }
 
 }  // namespace mllm

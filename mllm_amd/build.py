@@ -1,6 +1,6 @@
 """Builds libmllm_hip.so (HIP kernels + C-ABI + host engine) in-tree for gfx950.
 
-hipcc cross-compiles without a GPU.  (The fixture quantiser that writes synthetic .mllm files is separate: tools/quantlib.py.)
+hipcc cross-compiles without a GPU.
 """
 from __future__ import annotations
 

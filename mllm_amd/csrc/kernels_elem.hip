@@ -4,6 +4,7 @@
 //   A10/A11/A19 rotary apply (+ fp16 KV-slab store = A12 append), softmax, index_put, argmax
 // All are row- or element-parallel: one 64-lane wave owns one 256-value quant block (4 consecutive values per lane,
 // 16-B coalesced loads), reductions are wavefront shuffles, nothing is staged through LDS except cross-wave sums.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -391,6 +392,26 @@ __global__ __launch_bounds__(256) void index_put_rows_kernel(float *__restrict__
     for (int i = threadIdx.x; i < dim / 4; i += 256) out[i] = src[i];
 }
 
+// the same splice with the indices as the reference hands them over -- a Tensor of floats (CPUIndexPutFunc.hpp:85-92: `(int)replace_idx->dataAt<float>`); rows whose
+// destination lies outside [0, n_dst_rows) are skipped
+__global__ __launch_bounds__(256) void index_put_rows_fidx_kernel(float *__restrict__ dst, int n_dst_rows, const float *__restrict__ value, const float *__restrict__ idx, int dim) {
+    const int r = blockIdx.x, d = (int)idx[r];
+    if (d < 0 || d >= n_dst_rows) return;
+    const float4 *src = reinterpret_cast<const float4 *>(value + (int64_t)r * dim);
+    float4 *out = reinterpret_cast<float4 *>(dst + (int64_t)d * dim);
+    for (int i = threadIdx.x; i < dim / 4; i += 256) out[i] = src[i];
+}
+
+// dst[r][c] = src[r][c] for a [rows][cols] window of two pitched buffers (cols, both pitches and both bases multiples of 4 floats): the column split of a fused
+// projection (efficient_split, compute/Split.hpp as called by CPUSplitFunc.hpp:145-172)
+__global__ __launch_bounds__(256) void copy_2d_f32_kernel(const float *__restrict__ src, int64_t lds, float *__restrict__ dst, int64_t ldd, int rows, int cols4) {
+    const int64_t n = (int64_t)rows * cols4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols4, c = i - r * cols4;
+        reinterpret_cast<float4 *>(dst + r * ldd)[c] = reinterpret_cast<const float4 *>(src + r * lds)[c];
+    }
+}
+
 // out[c][r] = in[r][c]: 32 x 32 tiles through LDS (pitch 33: conflict-free both ways), coalesced on both sides
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
     __shared__ float tile[32][33];
@@ -690,6 +711,21 @@ extern "C" int mllm_hip_index_put_rows(float *dst, const float *value, const int
     hipLaunchKernelGGL(index_put_rows_kernel, dim3(n_rows), dim3(256), 0, as_stream(stream), dst, value, idx, dim);
     return MH_LAUNCH_OK("index_put_rows");
 }
+extern "C" int mllm_hip_index_put_rows_fidx(float *dst, int n_dst_rows, const float *value, const float *idx, int n_rows, int dim, void *stream) {
+    if (dim % 4 != 0 || n_dst_rows < 0) return MLLM_HIP_ERR_SHAPE;
+    if (n_rows <= 0) return MLLM_HIP_OK;
+    if (!dst || !value || !idx) return MLLM_HIP_ERR_ARG;
+    hipLaunchKernelGGL(index_put_rows_fidx_kernel, dim3(n_rows), dim3(256), 0, as_stream(stream), dst, n_dst_rows, value, idx, dim);
+    return MH_LAUNCH_OK("index_put_rows_fidx");
+}
+extern "C" int mllm_hip_copy_2d_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int rows, int cols, void *stream) {
+    if (rows < 0 || cols < 0 || cols % 4 || lds % 4 || ldd % 4 || lds < cols || ldd < cols) return MLLM_HIP_ERR_SHAPE;
+    if (rows == 0 || cols == 0) return MLLM_HIP_OK;
+    if (!src || !dst || ((uintptr_t)src | (uintptr_t)dst) % 16) return MLLM_HIP_ERR_ARG;
+    const int64_t n = (int64_t)rows * (cols / 4);
+    hipLaunchKernelGGL(copy_2d_f32_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, as_stream(stream), src, lds, dst, ldd, rows, cols / 4);
+    return MH_LAUNCH_OK("copy_2d_f32");
+}
 extern "C" int mllm_hip_transpose_f32(const float *x, float *y, int rows, int cols, void *stream) {
     if (rows <= 0 || cols <= 0) return MLLM_HIP_ERR_SHAPE;
     if (!x || !y || x == y) return MLLM_HIP_ERR_ARG;
@@ -819,12 +855,13 @@ extern "C" int mllm_hip_mrope_table(float base, int dim, const float *pos, int S
     }
     return MLLM_HIP_OK;
 }
-extern "C" int mllm_hip_vision_rope_table(int t, int h, int w, int merge, int rot_dim, float *sin_host, float *cos_host) {
-    // CPUVisionRoPE.cpp:19-28 inv_freq (float pow), :56-103 merge-block ordered (h,w), :29-55 angle = pos*inv_freq;
-    // CPUVisionRoPEFunc.hpp:21-60 evaluates std::sin/std::cos of the angle per use: tabulated here. Tables [t*h*w][rot_dim]
+// VISIONROPE's output (CPUVisionRoPE.cpp:19-28 inv_freq by float pow, :56-103 (h, w) per patch in merge-block order, :29-55 angle = pos * inv_freq): the angle
+// table `[t*h*w][rot_dim]`, h angles in columns [0, rot_dim/2), w angles behind them
+extern "C" int mllm_hip_vision_rope_angles(int t, int h, int w, int merge, int rot_dim, float *angles_host) {
     const int q = rot_dim / 2;
     float inv[256];
-    if (q > 256) return MLLM_HIP_ERR_SHAPE;
+    if (q <= 0 || q > 256 || merge <= 0 || t < 0 || h < 0 || w < 0) return MLLM_HIP_ERR_SHAPE;
+    if (!angles_host) return MLLM_HIP_ERR_ARG;
     for (int i = 0; i < q; ++i) inv[i] = 1.0f / powf(10000.0f, (2.0f * i) / (float)rot_dim);
     const int nhb = h / merge, nwb = w / merge;
     size_t p = 0;
@@ -835,10 +872,22 @@ extern "C" int mllm_hip_vision_rope_table(int t, int h, int w, int merge, int ro
                     for (int jw = 0; jw < merge; ++jw, ++p) {
                         const int ph = bh * merge + jh, pw = bw * merge + jw;
                         for (int i = 0; i < q; ++i) {
-                            const float ah = (float)ph * inv[i], aw = (float)pw * inv[i];
-                            sin_host[p * rot_dim + i] = sinf(ah); cos_host[p * rot_dim + i] = cosf(ah);
-                            sin_host[p * rot_dim + q + i] = sinf(aw); cos_host[p * rot_dim + q + i] = cosf(aw);
+                            angles_host[p * rot_dim + i] = (float)ph * inv[i];
+                            angles_host[p * rot_dim + q + i] = (float)pw * inv[i];
                         }
                     }
+    return MLLM_HIP_OK;
+}
+// CPUVisionRoPEFunc.hpp:21-60 evaluates std::sin / std::cos of the angle per use: tabulated here.  Tables [t*h*w][rot_dim]
+extern "C" int mllm_hip_vision_rope_table(int t, int h, int w, int merge, int rot_dim, float *sin_host, float *cos_host) {
+    if (!sin_host || !cos_host) return MLLM_HIP_ERR_ARG;
+    const int rc = mllm_hip_vision_rope_angles(t, h, w, merge, rot_dim, cos_host);      // angles parked in the cos table, replaced in place
+    if (rc != MLLM_HIP_OK) return rc;
+    const size_t n = (size_t)t * (h / merge) * (w / merge) * merge * merge * (size_t)(rot_dim / 2) * 2;
+    for (size_t i = 0; i < n; ++i) {
+        const float a = cos_host[i];
+        sin_host[i] = sinf(a);
+        cos_host[i] = cosf(a);
+    }
     return MLLM_HIP_OK;
 }

@@ -67,3 +67,86 @@ extern "C" int mllm_hip_sync(void *stream) {
     MH_CHECK(hipStreamSynchronize(as_stream(stream)));
     return MLLM_HIP_OK;
 }
+
+// ---- one in-order stream per backend instance (SURVEY §8b Threading: "one in-order stream; sync only at the end of the outermost forward and in
+// copy_to_host"); precedent: the command queue of mllm/backends/opencl/OpenCLBackend.cpp:476-477 --------------------------------------------------
+extern "C" int mllm_hip_stream_create(void **stream) {
+    if (!stream) return MLLM_HIP_ERR_ARG;
+    hipStream_t s;
+    MH_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return MLLM_HIP_OK;
+}
+extern "C" int mllm_hip_stream_destroy(void *stream) {
+    if (stream) MH_CHECK(hipStreamDestroy(as_stream(stream)));
+    return MLLM_HIP_OK;
+}
+
+// ---- stream-ordered activation pool: Backend::alloc_device / free_device of per-call Op outputs (the device analogue of the
+// reference's MemoryPoolManager, mllm/memory/MemoryPoolManager.hpp:15-214).  hipMallocAsync on the device's default pool with the release
+// threshold lifted, so a forward's buffers are recycled by the next forward without touching the driver; a block freed on `stream` may be handed
+// out again to work enqueued later on the same stream only. --------------------------------------------------------------------------------------
+static std::once_flag g_pool_once;
+static hipError_t g_pool_err = hipSuccess;
+extern "C" int mllm_hip_pool_alloc(void **dptr, size_t nbytes, void *stream) {
+    if (!dptr) return MLLM_HIP_ERR_ARG;
+    std::call_once(g_pool_once, [] {
+        int dev = 0;
+        hipMemPool_t pool;
+        uint64_t keep = UINT64_MAX;
+        g_pool_err = hipGetDevice(&dev);
+        if (g_pool_err == hipSuccess) g_pool_err = hipDeviceGetDefaultMemPool(&pool, dev);
+        if (g_pool_err == hipSuccess) g_pool_err = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    });
+    MH_CHECK(g_pool_err);
+    MH_CHECK(hipMallocAsync(dptr, nbytes ? nbytes : 16, as_stream(stream)));
+    return MLLM_HIP_OK;
+}
+extern "C" int mllm_hip_pool_free(void *dptr, void *stream) {
+    if (dptr) MH_CHECK(hipFreeAsync(dptr, as_stream(stream)));
+    return MLLM_HIP_OK;
+}
+
+// ---- Backend::load_from_file fast path (mllm/Backend.hpp:118; OpenCL precedent OpenCLBackend.cpp:928-980 maps the buffer and freads into it): host bytes
+// (the ParamLoader's mmap of the .mllm, or any pageable memory) -> HBM through two pinned staging buffers, the memcpy of chunk i + 1 overlapping the DMA of
+// chunk i.  Returns once `src` has been consumed (the caller may unmap it); the last DMAs may still be in flight on `stream`. ---------------------------
+namespace {
+constexpr size_t kStage = (size_t)32 << 20;
+struct Staging {
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int next = 0;
+    std::mutex mu;
+} g_stage;
+}  // namespace
+extern "C" int mllm_hip_upload(void *dst, const void *src_host, size_t nbytes, void *stream) {
+    if (nbytes == 0) return MLLM_HIP_OK;
+    if (!dst || !src_host) return MLLM_HIP_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_stage.mu);
+    for (int i = 0; i < 2; ++i)
+        if (!g_stage.buf[i]) {
+            MH_CHECK(hipHostMalloc(&g_stage.buf[i], kStage, hipHostMallocDefault));
+            MH_CHECK(hipEventCreateWithFlags(&g_stage.done[i], hipEventDisableTiming));
+        }
+    for (size_t off = 0; off < nbytes; off += kStage) {
+        const int s = g_stage.next;
+        g_stage.next ^= 1;
+        const size_t n = nbytes - off < kStage ? nbytes - off : kStage;
+        if (g_stage.busy[s]) MH_CHECK(hipEventSynchronize(g_stage.done[s]));      // the DMA that last read this staging buffer has finished
+        memcpy(g_stage.buf[s], (const char *)src_host + off, n);
+        MH_CHECK(hipMemcpyAsync((char *)dst + off, g_stage.buf[s], n, hipMemcpyHostToDevice, as_stream(stream)));
+        MH_CHECK(hipEventRecord(g_stage.done[s], as_stream(stream)));
+        g_stage.busy[s] = true;
+    }
+    return MLLM_HIP_OK;
+}
+extern "C" int mllm_hip_upload_release(void) {
+    std::lock_guard<std::mutex> lock(g_stage.mu);
+    for (int i = 0; i < 2; ++i) {
+        if (g_stage.busy[i]) MH_CHECK(hipEventSynchronize(g_stage.done[i]));
+        if (g_stage.buf[i]) { MH_CHECK(hipHostFree(g_stage.buf[i])); MH_CHECK(hipEventDestroy(g_stage.done[i])); }
+        g_stage.buf[i] = nullptr; g_stage.done[i] = nullptr; g_stage.busy[i] = false;
+    }
+    return MLLM_HIP_OK;
+}

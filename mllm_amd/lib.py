@@ -96,15 +96,6 @@ def i64(v):
 
 
 # ---- host-side helpers (no GPU needed) --------------------------------------------------------------------------------
-def quantize_host(dtype: int, x: np.ndarray) -> np.ndarray:
-    """Fixture helper kept for the tests' convenience: forwards to the tooling library (tools/quantlib.py), which is not part of libmllm_hip.so."""
-    from tools import quantlib
-    try:
-        return quantlib.quantize(dtype, x)
-    except ValueError as e:
-        raise MllmHipError(str(e))
-
-
 def build_act_luts():
     g = np.empty(65536, dtype=np.uint16)
     q = np.empty(65536, dtype=np.uint16)

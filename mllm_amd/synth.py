@@ -149,10 +149,6 @@ def qwen2vl_tensors(c: Qwen2VLConfig, vision: bool = True) -> Iterator[Tuple[str
     yield "visual.merger.mlp.2.bias", (H,), "bias"
 
 
-def write_fp32_mllm(path: str, specs) -> None:
-    mf.write_mllm(path, ((n, mf.F32, tensor_f32(n, s, k)) for n, s, k in specs))
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # synthetic prompt / image
 # ---------------------------------------------------------------------------------------------------------------

@@ -21,6 +21,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mllm_amd import mllmfile as mf, synth  # noqa: E402
+from tests.fixtures import weights  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -176,7 +177,7 @@ def e2e_tiny():
     c = synth.qwen2vl_tiny()
     td = tempfile.mkdtemp()
     src, dst = os.path.join(td, "f32.mllm"), os.path.join(td, "q4k.mllm")
-    synth.write_fp32_mllm(src, synth.qwen2vl_tensors(c))
+    weights.write_fp32_mllm(src, synth.qwen2vl_tensors(c))
     subprocess.run([os.path.join(REF, "quantize"), src, dst, "Q4_K"], check=True, capture_output=True)
     pix, grid, ids = synth.qwen2vl_inputs(c, (8, 8), 6)
     pix.tofile(os.path.join(td, "pix.f32"))
@@ -227,7 +228,7 @@ def _ref_weights(specs, target):
     """fp32 .mllm of the synthetic tensors -> the reference's own `quantize` (or the fp32 file itself for an F32 target)."""
     td = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP"))
     src, dst = os.path.join(td, "f32.mllm"), os.path.join(td, "q.mllm")
-    synth.write_fp32_mllm(src, specs)
+    weights.write_fp32_mllm(src, specs)
     if target == mf.F32:
         return td, src
     subprocess.run([os.path.join(REF, "quantize"), src, dst, "Q4_K"], check=True, capture_output=True)

@@ -2,7 +2,8 @@
 usage: python scratch/dec_time.py [config]   config: qwen2vl (default) | qwen15 | llava | tinyllama"""
 import sys, os, numpy as np
 sys.path.insert(0, '.')
-from mllm_amd import lib, synth, weights, mllmfile as mf
+from mllm_amd import lib, synth, mllmfile as mf
+from tests.fixtures import weights
 which = sys.argv[1] if len(sys.argv) > 1 else 'qwen2vl'
 if which == 'qwen2vl':
     cfg = synth.qwen2vl_2b(); path = weights.qwen2vl_file(cfg); pix, grid, ids = synth.qwen2vl_inputs(cfg, (32, 32), 24)

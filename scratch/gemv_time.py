@@ -1,6 +1,7 @@
 import sys, numpy as np
 sys.path.insert(0, '.')
-from mllm_amd import lib, synth, weights
+from mllm_amd import lib, synth
+from tests.fixtures import weights
 cfg = synth.qwen2vl_2b(); path = weights.qwen2vl_file(cfg)
 pix, grid, ids = synth.qwen2vl_inputs(cfg, (32,32), 24)
 m = lib.Qwen2VL(cfg, path)

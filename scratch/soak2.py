@@ -2,7 +2,8 @@
 batch size (identical rows every time), device memory in use unchanged after the first iteration."""
 import sys, os, numpy as np, time, torch
 sys.path.insert(0, '.')
-from mllm_amd import lib, synth, weights
+from mllm_amd import lib, synth
+from tests.fixtures import weights
 cfg = synth.qwen2vl_2b(); path = weights.qwen2vl_file(cfg)
 m = lib.Qwen2VL(cfg, path)
 pix, grid, ids = synth.qwen2vl_inputs(cfg, (32, 32), 24)

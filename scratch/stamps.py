@@ -2,7 +2,8 @@ import sys, os, ctypes as C, numpy as np
 sys.path.insert(0, '.')
 from mllm_amd import lib
 lib.SO_PATH = '/tmp/libmllm_hip_stamps.so'
-from mllm_amd import synth, weights
+from mllm_amd import synth
+from tests.fixtures import weights
 cfg = synth.qwen2vl_2b(); path = weights.qwen2vl_file(cfg)
 pix, grid, ids = synth.qwen2vl_inputs(cfg, (32,32), 24)
 m = lib.Qwen2VL(cfg, path)

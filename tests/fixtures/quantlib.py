@@ -1,5 +1,6 @@
-"""Fixture tooling: the host-side fp32 -> Q4_K / Q4_0 / Q8_0 block quantiser used to write synthetic `.mllm` files (tools/quantizer/host_quantize.cpp
--> tools/libmllm_quant.so).  Not part of the product library: libmllm_hip.so neither contains nor needs it."""
+"""TEST FIXTURE TOOLING, not product: the host-side fp32 -> Q4_K / Q4_0 / Q8_0 block quantiser used to write synthetic `.mllm` files
+(tests/fixtures/quantizer/host_quantize.cpp -> tests/fixtures/libmllm_quant.so).  It follows the reference's quantiser statement for statement (it has to:
+the files must be byte-identical to what `quantize ... Q4_K` writes, tests/test_host.py), which is why it lives under tests/ and nothing in mllm_amd/ imports it."""
 from __future__ import annotations
 
 import ctypes as C

@@ -1,4 +1,4 @@
-"""Build synthetic `*-q4_k.mllm` files with the product's own quantiser (no dependency on the reference tool).
+"""TEST FIXTURE TOOLING, not product: builds synthetic `*-q4_k.mllm` files with the fixture quantiser (tests/fixtures/quantlib.py; no dependency on the reference tool at run time).
 
 Same per-name dtype policy and block formats as `quantize <in> <out> Q4_K` of the reference
 (tools/quantizer/QuantWriter.cpp:123-157,288-300); byte-for-byte agreement with it is pinned by tests/test_host.py
@@ -11,14 +11,16 @@ import os
 
 import numpy as np
 
-from . import lib, mllmfile as mf, synth
+from mllm_amd import mllmfile as mf, synth
+
+from . import quantlib
 
 
 def _make_tensor(args):
     name, shape, kind, target = args
     x = synth.tensor_f32(name, shape, kind)
     dt = synth.storage_dtype(name, target)
-    return name, dt, (x if dt == mf.F32 else lib.quantize_host(dt, x))
+    return name, dt, (x if dt == mf.F32 else quantlib.quantize(dt, x))
 
 
 def build_q4k_file(path: str, specs, target: int = mf.Q4_K, workers: int | None = None) -> str:
@@ -80,3 +82,8 @@ def llava_file(cfg: synth.LLaVAConfig, cache_dir: str = "/tmp/mllm_amd_cache") -
     if not os.path.exists(path):
         build_q4k_file(path, synth.llava_tensors(cfg))
     return path
+
+
+def write_fp32_mllm(path: str, specs) -> None:
+    """The fp32 `.mllm` of the synthetic tensors -- the input of the reference's own `quantize` tool (oracle/make_golden.py)."""
+    mf.write_mllm(path, ((n, mf.F32, synth.tensor_f32(n, s, k)) for n, s, k in specs))

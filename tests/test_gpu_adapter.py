@@ -1,0 +1,70 @@
+"""SURVEY §8(b), executed: the reference's OWN Qwen2VLModel -- its Module / Layer / Tensor frontend compiled from the reference tree, unchanged -- runs on the MI355X
+through the Backend / Op adapter of integration/hip/ (`model.to(<hip slot>)` then `model.load(path)`, examples/demo_qwen.cpp:43-59) and must give the bits the same
+model gave on the reference's x86 CPU backend (tests/golden/qwen2vl_tiny.npz): greedy ids and every logit of every step, image + text and text only.
+The driver (oracle/ref_drivers/ref_hip_qwen2vl.cpp) is built in the container by oracle/Makefile.ref into oracle/_ref/ and travels to the GPU box as a binary.  It also
+reports which Ops the backend refused, i.e. ran on the CPU backend instead: the bar is none."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_hip_qwen2vl")
+
+
+def _cfg_string(c):
+    return (f"{c.hidden},{c.inter},{c.layers},{c.heads},{c.kv_heads},{c.vocab},{c.v_dim},{c.cache_limit},{c.image_token_id},{c.vision_start_token_id},"
+            f"{c.vision_end_token_id},{c.video_token_id}")
+
+
+def _run(td, cfg, path, ids, steps, pix=None, grid=None):
+    ids.astype(np.int32).tofile(os.path.join(td, "ids.i32"))
+    cmd = [DRIVER, "--model", path, "--ids", os.path.join(td, "ids.i32"), "--steps", str(steps), "--threads", "4", "--out", td, "--cfg", _cfg_string(cfg), "--dump-every", "1"]
+    if pix is not None:
+        pix.astype(np.float32).tofile(os.path.join(td, "pix.f32"))
+        cmd += ["--pix", os.path.join(td, "pix.f32"), "--grid", ",".join(str(int(g)) for g in grid)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
+    report = json.loads(next(l for l in out.stdout.splitlines() if l.startswith('{"backend"')))
+    toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
+    logits = np.stack([np.fromfile(os.path.join(td, f"logits_{s}.f32"), dtype=np.float32) for s in range(steps)])
+    return report, toks, logits
+
+
+@pytest.fixture(scope="module")
+def tiny(tmp_path_factory):
+    if not os.path.exists(DRIVER):
+        pytest.skip("oracle/_ref/ref_hip_qwen2vl was not built (make -f oracle/Makefile.ref, container only)")
+    from mllm_amd import synth
+    from tests.fixtures import weights
+    cfg = synth.qwen2vl_tiny()
+    return cfg, weights.qwen2vl_file(cfg, cache_dir=str(tmp_path_factory.mktemp("w")))
+
+
+def test_reference_module_on_the_hip_backend_matches_its_cpu_run(tiny, tiny_gold, tmp_path):
+    from mllm_amd import synth
+    cfg, path = tiny
+    g = tiny_gold
+    pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
+    assert np.array_equal(ids, g["ids"])
+    steps = len(g["tokens"])
+    report, toks, logits = _run(str(tmp_path), cfg, path, ids, steps, pix, grid)
+    print("adapter report:", report)
+    assert report["cpu_fallback_ops"] == 0 and report["refused"] == [], report
+    assert report["hip_ops_run"] > 600
+    assert toks.tolist() == g["tokens"].tolist(), (toks.tolist(), g["tokens"].tolist())
+    assert np.array_equal(logits, g["logits"]), float(np.max(np.abs(logits - g["logits"])))
+
+
+def test_reference_module_text_only_prompt(tiny, tiny_gold, tmp_path):
+    cfg, path = tiny
+    g = tiny_gold
+    steps = len(g["tokens_text"])
+    report, toks, logits = _run(str(tmp_path), cfg, path, g["ids_text"], steps)
+    assert report["cpu_fallback_ops"] == 0, report
+    assert toks.tolist() == g["tokens_text"].tolist()
+    assert np.array_equal(logits, g["logits_text"]), float(np.max(np.abs(logits - g["logits_text"])))

@@ -10,7 +10,8 @@ import pytest
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-from mllm_amd import lib, synth, weights  # noqa: E402
+from mllm_amd import lib, synth  # noqa: E402
+from tests.fixtures import weights  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -161,7 +162,7 @@ def test_lane_per_superblock_projection_on_short_rows(tmp_path):
     code = (
         "import os, sys, numpy as np\n"
         "sys.path.insert(0, %r)\n"
-        "from mllm_amd import lib, synth, weights\n"
+        "from mllm_amd import lib, synth\nfrom tests.fixtures import weights\n"
         "g = np.load(%r)\n"
         "cfg = synth.qwen2vl_tiny()\n"
         "m = lib.Qwen2VL(cfg, weights.qwen2vl_file(cfg, cache_dir=%r))\n"

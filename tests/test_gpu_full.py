@@ -10,7 +10,8 @@ import pytest
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-from mllm_amd import lib, synth, weights  # noqa: E402
+from mllm_amd import lib, synth  # noqa: E402
+from tests.fixtures import weights  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

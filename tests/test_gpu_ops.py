@@ -10,6 +10,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from mllm_amd import lib, mllmfile as mf, ops  # noqa: E402
+from tests.fixtures import quantlib  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
@@ -64,7 +65,7 @@ def _q4k_case(M, K, N, seed, bias=True):
     W = (r.standard_normal((N, K)) * 0.05).astype(np.float32)
     x = r.standard_normal((M, K)).astype(np.float32)
     b = (r.standard_normal(N) * 0.1).astype(np.float32) if bias else None
-    return lib.quantize_host(lib.Q4_K, W), x, b
+    return quantlib.quantize(lib.Q4_K, W), x, b
 
 
 @pytest.mark.parametrize("M,K,N", [(1, 1536, 2048), (1, 8960, 1536), (1, 256, 64), (1, 1280, 3840), (3, 512, 96), (1, 11008, 128)])
@@ -145,7 +146,7 @@ def test_linear_is_linear_in_weights_rows_and_zero_input():
     give bit-identical outputs whichever wave computes them."""
     K, N = 1536, 17920
     r = rng(11)
-    blk = lib.quantize_host(lib.Q4_K, (r.standard_normal((64, K)) * 0.02).astype(np.float32)).reshape(64, -1)
+    blk = quantlib.quantize(lib.Q4_K, (r.standard_normal((64, K)) * 0.02).astype(np.float32)).reshape(64, -1)
     Wq = np.tile(blk, (N // 64, 1)).ravel()
     x = r.standard_normal((1, K)).astype(np.float32)
     y = ops.linear_q4k(Wq, x, N).cpu().numpy().reshape(N // 64, 64)
@@ -159,7 +160,7 @@ def test_linear_is_linear_in_weights_rows_and_zero_input():
 @pytest.mark.parametrize("K,N", [(1536, 4096), (512, 160), (1024, 999), (4096, 64)])
 def test_linear_q40_vs_oracle(K, N):
     r = rng(K + N)
-    Wq = lib.quantize_host(lib.Q4_0, (r.standard_normal((N, K)) * 0.05).astype(np.float32))
+    Wq = quantlib.quantize(lib.Q4_0, (r.standard_normal((N, K)) * 0.05).astype(np.float32))
     x = r.standard_normal((1, K)).astype(np.float32)
     y = ops.linear_q40(Wq, x, N)
     ref = orc.linear(x, Wq, orc.Q4_0, N)

@@ -10,7 +10,8 @@ import os
 import numpy as np
 import pytest
 
-from mllm_amd import lib, mllmfile as mf, synth, weights
+from mllm_amd import lib, mllmfile as mf, synth
+from tests.fixtures import quantlib, weights
 from oracle import oracle as orc
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -25,17 +26,22 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_quantized_nbytes_and_errors():
-    from tools import quantlib
     assert quantlib.nbytes(quantlib.Q4_K, 512) == 288
     assert quantlib.nbytes(quantlib.Q4_0, 64) == 36
     assert quantlib.nbytes(quantlib.Q4_K, 100) == -1
-    with pytest.raises(lib.MllmHipError):
-        lib.quantize_host(lib.Q4_K, np.zeros(100, dtype=np.float32))
+    with pytest.raises(ValueError):
+        quantlib.quantize(lib.Q4_K, np.zeros(100, dtype=np.float32))
 
 
 def test_product_library_does_not_contain_the_fixture_quantiser():
     so = lib.load()
     assert not hasattr(so, "mllm_hip_quantize_host") and not hasattr(so, "mllm_quant_rows")
+    # ... and nothing under mllm_amd/ imports the fixture tooling (it lives under tests/fixtures/)
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mllm_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "quantlib" not in src and "quantize_host" not in src and "tests.fixtures" not in src, f
 
 
 def test_mllm_file_roundtrip(tmp_path):
@@ -88,7 +94,7 @@ def test_host_quantizer_full_size_digests():
 
 def test_q80_host_quantizer_vs_oracle():
     x = np.random.default_rng(3).standard_normal(32 * 40).astype(np.float32)
-    assert np.array_equal(lib.quantize_host(lib.Q8_0, x), orc.quantize_q8_0(x).ravel())
+    assert np.array_equal(quantlib.quantize(lib.Q8_0, x), orc.quantize_q8_0(x).ravel())
 
 
 def test_rotary_tables_match_oracle():

@@ -29,3 +29,37 @@ def test_hip_adapter_compiles_and_links_against_the_reference():
     used = {l.split()[-1] for l in syms.splitlines() if " U mllm_hip_" in l}
     assert used and used <= declared, used - declared
     assert {"mllm_hip_linear_q4kp_packed", "mllm_hip_fa2", "mllm_hip_rope_apply", "mllm_hip_rmsnorm", "mllm_hip_embedding_q40", "mllm_hip_patch_gemm_f32"} <= used
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not present (GPU box)")
+def test_reference_module_runs_through_the_adapter_on_the_null_device(tmp_path):
+    """The adapter's plumbing, executed in the container: the reference's own Qwen2VLModel (Module / Layer / Tensor frontend compiled from the reference tree) is moved
+    onto the HIP backend and run -- trace pass of `to()`, load pass, image prefill, decode steps -- with the device entry points of the C ABI replaced by the null device of
+    oracle/mock/mock_hip_abi.cpp (host memory; every launcher reads all its inputs and writes all its outputs) under AddressSanitizer.  No arithmetic is checked here (that
+    is tests/test_gpu_adapter.py on the MI355X); what is checked: no Op was refused (no CPU fallback), no ASan report, and device blocks do not leak from step to step."""
+    import json
+
+    import numpy as np
+
+    from mllm_amd import build as b, synth
+    from tests.fixtures import weights
+    b.build()
+    subprocess.run(["make", "-f", "oracle/Makefile.ref", "-j8", "mock"], cwd=ROOT, check=True, capture_output=True, timeout=1500)
+    exe = os.path.join(ROOT, "oracle", "_ref", "mock_hip_qwen2vl")
+    c = synth.qwen2vl_tiny()
+    path = weights.qwen2vl_file(c)
+    pix, grid, ids = synth.qwen2vl_inputs(c, (8, 8), 6)
+    pix.tofile(str(tmp_path / "pix.f32"))
+    ids.tofile(str(tmp_path / "ids.i32"))
+    cfg = f"{c.hidden},{c.inter},{c.layers},{c.heads},{c.kv_heads},{c.vocab},{c.v_dim},{c.cache_limit},{c.image_token_id},{c.vision_start_token_id},{c.vision_end_token_id},{c.video_token_id}"
+    reports = []
+    for steps in (2, 9):
+        out = subprocess.run([exe, "--model", path, "--ids", str(tmp_path / "ids.i32"), "--pix", str(tmp_path / "pix.f32"), "--grid", "1,8,8", "--steps", str(steps), "--threads", "2",
+                              "--out", str(tmp_path), "--cfg", cfg], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert out.returncode == 0 and "AddressSanitizer" not in out.stderr, (out.returncode, out.stderr[-3000:])
+        reports.append(json.loads(next(l for l in out.stdout.splitlines() if l.startswith('{"backend"'))))
+    for r in reports:
+        assert r["cpu_fallback_ops"] == 0 and r["refused"] == [], r
+    assert reports[0]["live_device_blocks"] == reports[1]["live_device_blocks"], reports      # nothing accumulates over decode steps
+    assert reports[1]["hip_ops_run"] > reports[0]["hip_ops_run"] > 600
+    assert len(np.fromfile(str(tmp_path / "tokens.i32"), dtype=np.int32)) == 9
