@@ -54,6 +54,12 @@ int mllm_hip_free(void *dptr);
 int mllm_hip_h2d(void *dst, const void *src, size_t nbytes, void *stream);
 int mllm_hip_d2h(void *dst, const void *src, size_t nbytes, void *stream);
 int mllm_hip_sync(void *stream);
+/* Measurement / bring-up switches of the launch paths.  They live in the library, not in the caller's environment: a shipped process picks the same kernels whatever
+ * its environment holds (the one environment variable left is MLLM_HIP_NO_GRAPH, read once per model by the profiling scripts to replay the decode step as plain launches).
+ * value -1 = unset (built-in choice).  Names: vision_batch (images per tower pass), time_layers (layers mllm_hip_model_time_kernel cycles over), no_gub / no_pjb (the
+ * 8-lanes-per-block GEMVs instead of one lane per super-block), pjb_min_ns, attn_flags, attn_ds (workgroups per head of the decode attention), head_wpc, gemm_order. */
+int mllm_hip_set_option(const char *name, int value);
+int mllm_hip_get_option(const char *name, int *value);
 /* one in-order stream per backend instance (hipStream_t as void*); the OpenCL backend's command queue, OpenCLBackend.cpp:476-477 */
 int mllm_hip_stream_create(void **stream);
 int mllm_hip_stream_destroy(void *stream);
@@ -77,7 +83,8 @@ int mllm_hip_quantize_q80(const float *x, int8_t *qs, uint16_t *d, int M, int K,
  *      y[m][n] = vec_dot(W[n], xq[m]) (+ bias[n]); y fp32 or fp16 (Matmul.cpp:257-268), row stride ldy elements.
  *      q4k: vec_dot_q4_K_q8_K (ggml VecDotQ4.cpp:32-346); q40: vec_dot_q4_0_q8_0 (:514-545, weights as planes);
  *      f32: vec_dot_fp32 (ggml VecDotFP32.cpp:31-58). `residual` (optional, fp32 [M][N] with stride ldy) is added after
- *      the bias: the `x + inputs[0]` of the decoder blocks (models/qwen2_vl/modeling_qwen2_vl.hpp:320-323) fused in. --- */
+ *      the bias: the `x + inputs[0]` of the decoder blocks (models/qwen2_vl/modeling_qwen2_vl.hpp:320-323) fused in; with an fp16
+ *      output a non-NULL residual is refused (MLLM_HIP_ERR_DTYPE). --- */
 int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums,
                             void *y, int y_dtype, int64_t ldy, const float *residual, int M, int N, int K, void *stream);
 int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, const float *bias, const int8_t *xqs, const uint16_t *xd,
@@ -277,6 +284,10 @@ void mllm_hip_model_destroy(mllm_hip_model *m);
 /* load-time report in the spirit of Module::profiling()'s load_time (mllm/Module.cpp:25-33): wall ms of create(), bytes read from
  * the file, ms the copy stream was busy, ms of repack kernels.  Any pointer may be NULL. */
 int mllm_hip_model_load_stats(const mllm_hip_model *m, float *total_ms, int64_t *file_bytes, float *h2d_ms, float *repack_ms);
+/* device bytes the model holds after the load (weights in the forms its kernels read, activations, KV slabs), and the bytes of weight forms that were NOT kept
+ * because no caller reads them: the GEMM-order copy of a Linear lm_head (it only ever meets one row), the on-disk rows of the vision-tower blocks once packed
+ * (a tower pass never has fewer than 16 rows). */
+int mllm_hip_model_memory_stats(const mllm_hip_model *m, int64_t *resident_bytes, int64_t *released_bytes);
 /* Module::clear_kvcache: KVCache sequence counters and RoPE position counters back to 0 (CPUKVCache.hpp:26-29, CPURoPE.hpp:63-65) */
 int mllm_hip_model_clear_kvcache(mllm_hip_model *m);
 /* One prefill forward.  ids: n_ids host ints.  image (optional, fp32, host or device memory): QWEN2VL pixel_values `[n_patch][3*2*14*14]` with
@@ -359,11 +370,12 @@ int mllm_hip_topk_rows(const float *x, int64_t ldx, float *values, float *indice
 /* F_BINCOUNT (CPUBinCountFunc.hpp:20-35): counts of the integer parts 0 .. nbins-1 (the reference's output has max + 1 entries; pass the bins wanted) */
 int mllm_hip_bincount(const float *ids, int n, float *counts, int nbins, void *stream);
 /* Tensor::clip(index, SEQUENCE) (CPUClipFunc.hpp:309-323): out[r] = src[idx[r]]; with skip_negative = 1 and out = the word-embedding rows it is
- * F_FUYU_GATHER_EMBD (CPUFuyuGatherEmbdFunc.hpp:45-62): rows whose index is negative keep their contents. */
-int mllm_hip_gather_rows(const float *src, int64_t lds, const float *idx, float *out, int64_t ldo, int R, int D, int skip_negative, void *stream);
+ * F_FUYU_GATHER_EMBD (CPUFuyuGatherEmbdFunc.hpp:45-62): rows whose index is negative keep their contents.  `src` has n_src_rows rows: an index outside
+ * [0, n_src_rows) is never dereferenced and leaves its output row untouched (the reference would read out of bounds). */
+int mllm_hip_gather_rows(const float *src, int64_t lds, int n_src_rows, const float *idx, float *out, int64_t ldo, int R, int D, int skip_negative, void *stream);
 /* F_SCATTERADD on SEQUENCE (Tensor::scatter_add, CPUScatterAddFunc.hpp:38-52; the MoE combine): dst[idx[r]] += src[r] for r ascending -- a repeated
- * destination row accumulates in that order. */
-int mllm_hip_scatter_add_rows(float *dst, int64_t ldd, const float *src, int64_t lds, const float *idx, int R, int D, void *stream);
+ * destination row accumulates in that order.  `dst` has n_dst_rows rows; a source row whose index lies outside [0, n_dst_rows) is skipped. */
+int mllm_hip_scatter_add_rows(float *dst, int64_t ldd, int n_dst_rows, const float *src, int64_t lds, const float *idx, int R, int D, void *stream);
 
 #ifdef __cplusplus
 }

@@ -491,7 +491,7 @@ public:
     ErrorCode execute(TensorList inputs, TensorList) override {
         if (inputs[1]->batch() == 0) return MLLM_NO_ERROR;
         const int D = inputs[0]->dimension();
-        HIPCHK(mllm_hip_scatter_add_rows((float *)dptr(inputs[0]), D, (const float *)dptr(inputs[1]), D, (const float *)dptr(inputs[2]), inputs[2]->dimension(), D, hb()->stream()));
+        HIPCHK(mllm_hip_scatter_add_rows((float *)dptr(inputs[0]), D, inputs[0]->sequence(), (const float *)dptr(inputs[1]), D, (const float *)dptr(inputs[2]), inputs[2]->dimension(), D, hb()->stream()));
         return MLLM_NO_ERROR;
     }
 };

@@ -218,13 +218,14 @@ struct mllm_hip_model {
     // state
     int cache_len = 0;
     float last_pos = -1.0f;
-    int64_t decode_weight_bytes = 0;
+    int64_t decode_weight_bytes = 0, resident_bytes = 0, released_bytes = 0;      // device bytes held after the load / raw rows and packs not kept (load_linear_q4k)
     float load_total_ms = 0, load_h2d_ms = 0, load_tail_ms = 0;
 
     template <typename T> int dalloc(T **p, size_t n, std::vector<void *> *list = nullptr) {
         void *q = nullptr;
         MH_CHECK(hipMalloc(&q, n ? n : 16));
         (list ? *list : allocs).push_back(q);
+        if (list != &temps) resident_bytes += (int64_t)n;
         *p = (T *)q;
         return 0;
     }
@@ -248,13 +249,20 @@ static int load_f32(M *m, const MllmFile &f, const std::string &n, size_t count,
     return m->ld.put(*out, f.base + e->off, count * 4);
 }
 
-// rows of several Q4_K Linear weights (same K) concatenated; biases concatenated.  `decode`: also the decode-order copy for the fused decode kernels.
-static int load_linear_q4k(M *m, const MllmFile &f, const std::vector<std::string> &names, const std::vector<int> &Ns, int K, bool bias, bool decode, LinearW *lw) {
+// rows of several Q4_K Linear weights (same K) concatenated; biases concatenated.  `forms` says which device copies the Linear's callers read:
+//   LW_RAW     the rows as stored on disk: the GEMV of passes with fewer than 16 rows (lin()), dec_gateup_blk / dec_proj_blk, the Linear lm_head
+//   LW_PACK    the GEMM order of mllm_hip_q4k_prepack: passes of 16 rows and more (prefill, the vision tower)
+//   LW_DECODE  the class-per-lane decode order (decode_order_q4k) of the fused decode kernels
+// A form nobody reads is not kept: the lm_head only ever meets one row (no LW_PACK), a tower block never fewer than 16 (its raw rows are released once packed).
+enum { LW_RAW = 1, LW_PACK = 2, LW_DECODE = 4 };
+static int load_linear_q4k(M *m, const MllmFile &f, const std::vector<std::string> &names, const std::vector<int> &Ns, int K, bool bias, int forms, LinearW *lw) {
     int N = 0;
     for (int n : Ns) N += n;
     const size_t row = (size_t)K / 256 * 144;
     uint8_t *w;
-    EH(m->dalloc(&w, row * N));
+    const bool keep_raw = (forms & LW_RAW) != 0;
+    EH(m->dalloc(&w, row * N, keep_raw ? nullptr : &m->temps));      // temps: freed when the load-time repacks have run
+    if (!keep_raw) m->released_bytes += (int64_t)(row * N);
     size_t ro = 0;
     for (size_t i = 0; i < names.size(); ++i) {
         const Entry *e;
@@ -262,7 +270,7 @@ static int load_linear_q4k(M *m, const MllmFile &f, const std::vector<std::strin
         EH(m->ld.put(w + ro * row, f.base + e->off, row * Ns[i]));
         ro += Ns[i];
     }
-    lw->w = w; lw->N = N; lw->K = K;
+    lw->w = keep_raw ? w : nullptr; lw->N = N; lw->K = K;
     if (bias) {
         EH(m->dalloc(&lw->bias, (size_t)N * 4));
         size_t bo = 0;
@@ -275,13 +283,15 @@ static int load_linear_q4k(M *m, const MllmFile &f, const std::vector<std::strin
     }
     // load-time repacks on the compute stream, behind the copies of this tensor; the next tensor's copies run meanwhile
     EH(m->ld.fence(m->st));
-    {
+    if (forms & LW_PACK) {
         uint8_t *wp;
         EH(m->dalloc(&wp, mllm_hip_q4k_wpack_bytes(N, K)));
         EH(mllm_hip_q4k_prepack(w, N, K, wp, m->st));
         lw->wp = wp;
+    } else {
+        m->released_bytes += (int64_t)mllm_hip_q4k_wpack_bytes(N, K);      // the GEMM-order copy that is not made
     }
-    if (decode) {
+    if (forms & LW_DECODE) {
         const int64_t nblk = (int64_t)N * (K / 256);
         uint8_t *wd = nullptr;
         EH(m->dalloc(&wd, (size_t)nblk * 144));
@@ -302,11 +312,11 @@ static int load_vblock(M *m, const MllmFile &f, M::VBlock &B, const std::string 
                        const std::string &proj, const std::string &fc1, const std::string &fc2, int V, int F) {
     EH(load_f32(m, f, n1 + ".weight", V, &B.n1w)); EH(load_f32(m, f, n1 + ".bias", V, &B.n1b));
     EH(load_f32(m, f, n2 + ".weight", V, &B.n2w)); EH(load_f32(m, f, n2 + ".bias", V, &B.n2b));
-    if (qkv.size() == 1) EH(load_linear_q4k(m, f, qkv, {3 * V}, V, true, false, &B.qkv));
-    else EH(load_linear_q4k(m, f, qkv, {V, V, V}, V, true, false, &B.qkv));
-    EH(load_linear_q4k(m, f, {proj}, {V}, V, true, false, &B.proj));
-    EH(load_linear_q4k(m, f, {fc1}, {F}, V, true, false, &B.fc1));
-    EH(load_linear_q4k(m, f, {fc2}, {V}, F, true, false, &B.fc2));
+    if (qkv.size() == 1) EH(load_linear_q4k(m, f, qkv, {3 * V}, V, true, LW_PACK, &B.qkv));
+    else EH(load_linear_q4k(m, f, qkv, {V, V, V}, V, true, LW_PACK, &B.qkv));
+    EH(load_linear_q4k(m, f, {proj}, {V}, V, true, LW_PACK, &B.proj));
+    EH(load_linear_q4k(m, f, {fc1}, {F}, V, true, LW_PACK, &B.fc1));
+    EH(load_linear_q4k(m, f, {fc2}, {V}, F, true, LW_PACK, &B.fc2));
     return 0;
 }
 
@@ -334,17 +344,17 @@ static int create_impl(M *m, const MllmFile &f) {
             const std::string p = P + "model.layers." + std::to_string(i) + ".";
             EH(load_f32(m, f, p + "input_layernorm.weight", H, &L.in_norm));
             EH(load_f32(m, f, p + "post_attention_layernorm.weight", H, &L.post_norm));
-            EH(load_linear_q4k(m, f, {p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"}, {m->HD, m->KVD, m->KVD}, H, c.qkv_bias != 0, true, &L.qkv));
-            EH(load_linear_q4k(m, f, {p + "self_attn.o_proj"}, {H}, m->HD, false, true, &L.o));
-            EH(load_linear_q4k(m, f, {p + "mlp.gate_proj", p + "mlp.up_proj"}, {I, I}, H, false, true, &L.gu));
-            EH(load_linear_q4k(m, f, {p + "mlp.down_proj"}, {H}, I, false, true, &L.down));
+            EH(load_linear_q4k(m, f, {p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"}, {m->HD, m->KVD, m->KVD}, H, c.qkv_bias != 0, LW_RAW | LW_PACK | LW_DECODE, &L.qkv));
+            EH(load_linear_q4k(m, f, {p + "self_attn.o_proj"}, {H}, m->HD, false, LW_RAW | LW_PACK | LW_DECODE, &L.o));
+            EH(load_linear_q4k(m, f, {p + "mlp.gate_proj", p + "mlp.up_proj"}, {I, I}, H, false, LW_RAW | LW_PACK | LW_DECODE, &L.gu));
+            EH(load_linear_q4k(m, f, {p + "mlp.down_proj"}, {H}, I, false, LW_RAW | LW_PACK | LW_DECODE, &L.down));
         }
         EH(load_f32(m, f, P + "model.norm.weight", H, &m->final_norm));
         m->decode_weight_bytes = (int64_t)c.layers * ((int64_t)(m->QKV + H) * (H / 256) * 144 + (int64_t)2 * I * (H / 256) * 144 + (int64_t)H * (I / 256) * 144);
         if (c.tie_embedding) {
             m->decode_weight_bytes += (int64_t)c.vocab * (H / 32) * 18;
         } else {
-            EH(load_linear_q4k(m, f, {P + "lm_head"}, {c.vocab}, H, false, true, &m->head));
+            EH(load_linear_q4k(m, f, {P + "lm_head"}, {c.vocab}, H, false, LW_RAW | LW_DECODE, &m->head));
             m->decode_weight_bytes += (int64_t)c.vocab * (H / 256) * 144;
         }
     }
@@ -360,8 +370,8 @@ static int create_impl(M *m, const MllmFile &f) {
                 EH(load_vblock(m, f, m->vblocks[i], p + "norm1", p + "norm2", {p + "attn.qkv"}, p + "attn.proj", p + "mlp.fc1", p + "mlp.fc2", V, VM));
             }
             EH(load_f32(m, f, "visual.merger.ln_q.weight", V, &m->lnq_w)); EH(load_f32(m, f, "visual.merger.ln_q.bias", V, &m->lnq_b));
-            EH(load_linear_q4k(m, f, {"visual.merger.mlp.0"}, {MM}, MM, true, false, &m->m0));
-            EH(load_linear_q4k(m, f, {"visual.merger.mlp.2"}, {H}, MM, true, false, &m->m2));
+            EH(load_linear_q4k(m, f, {"visual.merger.mlp.0"}, {MM}, MM, true, LW_RAW | LW_PACK, &m->m0));
+            EH(load_linear_q4k(m, f, {"visual.merger.mlp.2"}, {H}, MM, true, LW_RAW | LW_PACK, &m->m2));
         } else {
             const bool clip = m->vkind == V_CLIP;
             const int F = c.v_ffn, KK = 3 * c.v_patch * c.v_patch, NP = (c.v_img / c.v_patch) * (c.v_img / c.v_patch) + 1;
@@ -386,11 +396,11 @@ static int create_impl(M *m, const MllmFile &f) {
                 }
             }
             if (clip) {
-                EH(load_linear_q4k(m, f, {"multi_modal_projector.linear_1"}, {F}, V, true, false, &m->m0));
-                EH(load_linear_q4k(m, f, {"multi_modal_projector.linear_2"}, {F}, F, true, false, &m->m2));
+                EH(load_linear_q4k(m, f, {"multi_modal_projector.linear_1"}, {F}, V, true, LW_RAW | LW_PACK, &m->m0));
+                EH(load_linear_q4k(m, f, {"multi_modal_projector.linear_2"}, {F}, F, true, LW_RAW | LW_PACK, &m->m2));
             } else {
                 EH(load_f32(m, f, "vit.layernorm.weight", V, &m->lnq_w)); EH(load_f32(m, f, "vit.layernorm.bias", V, &m->lnq_b));
-                EH(load_linear_q4k(m, f, {"classifier"}, {c.v_classes}, V, false, false, &m->m0));
+                EH(load_linear_q4k(m, f, {"classifier"}, {c.v_classes}, V, false, LW_RAW | LW_PACK, &m->m0));
             }
         }
         std::vector<uint16_t> g(65536), q(65536);
@@ -527,6 +537,13 @@ extern "C" int mllm_hip_model_load_stats(const mllm_hip_model *m, float *total_m
     return MLLM_HIP_OK;
 }
 
+extern "C" int mllm_hip_model_memory_stats(const mllm_hip_model *m, int64_t *resident_bytes, int64_t *released_bytes) {
+    if (!m) return MLLM_HIP_ERR_ARG;
+    if (resident_bytes) *resident_bytes = m->resident_bytes;
+    if (released_bytes) *released_bytes = m->released_bytes;
+    return MLLM_HIP_OK;
+}
+
 extern "C" void mllm_hip_model_destroy(mllm_hip_model *m) {
     if (!m) return;
     // teardown: nothing useful can be done with a failing release, the codes are dropped on purpose
@@ -637,6 +654,7 @@ static int q_layernorm(M *m, const float *x, const float *w, const float *b, con
 }
 // Linear on the activations the last q_* call produced
 static int lin(M *m, const LinearW &w, const Q8Planes &x, void *y, int ydt, int64_t ldy, const float *res, int Mrows) {
+    if (Mrows >= 16 ? !w.wp : !w.w) { fprintf(stderr, "mllm_hip: a Linear met %d rows, a form it was not loaded for\n", Mrows); return MLLM_HIP_ERR_SHAPE; }
     if (Mrows >= 16) return mllm_hip_linear_q4kp_packed(w.wp, w.bias, m->xpack, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
     return mllm_hip_linear_q4k_q8k(w.w, w.bias, x.qs, x.d, x.bs, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
 }
@@ -968,6 +986,17 @@ static int launch_step(M *m) {
     return decode_step_launch(m->dctx, m->dlayers.data(), (int)m->dlayers.size(), m->st);
 }
 
+// After a failure inside a decode loop the host's counters follow the device's DecodeState (which the steps that did run have advanced), so a caller that carries on
+// does so from the state the cache is really in.  Best effort: if the device cannot be read either, the counters stay as they were.
+static int resync_after_error(mllm_hip_model *m, int rc) {
+    DecodeState st;
+    if (hipStreamSynchronize(m->st) == hipSuccess && hipMemcpy(&st, m->d_state, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess && st.T >= 0 && st.T <= m->c.cache_limit) {
+        m->last_pos += (float)(st.T - m->cache_len);
+        m->cache_len = st.T;
+    }
+    return rc;
+}
+
 extern "C" int mllm_hip_model_decode(mllm_hip_model *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms) {
     if (!m || !m->has_llm || m->cache_len <= 0) return MLLM_HIP_ERR_ARG;
     if (m->cache_len + 1 > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + 1 > %d)\n", m->cache_len, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
@@ -988,7 +1017,8 @@ extern "C" int mllm_hip_model_generate(mllm_hip_model *m, int32_t first_token, i
     const int step0 = st0.step;
     HH(hipMemcpy(&m->d_state->token, &first_token, 4, hipMemcpyHostToDevice));
     HH(hipEventRecord(m->ev0, m->st));
-    for (int s = 0; s < steps; ++s) EH(launch_step(m));
+    for (int s = 0; s < steps; ++s)
+        if (int rc = launch_step(m)) return resync_after_error(m, rc);
     m->cache_len += steps;
     m->last_pos += (float)steps;
     EH(finish(m, nullptr, nullptr, elapsed_ms));
@@ -1006,6 +1036,7 @@ extern "C" int mllm_hip_model_generate_sampled(mllm_hip_model *m, int32_t first_
     if (!m || !m->has_llm || m->cache_len <= 0 || steps <= 0 || method < 0 || method > 2) return MLLM_HIP_ERR_ARG;
     if (method != 0 && (!u01 || !(temperature > 0.0f))) return MLLM_HIP_ERR_ARG;
     if (method == 1 && (top_k < 0 || top_k > 64 || top_k > m->c.vocab)) return MLLM_HIP_ERR_SHAPE;
+    if (method == 2 && !(top_p > 0.0f)) return MLLM_HIP_ERR_ARG;      // p <= 0 or NaN keeps no candidate at all (the reference then indexes an empty vector, Generate.cpp:116-118)
     if (m->cache_len + steps > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + %d > %d)\n", m->cache_len, steps, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
     const int V = m->c.vocab;
     if (method != 0 && !m->samp_val) {
@@ -1018,7 +1049,8 @@ extern "C" int mllm_hip_model_generate_sampled(mllm_hip_model *m, int32_t first_
     int made = 0;
     std::vector<float> val, prob;
     std::vector<int> idx;
-    for (int s = 0; s < steps; ++s) {
+    // one step; the host counters advance once the step's launches are enqueued, and every later failure re-reads the device state (resync_after_error)
+    auto one_step = [&](int s, int32_t *out) -> int {
         HH(hipMemcpyAsync(&m->d_state->token, &tok, 4, hipMemcpyHostToDevice, m->st));
         EH(launch_step(m));
         m->cache_len += 1;
@@ -1064,6 +1096,12 @@ extern "C" int mllm_hip_model_generate_sampled(mllm_hip_model *m, int32_t first_
                 next = idx[mllm_hip_sample_index_host(prob.data(), k, u01[s])];
             }
         }
+        *out = next;
+        return 0;
+    };
+    for (int s = 0; s < steps; ++s) {
+        int32_t next = 0;
+        if (int rc = one_step(s, &next)) { if (n_out) *n_out = made; return resync_after_error(m, rc); }
         if (tokens_host) tokens_host[made] = next;
         ++made;
         tok = next;
@@ -1084,7 +1122,7 @@ extern "C" int mllm_hip_model_vision(mllm_hip_model *m, const float *images_host
     // images per pass: up to about 6400 token rows (the row-wise kernels then fill the chip even for 197-token images), at most 32, the images spread evenly over
     // the passes (8 images at 7 per pass = 4 + 4, not 7 + 1)
     int NB = std::max(1, std::min(std::min(32, 6400 / std::max(nt, 1)), n_img));
-    if (const char *e = getenv("MLLM_HIP_VISION_BATCH")) NB = std::max(1, std::min(atoi(e), n_img));
+    if (option(OPT_VISION_BATCH) > 0) NB = std::max(1, std::min(option(OPT_VISION_BATCH), n_img));
     NB = (n_img + (n_img + NB - 1) / NB - 1) / ((n_img + NB - 1) / NB);
     EH(ensure_vision_buffers(m, image_meta, NB));
     const int ngroups = (n_img + NB - 1) / NB;
@@ -1124,7 +1162,7 @@ extern "C" int mllm_hip_model_time_kernel(mllm_hip_model *m, int which, int iter
     // fit the 256 MiB Infinity Cache): the time is that of a cold HBM stream, like inside the decode step.
     if (!m || !m->has_llm || iters <= 0) return MLLM_HIP_ERR_ARG;
     int nl = (int)m->layers.size();
-    if (const char *e = getenv("MLLM_HIP_TIME_LAYERS")) nl = std::max(1, std::min(nl, atoi(e)));   // fewer layers: an Infinity-Cache-warm stream
+    if (option(OPT_TIME_LAYERS) > 0) nl = std::max(1, std::min(nl, option(OPT_TIME_LAYERS)));   // fewer layers: an Infinity-Cache-warm stream
     auto launch = [&](int i) -> int {
         auto &L = m->layers[i % nl];
         if (which >= 10) return decode_kernel_launch(m->dctx, m->dlayers.data(), i % nl == 0 && which == 10 ? 1 % nl : i % nl, which - 10, m->st);

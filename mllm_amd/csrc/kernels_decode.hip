@@ -899,7 +899,7 @@ static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *
 #ifndef GUB_WPB
 #define GUB_WPB 7
 #endif
-    static const bool gub_off = getenv("MLLM_HIP_NO_GUB") != nullptr;      // bring-up switch: the 8-lanes-per-block kernel instead
+    const bool gub_off = option(OPT_NO_GUB) > 0;      // bring-up switch: the 8-lanes-per-block kernel instead
     if (MLLM_HIP_GUB && !gub_off && NS == 1 && 2 * GUB_PAIRS * (c.H >> 8) <= 64 && c.I % GUB_PAIRS == 0 && (c.H >> 8) <= GUB_WPB) {
         constexpr int BP = GUB_PAIRS, BW = GUB_WPB, BNV = 1;      // one quant block per wave in the prologue: K/256 <= waves
         const int bw = c.I / BP;
@@ -934,8 +934,8 @@ static int launch_proj(const uint8_t *W, const uint8_t *Wraw, const float *xin, 
 #define PJ_WPB1 8
 #endif
     // one lane per super-block: rows per workgroup chosen for one workgroup per CU (256) within the 512 lanes of a workgroup
-    static const bool pjb_off = getenv("MLLM_HIP_NO_PJB") != nullptr;
-    static const int pjb_min_ns = getenv("MLLM_HIP_PJB_MIN_NS") ? atoi(getenv("MLLM_HIP_PJB_MIN_NS")) : 3;   // short rows: the 8-lane kernel is faster
+    const bool pjb_off = option(OPT_NO_PJB) > 0;
+    const int pjb_min_ns = option(OPT_PJB_MIN_NS) >= 0 ? option(OPT_PJB_MIN_NS) : 3;   // short rows: the 8-lane kernel is faster
     {
         const int nb = K >> 8;
         const int rpw = std::max(1, std::min(512 / nb, (N + 255) / 256));
@@ -1003,8 +1003,8 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
         // bit 0: XCD placement of a K/V group's heads, bit 1: two-stage key fetch (both neutral in time at T = 290..430, profiles/r02_attn_experiments.md;
         // the second keeps the fetched bytes near the algorithmic ones at short contexts)
-        static const int flags = getenv("MLLM_HIP_ATTN_FLAGS") ? atoi(getenv("MLLM_HIP_ATTN_FLAGS")) : 3;
-        static const int ds_env = getenv("MLLM_HIP_ATTN_DS") ? atoi(getenv("MLLM_HIP_ATTN_DS")) : 0;     // workgroups per head (1, 2 or 4); 0 = default
+        const int flags = option(OPT_ATTN_FLAGS) >= 0 ? option(OPT_ATTN_FLAGS) : 3;
+        const int ds_env = option(OPT_ATTN_DS) > 0 ? option(OPT_ATTN_DS) : 0;     // workgroups per head (1, 2 or 4); 0 = default
         const int ds = ds_env == 1 || ds_env == 2 || ds_env == 4 ? ds_env : 2;
         const dim3 grid((flags & 1) ? dec_attn_grid(c.heads, c.kv_heads, ds) : c.heads * ds);
 #define DEC_ATTN_CASE(DD, DSV)                                                                                                                          \
@@ -1059,7 +1059,7 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
         hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, st, c.state, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos, c.D / 2, c.cache_limit);
         return MH_LAUNCH_OK("dec_advance");
     }
-    static const int head_wpc = getenv("MLLM_HIP_HEAD_WPC") ? std::max(1, atoi(getenv("MLLM_HIP_HEAD_WPC"))) : 8;   // waves per CU the row split aims at
+    const int head_wpc = option(OPT_HEAD_WPC) > 0 ? option(OPT_HEAD_WPC) : 8;   // waves per CU the row split aims at
     const int target_waves = 256 * head_wpc;
     int rpw = (c.vocab + target_waves - 1) / target_waves;
     rpw = ((rpw + 7) / 8) * 8;

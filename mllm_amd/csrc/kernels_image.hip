@@ -22,16 +22,19 @@ namespace {
 bool smart_resize_host(int height, int width, int factor, int min_pixels, int max_pixels, int *hb, int *wb) {
     if (height <= 0 || width <= 0 || factor <= 0) return false;
     if (std::max(height, width) / static_cast<float>(std::min(height, width)) > 200) return false;      // MAX_RATIO
+    const int64_t hw64 = (int64_t)height * width;
+    if (hw64 > 0x7fffffff) return false;      // the reference forms height * width in int (processing_qwen2_vl.hpp:97,101): beyond that it has no defined result
+    const int hw = (int)hw64;
     auto round_by_factor = [](int value, int f) { return ((value + f / 2) / f) * f; };
     auto floor_by_factor = [](float value, int f) { return static_cast<int>(std::floor(value / f)) * f; };
     auto ceil_by_factor = [](float value, int f) { return static_cast<int>(std::ceil(value / f)) * f; };
     int h_bar = std::max(factor, round_by_factor(height, factor)), w_bar = std::max(factor, round_by_factor(width, factor));
     if ((int64_t)h_bar * w_bar > max_pixels) {
-        const float beta = std::sqrt((height * width) / static_cast<float>(max_pixels));
+        const float beta = std::sqrt(hw / static_cast<float>(max_pixels));
         h_bar = floor_by_factor(height / beta, factor);
         w_bar = floor_by_factor(width / beta, factor);
     } else if ((int64_t)h_bar * w_bar < min_pixels) {
-        const float beta = std::sqrt(min_pixels / static_cast<float>(height * width));
+        const float beta = std::sqrt(min_pixels / static_cast<float>(hw));
         h_bar = ceil_by_factor(height * beta, factor);
         w_bar = ceil_by_factor(width * beta, factor);
     }
@@ -159,24 +162,32 @@ extern "C" int mllm_hip_qwen2vl_preprocess(const uint8_t *rgb_host, int height, 
     float *d_tmp = (float *)(ws + b_rgb);
     int *d_n0w = (int *)(ws + b_rgb + b_tmp), *d_ntw = d_n0w + Wo, *d_n0h = d_ntw + Wo, *d_nth = d_n0h + Ho;
     float *d_cw = (float *)(d_nth + Ho), *d_ch = d_cw + cw.size();
-    MH_CHECK(hipMemcpyAsync(d_rgb, rgb_host, (size_t)height * width * 3, hipMemcpyHostToDevice, st));
-    MH_CHECK(hipMemcpyAsync(d_n0w, n0w.data(), (size_t)Wo * 4, hipMemcpyHostToDevice, st));
-    MH_CHECK(hipMemcpyAsync(d_ntw, ntw.data(), (size_t)Wo * 4, hipMemcpyHostToDevice, st));
-    MH_CHECK(hipMemcpyAsync(d_n0h, n0h.data(), (size_t)Ho * 4, hipMemcpyHostToDevice, st));
-    MH_CHECK(hipMemcpyAsync(d_nth, nth.data(), (size_t)Ho * 4, hipMemcpyHostToDevice, st));
-    MH_CHECK(hipMemcpyAsync(d_cw, cw.data(), cw.size() * 4, hipMemcpyHostToDevice, st));
-    MH_CHECK(hipMemcpyAsync(d_ch, ch.data(), ch.size() * 4, hipMemcpyHostToDevice, st));
-    MH_CHECK(hipStreamSynchronize(st));      // the host tables go out of scope (pageable memory: the copies above are staged, the sync makes that explicit)
+    // from here on every exit returns the scratch block: errors are collected, not returned on the spot
+    int rc = MLLM_HIP_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) { set_error(what, e, __FILE__, __LINE__); rc = MLLM_HIP_ERR_HIP; }
+    };
+    step(hipMemcpyAsync(d_rgb, rgb_host, (size_t)height * width * 3, hipMemcpyHostToDevice, st), "hipMemcpyAsync(rgb)");
+    step(hipMemcpyAsync(d_n0w, n0w.data(), (size_t)Wo * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync(n0w)");
+    step(hipMemcpyAsync(d_ntw, ntw.data(), (size_t)Wo * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync(ntw)");
+    step(hipMemcpyAsync(d_n0h, n0h.data(), (size_t)Ho * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync(n0h)");
+    step(hipMemcpyAsync(d_nth, nth.data(), (size_t)Ho * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync(nth)");
+    step(hipMemcpyAsync(d_cw, cw.data(), cw.size() * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync(cw)");
+    step(hipMemcpyAsync(d_ch, ch.data(), ch.size() * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync(ch)");
+    step(hipStreamSynchronize(st), "hipStreamSynchronize");      // the host tables go out of scope (pageable memory: the copies above are staged, the sync makes that explicit)
     const int64_t n1 = (int64_t)height * Wo * 3, n2 = (int64_t)Ho * Wo * 3;
-    hipLaunchKernelGGL(img_resize_h_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, d_rgb, d_n0w, d_ntw, d_cw, tw, d_tmp, height, width, Wo);
-    int rc = MH_LAUNCH_OK("img_resize_h");
+    if (!rc) {
+        hipLaunchKernelGGL(img_resize_h_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, d_rgb, d_n0w, d_ntw, d_cw, tw, d_tmp, height, width, Wo);
+        rc = MH_LAUNCH_OK("img_resize_h");
+    }
     if (!rc) {
         // mean_ / std_ of Qwen2VLImageProcessor (processing_qwen2_vl.hpp:70-71)
         hipLaunchKernelGGL(img_resize_v_patch_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, d_tmp, d_n0h, d_nth, d_ch, th, patches_dev, Ho, Wo, 0.48145466f, 0.4578275f,
                            0.40821073f, 0.26862954f, 0.26130258f, 0.27577711f, patch, merge, tps);
         rc = MH_LAUNCH_OK("img_resize_v_patch");
     }
-    MH_CHECK(hipFreeAsync(ws, st));
+    step(hipFreeAsync(ws, st), "hipFreeAsync");
+    if (rc) return rc;
     grid_thw[0] = 1; grid_thw[1] = Ho / patch; grid_thw[2] = Wo / patch;
     return rc;
 }

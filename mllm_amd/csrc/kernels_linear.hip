@@ -736,7 +736,7 @@ static int launch_gemm_packed(const void *Wpacked, const float *bias, const void
     const int64_t ntiles = (int64_t)((N + 63) / 64) * ((M + 31) / 32);
     if (ntiles > 0x7fffffff) return MLLM_HIP_ERR_SHAPE;
     // the operand that all eight XCD L2s re-read should be the smaller one: activations cost 2.16 B per element (fp16 fragments), weights 0.72 B
-    static const int order_env = getenv("MLLM_HIP_GEMM_ORDER") ? atoi(getenv("MLLM_HIP_GEMM_ORDER")) : -1;      // 0 / 1 force n- / m-fastest (measurement)
+    const int order_env = option(OPT_GEMM_ORDER);      // 0 / 1 force n- / m-fastest (measurement)
     const int m_fastest = order_env >= 0 ? order_env : (q4kp_bytes(M, K) > q4kw_bytes(N, K) ? 1 : 0);
     hipLaunchKernelGGL(gemm_q4k_kernel, dim3((unsigned)ntiles), dim3(256), GQ_LDS, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16,
                        ldy, residual, M, N, nb, m_fastest);
@@ -747,6 +747,7 @@ extern "C" int mllm_hip_linear_q4kp_packed(const void *Wpacked, const float *bia
                                            const float *residual, int M, int N, int K, void *stream) {
     if (K % 256 != 0 || K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
     if (y_dtype != MLLM_HIP_F32 && y_dtype != MLLM_HIP_F16) return MLLM_HIP_ERR_DTYPE;
+    if (residual && y_dtype != MLLM_HIP_F32) return MLLM_HIP_ERR_DTYPE;      // the residual is an fp32 [M][N] buffer with y's pitch: it exists for fp32 outputs only
     if (M <= 0) return MLLM_HIP_OK;
     if (!Wpacked || !xpack) return MLLM_HIP_ERR_ARG;
     return launch_gemm_packed(Wpacked, bias, xpack, y, y_dtype, ldy, residual, M, N, K, as_stream(stream));
@@ -756,6 +757,7 @@ extern "C" int mllm_hip_linear_q4kp_q8k(const void *Wpacked, const float *bias, 
                                         void *y, int y_dtype, int64_t ldy, const float *residual, int M, int N, int K, void *stream) {
     if (K % 256 != 0 || K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
     if (y_dtype != MLLM_HIP_F32 && y_dtype != MLLM_HIP_F16) return MLLM_HIP_ERR_DTYPE;
+    if (residual && y_dtype != MLLM_HIP_F32) return MLLM_HIP_ERR_DTYPE;      // the residual is an fp32 [M][N] buffer with y's pitch: it exists for fp32 outputs only
     if (M <= 0) return MLLM_HIP_OK;
     if (!Wpacked || !xpack) return MLLM_HIP_ERR_ARG;
     const int nb = K / 256;
@@ -771,6 +773,7 @@ extern "C" int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const i
                                        int y_dtype, int64_t ldy, const float *residual, int M, int N, int K, void *stream) {
     if (K % 256 != 0 || K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
     if (y_dtype != MLLM_HIP_F32 && y_dtype != MLLM_HIP_F16) return MLLM_HIP_ERR_DTYPE;
+    if (residual && y_dtype != MLLM_HIP_F32) return MLLM_HIP_ERR_DTYPE;      // the residual is an fp32 [M][N] buffer with y's pitch: it exists for fp32 outputs only
     if (M <= 0) return MLLM_HIP_OK;
     const int y_f16 = y_dtype == MLLM_HIP_F16;
     hipStream_t st = as_stream(stream);
@@ -788,11 +791,17 @@ extern "C" int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const i
     // weights resident pre-pack once with mllm_hip_q4k_prepack and call mllm_hip_linear_q4kp_q8k)
     void *wp = nullptr, *xp = nullptr;
     MH_CHECK(hipMallocAsync(&wp, q4kw_bytes(N, K), st));
-    MH_CHECK(hipMallocAsync(&xp, q4kp_bytes(M, K), st));
-    int rc = mllm_hip_q4k_prepack(W, N, K, wp, stream);
+    hipError_t e = hipMallocAsync(&xp, q4kp_bytes(M, K), st);
+    int rc = MLLM_HIP_OK;
+    if (e != hipSuccess) { set_error("hipMallocAsync(xpack)", e, __FILE__, __LINE__); rc = MLLM_HIP_ERR_HIP; }
+    if (!rc) rc = mllm_hip_q4k_prepack(W, N, K, wp, stream);
     if (!rc) rc = mllm_hip_linear_q4kp_q8k(wp, bias, xqs, xd, xbsums, xp, y, y_dtype, ldy, residual, M, N, K, stream);
-    MH_CHECK(hipFreeAsync(wp, st));
-    MH_CHECK(hipFreeAsync(xp, st));
+    // both blocks are returned on every path (a failing free is reported only when nothing failed before it)
+    for (void *p : {wp, xp}) {
+        if (!p) continue;
+        e = hipFreeAsync(p, st);
+        if (e != hipSuccess && !rc) { set_error("hipFreeAsync", e, __FILE__, __LINE__); rc = MLLM_HIP_ERR_HIP; }
+    }
     return rc;
 }
 

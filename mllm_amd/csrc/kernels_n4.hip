@@ -72,23 +72,27 @@ __global__ __launch_bounds__(256) void bincount_kernel(const float *__restrict__
 }
 
 // out[r] = src[idx[r]]; with skip_negative (the Fuyu gather: out is the word-embedding buffer itself) rows whose index is negative are left alone
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t lds, const float *__restrict__ idx, float *__restrict__ out, int64_t ldo, int D,
-                                                          int skip_negative) {
+// (an index outside [0, n_src_rows) is never dereferenced: negative ones are the Fuyu form's "keep", anything else leaves the row untouched)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t lds, int n_src_rows, const float *__restrict__ idx, float *__restrict__ out, int64_t ldo,
+                                                          int D, int skip_negative) {
     const int r = blockIdx.x;
     const int i = (int)idx[r];
-    if (i < 0 && skip_negative) return;
+    if (i < 0 || i >= n_src_rows) return;
+    (void)skip_negative;
     const float *s = src + (int64_t)i * lds;
     float *o = out + (int64_t)r * ldo;
     for (int d = threadIdx.x; d < D; d += 256) o[d] = s[d];
 }
 
 // dst[idx[r]] += src[r] for r = 0 .. R-1 IN THAT ORDER: a thread owns a column and walks the rows, so a repeated destination accumulates exactly as the reference's loop does
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float *__restrict__ dst, int64_t ldd, const float *__restrict__ src, int64_t lds,
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float *__restrict__ dst, int64_t ldd, int n_dst_rows, const float *__restrict__ src, int64_t lds,
                                                                const float *__restrict__ idx, int R, int D) {
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= D) return;
     for (int r = 0; r < R; ++r) {
-        float *p = dst + (int64_t)(int)idx[r] * ldd + d;
+        const int i = (int)idx[r];
+        if (i < 0 || i >= n_dst_rows) continue;      // out of range: skipped, never dereferenced
+        float *p = dst + (int64_t)i * ldd + d;
         *p = *p + src[(int64_t)r * lds + d];
     }
 }
@@ -117,18 +121,18 @@ extern "C" int mllm_hip_bincount(const float *ids, int n, float *counts, int nbi
     hipLaunchKernelGGL(bincount_kernel, dim3(1), dim3(256), (size_t)nbins * sizeof(int), as_stream(stream), ids, n, counts, nbins);
     return MH_LAUNCH_OK("bincount");
 }
-extern "C" int mllm_hip_gather_rows(const float *src, int64_t lds, const float *idx, float *out, int64_t ldo, int R, int D, int skip_negative, void *stream) {
-    if (R < 0 || D <= 0) return MLLM_HIP_ERR_SHAPE;
+extern "C" int mllm_hip_gather_rows(const float *src, int64_t lds, int n_src_rows, const float *idx, float *out, int64_t ldo, int R, int D, int skip_negative, void *stream) {
+    if (R < 0 || D <= 0 || n_src_rows < 0) return MLLM_HIP_ERR_SHAPE;
     if (R == 0) return MLLM_HIP_OK;
     if (!src || !idx || !out) return MLLM_HIP_ERR_ARG;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(R), dim3(256), 0, as_stream(stream), src, lds, idx, out, ldo, D, skip_negative);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(R), dim3(256), 0, as_stream(stream), src, lds, n_src_rows, idx, out, ldo, D, skip_negative);
     return MH_LAUNCH_OK("gather_rows");
 }
-extern "C" int mllm_hip_scatter_add_rows(float *dst, int64_t ldd, const float *src, int64_t lds, const float *idx, int R, int D, void *stream) {
-    if (R < 0 || D <= 0) return MLLM_HIP_ERR_SHAPE;
+extern "C" int mllm_hip_scatter_add_rows(float *dst, int64_t ldd, int n_dst_rows, const float *src, int64_t lds, const float *idx, int R, int D, void *stream) {
+    if (R < 0 || D <= 0 || n_dst_rows < 0) return MLLM_HIP_ERR_SHAPE;
     if (R == 0) return MLLM_HIP_OK;
     if (!dst || !src || !idx) return MLLM_HIP_ERR_ARG;
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((D + 255) / 256), dim3(256), 0, as_stream(stream), dst, ldd, src, lds, idx, R, D);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((D + 255) / 256), dim3(256), 0, as_stream(stream), dst, ldd, n_dst_rows, src, lds, idx, R, D);
     return MH_LAUNCH_OK("scatter_add_rows");
 }
 extern "C" int mllm_hip_rope_table_ntk(float theta, int dim, int n_pos, int original_max_pos, const float *long_factor, const float *short_factor, float *sin_host,

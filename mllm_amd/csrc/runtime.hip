@@ -21,9 +21,26 @@ int check_launch(const char *what, const char *file, int line) {
     }
     return MLLM_HIP_OK;
 }
+static int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+static const char *const g_option_names[OPT_COUNT] = {"vision_batch", "time_layers", "no_gub", "no_pjb", "pjb_min_ns", "attn_flags", "attn_ds", "head_wpc", "gemm_order"};
+int option(Option o) { return g_options[o]; }
 }  // namespace mllm_hip
 
 using namespace mllm_hip;
+
+extern "C" int mllm_hip_set_option(const char *name, int value) {
+    if (!name) return MLLM_HIP_ERR_ARG;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcmp(name, g_option_names[i]) == 0) { g_options[i] = value; return MLLM_HIP_OK; }
+    snprintf(g_err, sizeof(g_err), "mllm_hip_set_option: unknown option '%s'", name);
+    return MLLM_HIP_ERR_ARG;
+}
+extern "C" int mllm_hip_get_option(const char *name, int *value) {
+    if (!name || !value) return MLLM_HIP_ERR_ARG;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcmp(name, g_option_names[i]) == 0) { *value = g_options[i]; return MLLM_HIP_OK; }
+    return MLLM_HIP_ERR_ARG;
+}
 
 extern "C" const char *mllm_hip_last_error(void) { return g_err; }
 

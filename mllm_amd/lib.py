@@ -96,6 +96,17 @@ def i64(v):
 
 
 # ---- host-side helpers (no GPU needed) --------------------------------------------------------------------------------
+def set_option(name: str, value: int) -> None:
+    """mllm_hip_set_option: measurement / bring-up switches of the launch paths (-1 = unset); they live in the library, not in the environment."""
+    check(load().mllm_hip_set_option(name.encode(), int(value)), "set_option")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(load().mllm_hip_get_option(name.encode(), C.byref(v)), "get_option")
+    return v.value
+
+
 def build_act_luts():
     g = np.empty(65536, dtype=np.uint16)
     q = np.empty(65536, dtype=np.uint16)
@@ -217,6 +228,11 @@ class Model:
         tot, h2d, tail, nb = C.c_float(), C.c_float(), C.c_float(), C.c_int64()
         check(load().mllm_hip_model_load_stats(self._h, C.byref(tot), C.byref(nb), C.byref(h2d), C.byref(tail)), "load_stats")
         return {"total_ms": tot.value, "file_bytes": nb.value, "h2d_ms": h2d.value, "repack_tail_ms": tail.value}
+
+    def memory_stats(self):
+        res, rel = C.c_int64(), C.c_int64()
+        check(load().mllm_hip_model_memory_stats(self._h, C.byref(res), C.byref(rel)), "memory_stats")
+        return {"resident_bytes": res.value, "released_bytes": rel.value}
 
     def prefill(self, ids, image=None, image_meta=None, want_logits=True, visual_dev=None, n_visual_rows=0):
         ids = np.ascontiguousarray(ids, dtype=np.int32)

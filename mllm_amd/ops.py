@@ -348,20 +348,20 @@ def bincount(ids, nbins):
 def gather_rows(src, idx):
     src, idx = _dev(src, torch.float32), _dev(idx, torch.float32)
     D = src.shape[-1]
-    out = torch.empty((idx.numel(), D), dtype=torch.float32, device="cuda")
-    check(L.load().mllm_hip_gather_rows(vp(src), i64(D), vp(idx), vp(out), i64(D), C.c_int(idx.numel()), C.c_int(D), C.c_int(0), _stream()), "gather_rows")
+    out = torch.zeros((idx.numel(), D), dtype=torch.float32, device="cuda")      # rows whose index is out of range stay zero
+    check(L.load().mllm_hip_gather_rows(vp(src), i64(D), C.c_int(src.reshape(-1, D).shape[0]), vp(idx), vp(out), i64(D), C.c_int(idx.numel()), C.c_int(D), C.c_int(0), _stream()), "gather_rows")
     return out
 
 
 def fuyu_gather(word, patches, idx):
     word, patches, idx = _dev(word, torch.float32).clone(), _dev(patches, torch.float32), _dev(idx, torch.float32)
     D = word.shape[-1]
-    check(L.load().mllm_hip_gather_rows(vp(patches), i64(D), vp(idx), vp(word), i64(D), C.c_int(idx.numel()), C.c_int(D), C.c_int(1), _stream()), "fuyu_gather")
+    check(L.load().mllm_hip_gather_rows(vp(patches), i64(D), C.c_int(patches.reshape(-1, D).shape[0]), vp(idx), vp(word), i64(D), C.c_int(idx.numel()), C.c_int(D), C.c_int(1), _stream()), "fuyu_gather")
     return word
 
 
 def scatter_add_rows(dst, src, idx):
     dst, src, idx = _dev(dst, torch.float32).clone(), _dev(src, torch.float32), _dev(idx, torch.float32)
     D = dst.shape[-1]
-    check(L.load().mllm_hip_scatter_add_rows(vp(dst), i64(D), vp(src), i64(D), vp(idx), C.c_int(idx.numel()), C.c_int(D), _stream()), "scatter_add_rows")
+    check(L.load().mllm_hip_scatter_add_rows(vp(dst), i64(D), C.c_int(dst.reshape(-1, D).shape[0]), vp(src), i64(D), vp(idx), C.c_int(idx.numel()), C.c_int(D), _stream()), "scatter_add_rows")
     return dst

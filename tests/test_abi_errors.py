@@ -150,3 +150,30 @@ def test_fa2_batch_validates_before_any_launch(L):
     assert call(bk=4100) == ERR_SHAPE
     assert call(q=NULL) == ERR_ARG
     assert call(D=48) == ERR_SHAPE               # head sizes 16, 64, 80, 128
+
+
+def test_options_live_in_the_library_not_in_the_environment(L, monkeypatch):
+    """mllm_hip_set_option: the measurement / bring-up switches of the launch paths are a table in the library; setting the old environment names changes nothing,
+    unknown names are refused, -1 means unset."""
+    from mllm_amd import lib
+    monkeypatch.setenv("MLLM_HIP_VISION_BATCH", "3")
+    assert lib.get_option("vision_batch") == -1
+    lib.set_option("vision_batch", 2)
+    assert lib.get_option("vision_batch") == 2
+    lib.set_option("vision_batch", -1)
+    assert L.mllm_hip_set_option(b"no_such_switch", C.c_int(1)) == ERR_ARG
+    assert L.mllm_hip_set_option(NULL, C.c_int(1)) == ERR_ARG
+    v = C.c_int(7)
+    assert L.mllm_hip_get_option(b"attn_ds", C.byref(v)) == OK and v.value == -1
+    # the one environment variable the library still reads (profiling scripts: replay the decode step as plain launches)
+    import os
+    import re
+    src = "".join(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mllm_amd", "csrc", f)).read()
+                  for f in os.listdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mllm_amd", "csrc")) if f.endswith((".hip", ".h")))
+    assert set(re.findall(r'getenv\("([A-Z_]+)"\)', src)) == {"MLLM_HIP_NO_GRAPH"}
+
+
+def test_linear_refuses_a_residual_with_an_fp16_output(L):
+    for fn, args in ((L.mllm_hip_linear_q4kp_packed, (P, NULL, P, P, C.c_int(1), C.c_int64(64), P, C.c_int(16), C.c_int(64), C.c_int(256), NULL)),
+                     (L.mllm_hip_linear_q4k_q8k, (P, NULL, P, P, P, P, C.c_int(1), C.c_int64(64), P, C.c_int(1), C.c_int(64), C.c_int(256), NULL))):
+        assert fn(*args) == ERR_DTYPE

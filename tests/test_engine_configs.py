@@ -200,8 +200,7 @@ def test_vision_batches_give_the_single_image_rows(monkeypatch):
     rows, cols = m.vision_shape()
     imgs = r.standard_normal((5, cfg.img, 3, cfg.img)).astype(np.float32)
     def run(n_batch):
-        if n_batch is None: monkeypatch.delenv("MLLM_HIP_VISION_BATCH", raising=False)
-        else: monkeypatch.setenv("MLLM_HIP_VISION_BATCH", str(n_batch))
+        lib.set_option("vision_batch", -1 if n_batch is None else n_batch)
         out = torch.empty((5 * rows, cols), dtype=torch.float32, device="cuda")
         m.vision(imgs, None, out.data_ptr(), 5)
         return out.cpu().numpy()
@@ -213,14 +212,14 @@ def test_vision_batches_give_the_single_image_rows(monkeypatch):
     grid = np.array([1, 8, 8], dtype=np.int32)
     pix = r.standard_normal((3, 64, cfg.patch_elems)).astype(np.float32)
     outs = []
-    for nb in ("1", "3", "2"):
-        monkeypatch.setenv("MLLM_HIP_VISION_BATCH", nb)
+    for nb in (1, 3, 2):
+        lib.set_option("vision_batch", nb)
         out = torch.empty((3 * 16, cfg.hidden), dtype=torch.float32, device="cuda")
         m.vision(pix, grid, out.data_ptr(), 3)
         outs.append(out.cpu().numpy())
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     # image sizes and batch sizes that grow and shrink between calls (the buffers are re-sized for the largest of each seen so far)
-    monkeypatch.delenv("MLLM_HIP_VISION_BATCH", raising=False)
+    lib.set_option("vision_batch", -1)
     for (gh, gw, n) in ((8, 8, 3), (16, 8, 2), (8, 8, 5), (16, 16, 1), (8, 16, 4)):
         grid = np.array([1, gh, gw], dtype=np.int32)
         pix = r.standard_normal((n, gh * gw, cfg.patch_elems)).astype(np.float32)

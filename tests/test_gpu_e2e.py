@@ -156,24 +156,17 @@ def test_mid_shape_engine_matches_oracle_composition(tmp_path):
 
 def test_lane_per_superblock_projection_on_short_rows(tmp_path):
     """dec_proj_blk serves rows of >= 17 super-blocks by default (the 2B model's down projection); forced onto the toy model's o / down
-    projections (MLLM_HIP_PJB_MIN_NS=1, read once per process -> a child process) it must reproduce the golden run as well."""
-    import subprocess
-    import sys
-    code = (
-        "import os, sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from mllm_amd import lib, synth\nfrom tests.fixtures import weights\n"
-        "g = np.load(%r)\n"
-        "cfg = synth.qwen2vl_tiny()\n"
-        "m = lib.Qwen2VL(cfg, weights.qwen2vl_file(cfg, cache_dir=%r))\n"
-        "tok, logits, _ = m.prefill(g['ids_text'])\n"
-        "ok = np.array_equal(logits, g['logits_text'][0])\n"
-        "for s in range(1, len(g['tokens_text'])):\n"
-        "    tok, logits, _ = m.decode(tok)\n"
-        "    ok = ok and np.array_equal(logits, g['logits_text'][s])\n"
-        "m.close()\n"
-        "sys.exit(0 if ok else 3)\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qwen2vl_tiny.npz"), str(tmp_path))
-    env = dict(os.environ, MLLM_HIP_PJB_MIN_NS="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
+    projections (mllm_hip_set_option("pjb_min_ns", 1)) it must reproduce the golden run as well."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qwen2vl_tiny.npz"))
+    cfg = synth.qwen2vl_tiny()
+    lib.set_option("pjb_min_ns", 1)      # before the model captures its decode graph
+    try:
+        m = lib.Qwen2VL(cfg, weights.qwen2vl_file(cfg, cache_dir=str(tmp_path)))
+        tok, logits, _ = m.prefill(g["ids_text"])
+        assert np.array_equal(logits, g["logits_text"][0])
+        for s in range(1, len(g["tokens_text"])):
+            tok, logits, _ = m.decode(tok)
+            assert np.array_equal(logits, g["logits_text"][s]), s
+        m.close()
+    finally:
+        lib.set_option("pjb_min_ns", -1)

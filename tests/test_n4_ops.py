@@ -79,8 +79,9 @@ def test_n4_entry_points_validate_before_any_launch():
     assert L.mllm_hip_topk_rows(None, C.c_int64(8), None, None, C.c_int(2), C.c_int(8), C.c_int(9), None) == lib.ERR_SHAPE           # k > n
     assert L.mllm_hip_topk_rows(None, C.c_int64(8), None, None, C.c_int(2), C.c_int(8), C.c_int(2), None) == lib.ERR_ARG
     assert L.mllm_hip_bincount(None, C.c_int(0), None, C.c_int(4), None) == lib.ERR_ARG
-    assert L.mllm_hip_gather_rows(None, C.c_int64(8), None, None, C.c_int64(8), C.c_int(0), C.c_int(8), C.c_int(0), None) == lib.OK
-    assert L.mllm_hip_scatter_add_rows(None, C.c_int64(8), None, C.c_int64(8), None, C.c_int(3), C.c_int(8), None) == lib.ERR_ARG
+    assert L.mllm_hip_gather_rows(None, C.c_int64(8), C.c_int(4), None, None, C.c_int64(8), C.c_int(0), C.c_int(8), C.c_int(0), None) == lib.OK
+    assert L.mllm_hip_scatter_add_rows(None, C.c_int64(8), C.c_int(4), None, C.c_int64(8), None, C.c_int(3), C.c_int(8), None) == lib.ERR_ARG
+    assert L.mllm_hip_scatter_add_rows(None, C.c_int64(8), C.c_int(-1), None, C.c_int64(8), None, C.c_int(3), C.c_int(8), None) == lib.ERR_SHAPE
 
 
 # ---- GPU: the kernels against the reference's outputs and, at larger sizes, against the restatement ---------------------------------------------------------
@@ -129,3 +130,10 @@ def test_hip_n4_ops_at_model_sizes_match_the_restatement():
     assert eq(ops.gather_rows(src, idx[:77]), orc.gather_rows(src, idx[:77]))
     fi = np.where(r.random(128) < 0.4, r.integers(0, 500, size=128), -1).astype(np.float32)
     assert eq(ops.fuyu_gather(dst, src, fi), orc.fuyu_gather(dst, src, fi))
+    # indices outside the table are never dereferenced: a bad destination row is skipped, a bad source row leaves its output row as it was (zeros here)
+    bad = idx.copy(); bad[[3, 77, 400]] = [-1.0, 128.0, 1e9]
+    keep = np.ones(500, dtype=bool); keep[[3, 77, 400]] = False
+    assert eq(ops.scatter_add_rows(dst, src, bad), orc.scatter_add_rows(dst, src[keep], bad[keep]))
+    gi = np.array([5, 499, 500, -3, 0], dtype=np.float32)
+    want = np.zeros((5, 2048), dtype=np.float32); want[[0, 1, 4]] = src[[5, 499, 0]]
+    assert eq(ops.gather_rows(src, gi), want)

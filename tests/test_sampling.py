@@ -128,4 +128,13 @@ def test_generate_sampled_on_the_engine():
     m.prefill(ids, pix, grid)
     cut, _ = m.generate_sampled(tok, steps, 0, np.zeros(steps, dtype=np.float32), eos=int(greedy[3]))
     assert cut.tolist() == greedy[:list(greedy).index(greedy[3]) + 1].tolist()
+    # a nucleus mass that keeps no candidate (p <= 0, NaN) is refused before anything runs, and the cache is where it was
+    for bad in (0.0, -0.5, float("nan")):
+        with pytest.raises(lib.MllmHipError):
+            m.generate_sampled(tok, 2, 2, np.zeros(2, dtype=np.float32), top_p=bad)
+    again, _ = m.generate_sampled(int(cut[-1]), 3, 0, np.zeros(3, dtype=np.float32))
+    assert again.size == 3
+    # the tower blocks' on-disk rows were released once packed (a tower pass never has fewer than 16 rows); the towers still give the reference's rows (test_gpu_e2e)
+    st = m.memory_stats()
+    assert st["released_bytes"] > 0 and st["resident_bytes"] > st["released_bytes"], st
     m.close()
