@@ -11,6 +11,9 @@
 #ifndef STAMPV
 #define STAMPV(i, v)
 #endif
+#ifndef STAMPB
+#define STAMPB(i)
+#endif
 
 namespace mllm_hip {
 
@@ -511,6 +514,411 @@ __device__ __forceinline__ void fa2_decode_head(const DecodeLds &L, DecodePrefet
     }
     __syncthreads();
     if (walker) L.ob[tid] = o * (1.0f / L.wred[NT / 64]);
+    __syncthreads();
+}
+// ==================================================================================================================
+// The same decode step with its two halves overlapped (round 3).  fa2_decode_head above runs A (scores of all keys) -> B (prefix maximum, p, c) ->
+// park V -> C (the sequential walk): the walk, bound by one wave's dependent fma chain, starts when the last score is done.  Here a workgroup is a small
+// pipeline over BLOCKS of FP_B = 32 keys:
+//   producer waves (all but the walkers and the logsum wave)   block b of wave w = b mod NP: the block's key rows and its V^T slice are requested from memory
+//       (coalesced 16-byte pieces, both speculatively at kernel entry for the first round), the key rows staged in the wave's own LDS region, two lanes per key
+//       compute the score (the chains and the pair adds of phase A), the wave scans its block maximum and publishes it; once every earlier block has published,
+//       the carry is their maximum and p_j / c_j / the moved-bits follow exactly as in phase B; the V^T slice is parked over the (now dead) key rows of the
+//       region and the block is flagged READY.
+//   walker wave(s)    lane d walks o[d] = fma(p_j, v_j[d], o[d] * c_j) over the keys in order, block after block as they become READY (three-stage register ring of
+//       16-key steps as above); after a block it publishes `walked`, which lets the producer of block b + NP reuse the region.
+//   logsum lane        the same walk over p / c only.
+// Nothing in the arithmetic changes -- every score, every maximum, every expf argument and the order of the dependent fma chain are those of fa2_decode_head -- so
+// the results are bit-identical; what changes is that the walk of key 0 starts as soon as block 0 is through, while the other blocks' scores are still being computed.
+// Hand-offs are words in LDS written after `s_waitcnt lgkmcnt(0)` (LDS is one memory per CU: no cache to invalidate); the only workgroup barriers are the one behind
+// the rotary prologue and the one in front of the final normalisation.
+// ==================================================================================================================
+constexpr int FP_B = 32;
+template <int D, int DV>
+struct PipeGeom {
+    static constexpr int KPITCH = D * 2 + 16;            // bytes per staged key row: conflict-free 8-byte reads by (key, half) lanes
+    static constexpr int VPITCH = FP_B * 2 + 16;         // bytes per V^T row of a block (32 keys fp16 + pad): conflict-free 16-byte reads by lane = dim
+    static constexpr int KBYTES = FP_B * KPITCH, VBYTES = DV * VPITCH;
+    static constexpr int REGION = ((KBYTES > VBYTES ? KBYTES : VBYTES) + 15) & ~15;
+    static constexpr int ROWK = D * 2 / 16;              // 16-byte pieces per key row
+    static constexpr int NKV = FP_B * ROWK / 64;         // key pieces per lane per block
+    static constexpr int ROWV = FP_B * 2 / 16;           // 16-byte pieces per V^T row of a block (4)
+    static constexpr int NVV = (DV * ROWV + 63) / 64;    // V pieces per lane per block
+};
+// hand-off words live in LDS and are read / written with explicit ds_ instructions (a volatile access through the generic pointer is lowered to flat_load ... sc0 sc1)
+__device__ __forceinline__ uint32_t lds_ld_u32(const uint32_t *p) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+    return v;
+}
+// every LDS store this wave issued before is complete (and visible to the other waves of the CU) before the word is written
+__device__ __forceinline__ void lds_publish_u32(uint32_t *p, uint32_t v) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint64_t lds_ld_u64(const uint32_t *p) {
+    uint64_t v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+    return v;
+}
+// one more block READY: bit `bit` of the 64-bit word at p (two dwords), set after every LDS store this wave issued before has completed
+__device__ __forceinline__ void lds_publish_bit(uint32_t *p, int bit) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_or_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)(p + (bit >> 5))), "v"(1u << (bit & 31)) : "memory");
+}
+// a progress word nobody has to order anything behind (the reads it vouches for have already returned into registers)
+__device__ __forceinline__ void lds_st_u32(uint32_t *p, uint32_t v) {
+    asm volatile("ds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+}
+struct PipeLds {
+    float *p, *c, *tot, *qs, *ob, *lsum;
+    uint32_t *flagT, *walked;
+    uint2 *rm;      // per block {READY word, moved-bits of its 32 keys}: one 8-byte read gives a consumer both, the READY word first in program order of its stage
+    uint64_t *etab;
+    char *regions;
+};
+__host__ __device__ static inline int pipe_nblk(int cap) { return (cap + FP_B - 1) / FP_B + 1; }
+__host__ __device__ static inline size_t pipe_lds_fixed(int cap, int D, int DV) {
+    const size_t capr = (size_t)((cap + 63) & ~63), nb = (size_t)((pipe_nblk(cap) + 3) & ~3);
+    return capr * 8 + nb * 16 + 16 + (size_t)(D + DV) * 4 + 16 + 256 + 64;      // p c | tot flagT rm(2) | walked | qs ob | lsum | etab | slack
+}
+template <int D, int DV>
+__host__ __device__ static inline size_t pipe_lds_bytes(int cap, int np) { return ((pipe_lds_fixed(cap, D, DV) + 15) & ~(size_t)15) + (size_t)np * PipeGeom<D, DV>::REGION; }
+__device__ __forceinline__ PipeLds carve_pipe(char *smem, int cap, int D, int DV) {
+    const size_t capr = (size_t)((cap + 63) & ~63), nb = (size_t)((pipe_nblk(cap) + 3) & ~3);
+    PipeLds L;
+    L.p = reinterpret_cast<float *>(smem);
+    L.c = L.p + capr;
+    L.tot = reinterpret_cast<float *>(L.c + capr);
+    L.flagT = reinterpret_cast<uint32_t *>(L.tot + nb);
+    L.rm = reinterpret_cast<uint2 *>(L.flagT + nb);
+    L.walked = reinterpret_cast<uint32_t *>(L.rm + nb);
+    L.qs = reinterpret_cast<float *>(L.walked + 4);
+    L.ob = L.qs + D;
+    L.lsum = L.ob + DV;
+    L.etab = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(L.lsum + 4) + 15) & ~(uintptr_t)15);
+    L.regions = smem + ((pipe_lds_fixed(cap, D, DV) + 15) & ~(size_t)15);
+    return L;
+}
+// what a producer lane holds of one block between the request and the LDS stores
+typedef unsigned int pipe_u32x4 __attribute__((ext_vector_type(4)));      // a native vector: assignments stay loads / stores of <4 x i32> (HIP's uint4 struct copies as memcpy,
+                                                                          // which kept the loop-carried block registers in scratch memory)
+template <int D, int DV>
+struct PipeRegs {
+    pipe_u32x4 k[PipeGeom<D, DV>::NKV];
+    pipe_u32x4 v[PipeGeom<D, DV>::NVV];
+};
+template <int D, int DV>
+__device__ __forceinline__ void pipe_fetch_k(PipeRegs<D, DV> &R, const uint16_t *K, int64_t ldk, int kvoff, int b, int cap, int lane) {
+    using G = PipeGeom<D, DV>;
+#pragma unroll
+    for (int i = 0; i < G::NKV; ++i) {
+        const int vi = lane + 64 * i, key = min(b * FP_B + vi / G::ROWK, cap - 1), part = vi % G::ROWK;
+        R.k[i] = *reinterpret_cast<const pipe_u32x4 *>(K + (int64_t)key * ldk + kvoff + part * 8);
+    }
+}
+template <int D, int DV>
+__device__ __forceinline__ void pipe_fetch_v(PipeRegs<D, DV> &R, const uint16_t *V, int64_t ldv, int voff, int b, int lane) {
+    using G = PipeGeom<D, DV>;
+#pragma unroll
+    for (int i = 0; i < G::NVV; ++i) {
+        const int vi = lane + 64 * i, row = vi / G::ROWV, part = vi % G::ROWV;
+        if (vi < DV * G::ROWV) R.v[i] = *reinterpret_cast<const pipe_u32x4 *>(V + (int64_t)(voff + row) * ldv + b * FP_B + part * 8);      // rows are padded by >= 128 keys
+    }
+}
+
+// NT threads: waves [0, NWK) walk the DV value dims, wave NWK holds the logsum lane, the rest produce.  `R` holds the first-round block of a producer wave, requested
+// by the caller before its prologue (fa2_pipe_prefetch); `first_block` is that block's index (< 0: none).
+template <int D, int DV, int NT>
+__device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<D, DV> &R, const uint16_t *K, int64_t ldk, const uint16_t *V, int64_t ldv, int kvoff,
+                                                     int voff, int Sk, int cap, const uint16_t *knew, const uint16_t *vnew, int tnew) {
+    using G = PipeGeom<D, DV>;
+    constexpr int NWK = (DV + 63) / 64, NP = NT / 64 - NWK - 1;
+    static_assert(NP >= 2, "the pipeline needs at least two producer waves");
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float scale = 1.0f / sqrtf((float)D);
+    const int nkv = Sk - 1;                                  // keys whose value comes from the slab; the appended token (key Sk - 1) is walked from vnew
+    const int nblkS = (Sk + FP_B - 1) / FP_B;                // blocks with scores
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // READY words (L.rm[b].x, one per block).  A consumer keeps `known`, the count of leading blocks it has seen READY, and goes back to LDS only when it needs a block
+    // beyond that: one wave-wide read of the next 64 words, whose leading ones extend `known`.  With the producers ahead that is a handful of polls per launch, so
+    // the read that drains the wave's LDS queue is off the per-block path, and no inline-asm LDS access sits on it either (the compiler's lgkmcnt bookkeeping stays
+    // exact, which is what keeps the read-ahead ahead).
+    int known = 0;
+    auto ensure = [&](int b) {
+        while (b >= known) {
+            asm volatile("" ::: "memory");
+            const int idx = known + lane;
+            const uint32_t f = idx < nblkS ? L.rm[idx].x : 0u;
+            const unsigned long long ball = __ballot(f != 0);
+            const int cnt = ball == ~0ull ? 64 : __builtin_ctzll(~ball);
+            if (cnt == 0) __builtin_amdgcn_s_sleep(1);
+            else known += cnt;
+        }
+        asm volatile("" ::: "memory");
+    };
+    if (wid > NWK) {
+        // ---------------------------------------------------------------- producers ----------------------------------------------------------------
+        const int pw = wid - NWK - 1;
+        char *region = L.regions + (size_t)pw * G::REGION;
+        const int key = lane >> 1, hf = lane & 1;
+        for (int b = pw; b < nblkS; b += NP) {
+            if (b != pw) {      // later rounds: request the block now (the first round's was requested at kernel entry), then wait for the walker to leave the region
+                pipe_fetch_k<D, DV>(R, K, ldk, kvoff, b, cap, lane);
+                pipe_fetch_v<D, DV>(R, V, ldv, voff, b, lane);
+                while (true) {      // every walker wave has left block b - NP
+                    bool free = true;
+#pragma unroll
+                    for (int w = 0; w < NWK; ++w) free = free && (int)lds_ld_u32(L.walked + w) >= b - NP + 1;
+                    if (free) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            // key rows -> the region (pitch KPITCH), then each (key, half) lane reads its 8-byte pieces back
+#pragma unroll
+            for (int i = 0; i < G::NKV; ++i) {
+                const int vi = lane + 64 * i;
+                *reinterpret_cast<pipe_u32x4 *>(region + (size_t)(vi / G::ROWK) * G::KPITCH + (vi % G::ROWK) * 16) = R.k[i];
+            }
+            const int j = b * FP_B + key;
+            float s = FA_NEG;
+            {
+                float l[4] = {0, 0, 0, 0};
+                const float *q = L.qs + 4 * hf;
+                uint2 kw[D / 8];
+                if (knew && j == tnew) {
+#pragma unroll
+                    for (int i = 0; i < D / 8; ++i) kw[i] = *reinterpret_cast<const uint2 *>(knew + 8 * i + 4 * hf);
+                } else {
+                    const char *kr = region + (size_t)key * G::KPITCH + 8 * hf;
+#pragma unroll
+                    for (int i = 0; i < D / 8; ++i) kw[i] = *reinterpret_cast<const uint2 *>(kr + 16 * i);
+                }
+#pragma unroll
+                for (int i = 0; i < D / 8; ++i) {
+                    const float4 a = *reinterpret_cast<const float4 *>(q + 8 * i);
+                    l[0] = __fmaf_rn(a.x, h2f((uint16_t)(kw[i].x & 0xffff)), l[0]); l[1] = __fmaf_rn(a.y, h2f((uint16_t)(kw[i].x >> 16)), l[1]);
+                    l[2] = __fmaf_rn(a.z, h2f((uint16_t)(kw[i].y & 0xffff)), l[2]); l[3] = __fmaf_rn(a.w, h2f((uint16_t)(kw[i].y >> 16)), l[3]);
+                }
+                // _mm256_hadd_ps: ((l0+l4)+(l1+l5)) + ((l2+l6)+(l3+l7)); the partner lane holds the other half of the chains
+                const float r0 = l[0] + MH_DPPF(0.0f, l[0], DPP_QUAD_X1, 0xF), r1 = l[1] + MH_DPPF(0.0f, l[1], DPP_QUAD_X1, 0xF);
+                const float r2 = l[2] + MH_DPPF(0.0f, l[2], DPP_QUAD_X1, 0xF), r3 = l[3] + MH_DPPF(0.0f, l[3], DPP_QUAD_X1, 0xF);
+                if (j < Sk) s = (r0 + r1) + (r2 + r3);
+            }
+            if (b == pw) STAMPT(8, (NWK + 1) * 64);
+            // the block's running maximum; its total goes out first, so that later blocks can take their carry while this one still computes its expf
+            const float wincl = wave_scan_max(s);
+            if (lane == 63) { L.tot[b] = wincl; lds_publish_u32(L.flagT + b, 1u); }
+            float before = FA_NEG;
+            if (b > 0) {
+                const bool mine = lane < b;      // b <= 64: cap <= 2048 keys (the launcher keeps longer caches on fa2_decode_head)
+                while (true) {
+                    const uint32_t f = lds_ld_u32(L.flagT + (mine ? lane : 0));
+                    if (__ballot(f != 0 || !mine) == ~0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const float t = mine ? L.tot[lane] : FA_NEG;
+                before = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan_max(t)), 63));
+            }
+            if (b == pw) { STAMPT(9, (NWK + 1) * 64); STAMPT(12, (NWK + 5) * 64); }
+            const float incl = fmaxf(wincl, before);
+            const float up1 = wave_shift_up(incl, before);
+            const float up2 = wave_shift_up(up1, before);
+            const float excl = hf ? up2 : up1;
+            const bool moved = j < Sk && excl != incl;
+            if (j < Sk) {
+                const float e = glibc_expf(((hf ? excl : s) - incl) * scale, L.etab);
+                (hf ? L.c : L.p)[j] = e;
+            }
+            unsigned long long mv = __ballot(moved && hf == 0);
+            mv = (mv | (mv >> 1)) & 0x3333333333333333ull; mv = (mv | (mv >> 2)) & 0x0f0f0f0f0f0f0f0full; mv = (mv | (mv >> 4)) & 0x00ff00ff00ff00ffull;
+            mv = (mv | (mv >> 8)) & 0x0000ffff0000ffffull; mv = (mv | (mv >> 16)) & 0x00000000ffffffffull;
+            if (lane == 0) L.rm[b].y = (uint32_t)mv;
+            // the V^T slice over the dead key rows (every lane's key reads above have returned: their values were consumed by the score)
+#pragma unroll
+            for (int i = 0; i < G::NVV; ++i) {
+                const int vi = lane + 64 * i;
+                if (vi < DV * G::ROWV) *reinterpret_cast<pipe_u32x4 *>(region + (size_t)(vi / G::ROWV) * G::VPITCH + (vi % G::ROWV) * 16) = R.v[i];
+            }
+            // (s_waitcnt lgkmcnt(0) covers the whole wave's stores: the wave executes it as one instruction)
+            if (lane == 0) lds_publish_u32(&L.rm[b].x, 1u);
+            if (b == pw) { STAMPT(10, (NWK + 1) * 64); STAMPT(13, (NWK + 5) * 64); }
+        }
+    } else if (wid < NWK) {
+        // ---------------------------------------------------------------- walkers ------------------------------------------------------------------
+        // One block (32 keys) per stage, the next block's LDS reads issued before this block's 32-long fma chain (two register stages): a lone wave issues about one
+        // instruction per six cycles whatever its kind, so the walk is priced by instructions per key -- per block: 32 fma, 13 LDS reads, one READY / moved-bits
+        // check and the loop, instead of that per 16 keys.
+        float o = 0.0f;
+        const int nblkV = (nkv + FP_B - 1) / FP_B;
+        struct Stage { u32x4 v[4]; f32x4 p[8]; uint32_t m; };
+        Stage SA, SB;
+        const bool active = tid < DV;
+        const char *row0 = L.regions + (size_t)(active ? tid : 0) * G::VPITCH;
+        auto rd = [&](int b, Stage &S) {
+            const char *row = row0 + (size_t)(b % NP) * G::REGION;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S.v[i] = *reinterpret_cast<const u32x4 *>(row + 16 * i);
+#pragma unroll
+            for (int q4 = 0; q4 < 8; ++q4) S.p[q4] = *reinterpret_cast<const f32x4 *>(L.p + FP_B * b + 4 * q4);
+            S.m = L.rm[b].y;
+        };
+        auto proc = [&](int b, const Stage &S) {
+            const uint32_t m32 = (uint32_t)__builtin_amdgcn_readfirstlane(S.m);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k0 = FP_B * b + 16 * h;
+                if (k0 >= nkv) break;
+                const unsigned w[8] = {S.v[2 * h][0], S.v[2 * h][1], S.v[2 * h][2], S.v[2 * h][3], S.v[2 * h + 1][0], S.v[2 * h + 1][1], S.v[2 * h + 1][2], S.v[2 * h + 1][3]};
+                const int m16 = (int)((m32 >> (16 * h)) & 0xffff);
+                if (m16 == 0 && k0 + 16 <= nkv) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) o = __fmaf_rn(S.p[4 * h + (k >> 2)][k & 3], h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff))), o);
+                } else if (k0 + 16 <= nkv) {
+                    // some maximum moved inside these 16 keys: c is exactly 1.0f wherever it did not, so the rescale needs no select
+                    f32x4 cq[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + k0 + 4 * q4);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        o = o * cq[k >> 2][k & 3];
+                        o = __fmaf_rn(S.p[4 * h + (k >> 2)][k & 3], h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff))), o);
+                    }
+                } else {
+                    f32x4 cq[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + k0 + 4 * q4);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const bool in = k0 + k < nkv;            // keys past the end: c = 1, p = 0, v = 0
+                        const float vk = h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff)));
+                        o = o * (in ? cq[k >> 2][k & 3] : 1.0f);
+                        o = __fmaf_rn(in ? S.p[4 * h + (k >> 2)][k & 3] : 0.0f, in ? vk : 0.0f, o);
+                    }
+                }
+            }
+            STAMPB(b);
+            if (nblkS > NP) {      // this wave has left the block: its region may be overwritten (only a cache of more than NP blocks reuses regions)
+                if (lane == 0) L.walked[wid] = (uint32_t)(b + 1);
+                asm volatile("" ::: "memory");
+            }
+        };
+        // Order inside an iteration: (1) this block's stage is waited for -- `landed` names its last-requested registers, and LDS returns a wave's reads in order --,
+        // (2) the next block's reads are issued, (3) the 32-long chain runs on registers that need no further wait.  In the common case (no maximum moved inside the
+        // block, the block is full) (2) and (3) share one basic block and the 13 reads are interleaved with the dependent fmas (sched_group_barrier): a lone wave
+        // issues in order, so an independent instruction placed between two dependent fmas issues in the shadow of the first one's latency; placed in front of the
+        // chain it costs its own issue slots.  The chain's 6.6 cycles per key is then what a block costs.
+        auto landed = [&](const Stage &S) { asm volatile("" : : "v"(S.p[7]), "v"(S.m) : "memory"); };
+        auto chain32 = [&](const Stage &S) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const unsigned wk = S.v[k >> 3][(k >> 1) & 3];
+                o = __fmaf_rn(S.p[k >> 2][k & 3], h2f((uint16_t)((k & 1) ? (wk >> 16) : (wk & 0xffff))), o);
+            }
+        };
+        auto turn = [&](int b, const Stage &Scur, Stage &Snext) {      // block b is in Scur; block b + 1 exists and goes to Snext
+            landed(Scur);
+            ensure(b + 1);
+            const uint32_t m32 = (uint32_t)__builtin_amdgcn_readfirstlane(Scur.m);
+            if (m32 == 0 && FP_B * (b + 1) <= nkv) {
+                rd(b + 1, Snext);
+                chain32(Scur);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two of the chain's fmas ...
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ... then one of the next block's LDS reads
+                }
+                STAMPB(b);
+                L.walked[wid] = (uint32_t)(b + 1);      // every lane stores the same word: neither a uniform branch nor an EXEC write (both are scheduling boundaries
+                                                        // and would cut the block the interleave lives in)
+            } else {
+                asm volatile("" ::: "memory");      // keeps the two arms from sharing a prefix: the common arm's reads must stay inside its block to be interleaved
+                rd(b + 1, Snext);
+                proc(b, Scur);
+            }
+        };
+        if (nblkV > 0) { ensure(0); rd(0, SA); }
+        STAMP(2);
+        int b = 0;
+        for (; b + 2 < nblkV; b += 2) {
+            turn(b, SA, SB);
+            turn(b + 1, SB, SA);
+        }
+        if (b + 1 < nblkV) { turn(b, SA, SB); landed(SB); proc(b + 1, SB); }
+        else if (b < nblkV) { landed(SA); proc(b, SA); }
+        STAMP(3);
+        if (vnew) {   // the appended token: rescale (always a multiply in the reference), then its value row
+            ensure(nblkS - 1);
+            if (active) {
+                o = o * L.c[Sk - 1];
+                o = __fmaf_rn(L.p[Sk - 1], h2f(vnew[tid]), o);
+            }
+        }
+        if (active) L.ob[tid] = o;
+    } else if (lane == 0) {
+        // ---------------------------------------------------------------- logsum lane --------------------------------------------------------------
+        float lsum = 0.0f;
+        // the same shape as the walk: a block per stage, the next block's 9 reads interleaved with this block's 32 dependent adds
+        struct SStage { f32x4 p[8]; uint32_t m; };
+        SStage A, B;
+        auto rd = [&](int b, SStage &S) {
+#pragma unroll
+            for (int q4 = 0; q4 < 8; ++q4) S.p[q4] = *reinterpret_cast<const f32x4 *>(L.p + FP_B * b + 4 * q4);
+            S.m = L.rm[b].y;
+        };
+        auto landed = [&](const SStage &S) { asm volatile("" : : "v"(S.p[7]), "v"(S.m) : "memory"); };
+        auto general = [&](int b, const SStage &S) {
+            const int j0 = FP_B * b, ns = min(FP_B, Sk - j0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (16 * h >= ns) break;
+                if (((S.m >> (16 * h)) & 0xffff) == 0 && 16 * h + 16 <= ns) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) lsum = lsum + S.p[4 * h + (k >> 2)][k & 3];
+                } else {
+                    f32x4 cq[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + j0 + 16 * h + 4 * q4);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const bool in = 16 * h + k < ns;
+                        lsum = __fmaf_rn(lsum, in ? cq[k >> 2][k & 3] : 1.0f, in ? S.p[4 * h + (k >> 2)][k & 3] : 0.0f);
+                    }
+                }
+            }
+        };
+        auto turn = [&](int b, const SStage &Scur, SStage &Snext) {      // block b is in Scur; block b + 1 exists and goes to Snext
+            landed(Scur);
+            ensure(b + 1);
+            if (Scur.m == 0 && FP_B * (b + 1) <= Sk) {
+                rd(b + 1, Snext);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) lsum = lsum + Scur.p[k >> 2][k & 3];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            } else {
+                asm volatile("" ::: "memory");
+                rd(b + 1, Snext);
+                general(b, Scur);
+            }
+        };
+        ensure(0);
+        rd(0, A);
+        int b = 0;
+        for (; b + 2 < nblkS; b += 2) {
+            turn(b, A, B);
+            turn(b + 1, B, A);
+        }
+        if (b + 1 < nblkS) { turn(b, A, B); landed(B); general(b + 1, B); }
+        else { landed(A); general(b, A); }
+        *L.lsum = lsum;
+        STAMPT(7, NWK * 64);
+    }
+    STAMP(4);
+    __syncthreads();
+    if (tid < DV) L.ob[tid] = L.ob[tid] * (1.0f / *L.lsum);
     __syncthreads();
 }
 }  // namespace mllm_hip

@@ -62,6 +62,14 @@ __device__ unsigned long long g_stamps[8192 * 16];
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
+#define STAMPB(i)                                                                                        \
+    do {                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && (i) < 16) {                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            g_stamps[(4096 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();               \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+        }                                                                                                \
+    } while (0)
 #define STAMPV(i, v) do { if (threadIdx.x == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) g_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = (v); } while (0)
 #define STAMPT(i, t)                                                                                     \
     do {                                                                                                 \
@@ -73,6 +81,9 @@ __device__ unsigned long long g_stamps[8192 * 16];
     } while (0)
 #else
 #define STAMP(i)
+#define STAMPV(i, v)
+#define STAMPT(i, t)
+#define STAMPB(i)
 #endif
 }  // namespace mllm_hip
 #include "q4k_dot.h"
@@ -262,6 +273,13 @@ static inline size_t fused_lds_bytes(int K, bool with_xf, int wpb) {
     return ((act_lds_bytes(K, with_xf) + 15) & ~(size_t)15) + (size_t)wpb * q4k_tab_bytes(NSTEPS, ROWS);
 }
 
+// what dec_qkv needs to touch the layer's cache rows ahead of the attention launch (kslab == nullptr: off)
+struct KvWarm {
+    static constexpr int PER_THREAD = 4;      // 16-byte requests per thread: 16 workgroups x 512 threads x 4 cover K and V of one head up to ~1000 keys
+    const uint16_t *kslab, *vslab;
+    uint32_t *sink;
+    int Hkv, D, ldk, vt_ld, cache_limit;
+};
 // ------------------------------------------------------------------------------------------------------------------------
 // dec_qkv: x (or the embedding row of state->token for layer 0) -> RMSNorm -> Q8_K -> Wqkv rows (+bias) -> qkv fp32
 // ------------------------------------------------------------------------------------------------------------------------
@@ -269,11 +287,12 @@ template <int NSTEPS, int ROWS, bool EMBED, int NV, int WPB>
 __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
                                                       const uint8_t *__restrict__ emb_qs, const uint16_t *__restrict__ emb_d, int vocab,
                                                       const float *__restrict__ norm_w, float eps, const uint8_t *__restrict__ W,
-                                                      const float *__restrict__ bias, float *__restrict__ y, int N, int K) {
+                                                      const float *__restrict__ bias, float *__restrict__ y, int N, int K, KvWarm kw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[WPB];
     const ActLds a = carve_act(smem, K);
     const int lane = threadIdx.x & 63, wave = blockIdx.x * WPB + (threadIdx.x >> 6), nb = K >> 8;
+    const int T_warm = kw.kslab ? state->T : 0;      // a scalar load (uniform address): in flight under the prologue, waited for on lgkmcnt only
     int rows[ROWS];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) rows[rr] = min(wave * ROWS + rr, N - 1);
@@ -314,6 +333,27 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
     wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
     if (!(MLLM_HIP_EARLY_ROWS && NSTEPS == 1)) issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);   // long rows after the prologue: see dec_gateup_kernel
     __builtin_amdgcn_sched_barrier(0);
+    STAMPV(15, (unsigned long long)(__builtin_amdgcn_s_getreg(0x1814) & 15));
+    // Warm THIS XCD's L2 with the cache rows the attention kernel -- the next launch -- reads through one CU per head: its workgroups for K/V head k carry
+    // blockIdx.x % 8 == k % 8 (dec_attn_grid), and so do the workgroups that touch head k's rows here; under the dispatcher's round-robin both land on one XCD.
+    // A speed matter only: nothing depends on where a workgroup runs.  The requests go out behind the weight rows and are consumed (xor) at the very end.
+    uint32_t warm = 0;
+    uint4 wq[KvWarm::PER_THREAD];
+    const int kvh_w = blockIdx.x & 7;
+    const bool warms = kw.kslab && kvh_w < kw.Hkv && T_warm > 0;
+    if (warms) {
+        const int rank = blockIdx.x >> 3, nrank = (gridDim.x - kvh_w + 7) >> 3, T = min(T_warm, kw.cache_limit - 1);
+        const int rowk = kw.D * 2 / 16, nk = T * rowk, rowv = (T + 7) >> 3, nv = kw.D * rowv;
+#pragma unroll
+        for (int i = 0; i < KvWarm::PER_THREAD; ++i) {
+            const int v = (rank + i * nrank) * (64 * WPB) + (int)threadIdx.x;
+            const uint16_t *src = kw.kslab;      // an address that always exists
+            if (v < nk) src = kw.kslab + (int64_t)(v / rowk) * kw.ldk + kvh_w * kw.D + (v % rowk) * 8;
+            else if (v - nk < nv) src = kw.vslab + (int64_t)(kvh_w * kw.D + (v - nk) / rowv) * kw.vt_ld + ((v - nk) % rowv) * 8;
+            wq[i] = *reinterpret_cast<const uint4 *>(src);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float out[ROWS];
     dot_rows<NSTEPS, ROWS>(L, a, nb, lane, wave_tab<NSTEPS, ROWS>(smem, K, false, threadIdx.x >> 6), out);
     if (lane == 63) {
@@ -322,6 +362,11 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
             const int rw = wave * ROWS + rr;
             if (rw < N) y[rw] = bias ? out[rr] + bias[rw] : out[rr];
         }
+    }
+    if (warms) {
+#pragma unroll
+        for (int i = 0; i < KvWarm::PER_THREAD; ++i) warm ^= wq[i].x ^ wq[i].y ^ wq[i].z ^ wq[i].w;
+        if (kw.sink) kw.sink[blockIdx.x * (64 * WPB) + threadIdx.x] = warm;      // never set: the loads need a consumer the compiler can see
     }
 }
 
@@ -681,6 +726,79 @@ __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState
     if (tid < DV) out[head * D + vdim0 + tid] = L.ob[tid];
 }
 
+// The same step on fa2_decode_head_pipe (kernels_attn_core.h): the scores / softmax statistics of later key blocks are computed while the walk over the first ones runs.
+// Same grid, same placement, same arithmetic (bit-identical results); dynamic LDS = pipe_lds_bytes<D, DV>(cache_limit, NP).
+// 12 waves: the walker's two register stages (a block each: 50 registers) need more than the 128 registers a 16-wave workgroup leaves a lane -- with 1024 threads the
+// allocator folded the two stages into one and the read-ahead was gone
+constexpr int DEC_PIPE_NT = 768;
+template <int D, int DS>
+__global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_pipe_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
+                                                                    const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
+                                                                    float *__restrict__ out, int Hq, int Hkv, int cache_limit, int vt_ld, int flags) {
+    constexpr int HALF = D / 2, DV = D / DS, NWK = (DV + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) uint16_t knew[D];
+    __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
+    const int gsize = Hq / Hkv, per_kv = gsize * DS;
+    int kvh, sub;
+    if (flags & 1) { const int col = blockIdx.x & 7, idx = blockIdx.x >> 3; kvh = (idx / per_kv) * 8 + col; sub = idx % per_kv; }
+    else { kvh = blockIdx.x / per_kv; sub = blockIdx.x % per_kv; }
+    if (kvh >= Hkv) return;
+    const int gh = sub / DS, vdim0 = (sub % DS) * DV;
+    const int head = kvh * gsize + gh;
+    const PipeLds L = carve_pipe(smem, cache_limit, D, DV);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int HD = Hq * D, KVD = Hkv * D;
+    STAMP(1);
+    STAMPV(14, (unsigned long long)(__builtin_amdgcn_s_getreg(0x1814) & 15));      // HW_REG_XCC_ID of this workgroup (diagnostic build only)
+    // the step's own small operands first (vmcnt retires in issue order), then -- speculatively, T only masks them afterwards -- the first-round block of every producer wave
+    const int T_raw = state->T;
+    float qa = 0.0f, qb = 0.0f, sn = 0.0f, cs = 0.0f;
+    if (tid < HALF) { const float *qp = qkv + head * D; qa = qp[tid]; qb = qp[tid + HALF]; sn = sin_t[tid]; cs = cos_t[tid]; }
+    else if (tid < D) { const float *kp = qkv + HD + kvh * D; qa = kp[tid - HALF]; qb = kp[tid]; sn = sin_t[tid - HALF]; cs = cos_t[tid - HALF]; }
+    else if (tid < 2 * D) qa = qkv[HD + KVD + kvh * D + (tid - D)];
+    const uint64_t etab_v = expf_tab_fetch();
+    __builtin_amdgcn_sched_barrier(0);
+    PipeRegs<D, DV> R;
+    const int pw = wid - NWK - 1;      // producer index (< 0: walker / logsum wave)
+    constexpr int NSPEC = 4;           // producers whose first block is requested before T is known (keys below 128 always exist in the slab; T only masks them)
+    if (pw >= 0 && pw < NSPEC) {
+        pipe_fetch_k<D, DV>(R, kslab, KVD, kvh * D, pw, cache_limit, lane);
+        pipe_fetch_v<D, DV>(R, vslab, vt_ld, kvh * D + vdim0, pw, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the walk is the critical path and the first blocks feed it first: static priorities (walkers > early producers > the rest)
+    if (pw < 0) __builtin_amdgcn_s_setprio(3);
+    else if (pw < NSPEC) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
+    for (int i = tid; i < 3 * ((pipe_nblk(cache_limit) + 3) & ~3) + 4; i += DEC_PIPE_NT) L.flagT[i] = 0u;      // flagT | rm (two words per block) | walked are contiguous
+    expf_tab_store(L.etab, etab_v);
+    const int T = min(T_raw, cache_limit - 1), Sk = T + 1;
+    if (pw >= NSPEC && pw * FP_B < Sk) {      // the later blocks of the first round, now that the key count is known
+        pipe_fetch_k<D, DV>(R, kslab, KVD, kvh * D, pw, cache_limit, lane);
+        pipe_fetch_v<D, DV>(R, vslab, vt_ld, kvh * D + vdim0, pw, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < HALF) {
+        L.qs[tid] = __fmaf_rn(qa, cs, -(qb * sn));
+        L.qs[tid + HALF] = __fmaf_rn(qa, sn, qb * cs);
+    } else if (tid < D) {
+        knew[tid - HALF] = f2h(__fmaf_rn(qa, cs, -(qb * sn)));
+        knew[tid] = f2h(__fmaf_rn(qa, sn, qb * cs));
+    } else if (tid < 2 * D) {
+        vnew[tid - D] = f2h(qa);
+    }
+    __syncthreads();
+    STAMP(0);
+    if (sub == 0 && tid < D) {
+        kslab[(int64_t)T * KVD + kvh * D + tid] = knew[tid];
+        vslab[(int64_t)(kvh * D + tid) * vt_ld + T] = vnew[tid];
+    }
+    fa2_decode_head_pipe<D, DV, DEC_PIPE_NT>(L, R, kslab, KVD, vslab, vt_ld, kvh * D, kvh * D + vdim0, Sk, cache_limit, knew, vnew + vdim0, T);
+    if (tid < DV) out[head * D + vdim0 + tid] = L.ob[tid];
+    STAMP(5);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // dec_head: x -> RMSNorm -> Q8_0 -> tied lm_head rows (Q4_0 planes) -> logits, plus this workgroup's (max, first index)
 // ------------------------------------------------------------------------------------------------------------------------
@@ -864,7 +982,7 @@ static int allow_lds(KernelT kern, size_t lds) {
 // RMSNorm(x) -> Q8_K -> W rows (+bias) -> y: the q|k|v projection of a layer, and the Linear lm_head of the models whose head is not tied
 template <int NS>
 static int launch_norm_gemv(const DecodeCtx &c, const float *norm_w, float eps, const uint8_t *W, const float *bias, int N, bool embed, const float *x,
-                            float *x_out, float *y, hipStream_t st) {
+                            float *x_out, float *y, hipStream_t st, const KvWarm &kw = KvWarm{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}) {
 #ifndef QKV_ROWS
 #define QKV_ROWS 2
 #endif
@@ -879,10 +997,10 @@ static int launch_norm_gemv(const DecodeCtx &c, const float *norm_w, float eps, 
     if (rc) return rc;
     if (embed)
         hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, true, NV, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, norm_w,
-                           eps, W, bias, y, N, c.H);
+                           eps, W, bias, y, N, c.H, kw);
     else
         hipLaunchKernelGGL((dec_qkv_kernel<NS, ROWS, false, NV, WPB>), dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, norm_w,
-                           eps, W, bias, y, N, c.H);
+                           eps, W, bias, y, N, c.H, kw);
     return MH_LAUNCH_OK("dec_qkv");
 }
 template <int NS>
@@ -995,18 +1113,45 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
     int rc = 0;
     switch (which) {
     case 0:
-        NS_DISPATCH(c.H, rc = launch_norm_gemv<NS>(c, L.in_norm, c.eps, L.Wqkv, L.bqkv, L.qkv_N, li == 0, x, x, c.qkv, st));
+    {
+        // bit 3 of the attention flags (set by default): dec_qkv warms the L2 with the layer's cache rows for the attention launch that follows
+        const int aflags = option(OPT_ATTN_FLAGS) >= 0 ? option(OPT_ATTN_FLAGS) : 11;
+        KvWarm kw{nullptr, nullptr, nullptr, c.kv_heads, c.D, c.kv_heads * c.D, c.vt_ld, c.cache_limit};
+        if ((aflags & 8) && (aflags & 1) && c.kv_heads <= 8) {
+            kw.kslab = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D;
+            kw.vslab = c.vslab + (size_t)li * c.kv_heads * c.D * c.vt_ld;
+        }
+        NS_DISPATCH(c.H, rc = launch_norm_gemv<NS>(c, L.in_norm, c.eps, L.Wqkv, L.bqkv, L.qkv_N, li == 0, x, x, c.qkv, st, kw));
         return rc;
+    }
     case 1: {
         uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.kv_heads * c.D * c.vt_ld;
         const int nslots = decode_lds_slots(c.cache_limit, c.D, DEC_ATTN_NT, 2, true);
         const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
         // bit 0: XCD placement of a K/V group's heads, bit 1: two-stage key fetch (both neutral in time at T = 290..430, profiles/r02_attn_experiments.md;
         // the second keeps the fetched bytes near the algorithmic ones at short contexts)
-        const int flags = option(OPT_ATTN_FLAGS) >= 0 ? option(OPT_ATTN_FLAGS) : 3;
+        const int flags = option(OPT_ATTN_FLAGS) >= 0 ? option(OPT_ATTN_FLAGS) : 11;
         const int ds_env = option(OPT_ATTN_DS) > 0 ? option(OPT_ATTN_DS) : 0;     // workgroups per head (1, 2 or 4); 0 = default
         const int ds = ds_env == 1 || ds_env == 2 || ds_env == 4 ? ds_env : 2;
         const dim3 grid((flags & 1) ? dec_attn_grid(c.heads, c.kv_heads, ds) : c.heads * ds);
+        // bit 2 of the flags (unset by default) keeps the un-pipelined kernel; caches beyond 2048 keys (more than 64 blocks: the carry is taken by one wave pass) stay on it too
+        if (!(flags & 4) && c.cache_limit <= 2048 && (c.D == 128 || c.D == 64)) {
+#define DEC_PIPE_CASE(DD, DSV)                                                                                                                            \
+    {                                                                                                                                                     \
+        constexpr int NP_ = DEC_PIPE_NT / 64 - ((DD / DSV + 63) / 64) - 1;                                                                                \
+        const size_t plds = pipe_lds_bytes<DD, DD / DSV>(c.cache_limit, NP_);                                                                             \
+        if (plds <= 160 * 1024 - 2 * DD * 2 - 64) {                                                                                                       \
+            rc = allow_lds(dec_attn_pipe_kernel<DD, DSV>, plds);                                                                                          \
+            if (rc) return rc;                                                                                                                            \
+            hipLaunchKernelGGL((dec_attn_pipe_kernel<DD, DSV>), grid, dim3(DEC_PIPE_NT), plds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, \
+                               c.heads, c.kv_heads, c.cache_limit, c.vt_ld, flags);                                                                       \
+            return MH_LAUNCH_OK("dec_attn_pipe");                                                                                                         \
+        }                                                                                                                                                 \
+    }
+            if (c.D == 128) { if (ds == 1) DEC_PIPE_CASE(128, 1) else if (ds == 2) DEC_PIPE_CASE(128, 2) else DEC_PIPE_CASE(128, 4) }
+            else { if (ds == 1) DEC_PIPE_CASE(64, 1) else if (ds == 2) DEC_PIPE_CASE(64, 2) else DEC_PIPE_CASE(64, 4) }
+#undef DEC_PIPE_CASE
+        }
 #define DEC_ATTN_CASE(DD, DSV)                                                                                                                          \
     {                                                                                                                                                   \
         rc = allow_lds(dec_attn_kernel<DD, DSV>, lds);                                                                                                  \

@@ -73,3 +73,33 @@ def test_full_image_prompt_bit_exact(full_model):
     tok, _, _ = m.prefill(ids, pix, grid)
     gen, _ = m.generate(tok, len(g["tokens"]) - 1)
     assert [tok] + gen.tolist() == g["tokens"].tolist()
+
+
+def test_pipelined_decode_attention_equals_the_unpipelined_kernel_over_a_long_context(tmp_path):
+    """dec_attn_pipe_kernel (scores of later key blocks computed while the walk over the first ones runs; kernels_attn_core.h: fa2_decode_head_pipe) against
+    dec_attn_kernel (attn_flags bit 2: phases A -> B -> C one after the other, the form pinned against the oracle to T = 1500 by test_fa2_on_the_engine_kv_layout):
+    the same greedy ids and bit-identical logits along a decode that takes the cache from 30 to 760 keys -- every block count from 1 to 24, blocks that wrap the
+    producers' LDS regions (more than 14 blocks), partial last blocks, the appended key alone in its block."""
+    from mllm_amd import lib, synth
+    from tests.fixtures import weights
+    cfg = synth.qwen2vl_tiny()
+    cfg.cache_limit = 800
+    path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
+    ids = np.random.default_rng(21).integers(0, 2000, size=30).astype(np.int32)
+    runs = {}
+    for flags in (7, 3):
+        lib.set_option("attn_flags", flags)
+        try:
+            m = lib.Qwen2VL(cfg, path)
+            tok, lg0, _ = m.prefill(ids)
+            toks, _ = m.generate(tok, 700)
+            nxt, lg1, _ = m.decode(int(toks[-1]))
+            steps = [m.decode(nxt)[1]]
+            for _ in range(27):
+                steps.append(m.decode(int(np.argmax(steps[-1])))[1])
+            runs[flags] = (toks.copy(), lg1.copy(), np.stack(steps))
+            m.close()
+        finally:
+            lib.set_option("attn_flags", -1)
+    assert runs[7][0].tolist() == runs[3][0].tolist()
+    assert np.array_equal(runs[7][1], runs[3][1]) and np.array_equal(runs[7][2], runs[3][2])
