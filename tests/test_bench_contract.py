@@ -64,3 +64,30 @@ def test_bench_fails_loudly_without_a_hip_device():
     assert p.returncode != 0
     assert "no HIP device" in (p.stderr + p.stdout)
     assert not any(l.startswith("{") for l in p.stdout.splitlines())      # and prints no measurement
+
+
+def test_bench_two_ranks_dry_run_under_torchrun(tmp_path):
+    """bench.py's N > 1 skeleton, launched the way the driver launches it (python -m torch.distributed.run, rendezvous on 127.0.0.1), on gloo with the stub engine of
+    --dry-run: rank 1 is 1.25x slower than rank 0 by construction, so the barriers + MAX over ranks must give value = world * K / (K * 1.25 ms) = 1600 tok/s (sleep
+    granularity allows a few per cent), one JSON line from rank 0 only, rccl_world = n_gpus = 2, the vision prefill sharded with one all-gather per tower pass."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "4", "--dry-run"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["dry_run"] is True and r["n_gpus"] == 2 and r["config"]["rccl_world"] == 2 and r["config"]["parallelism"] == "replicas" and r["scaling"] == "weak"
+    assert r["steps"] == 40 and r["warmup"] == 4 and r["roofline"] is None and r["cpu_baseline"] is None
+    assert 1250.0 <= r["value"] <= 1620.0, r["value"]                      # 2 * 40 / (40 * 1.25 ms), never the faster rank's 2000
+    assert abs(r["ms_per_step"] - 1000.0 * 2 / r["value"]) < 1e-3
+    assert r["vit_prefill"]["world"] == 2 and r["vit_prefill"]["images"] == 8 and r["vit_prefill"]["all_gathers"] == 4
+    # without --dry-run the same command refuses to run where there is no HIP device
+    if not __import__("torch").cuda.is_available():
+        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "0"], capture_output=True, text=True, timeout=300, cwd=root)
+        assert bad.returncode != 0 and "no HIP device" in (bad.stderr + bad.stdout)

@@ -27,12 +27,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_img, out_dir):
+def _worker(rank, world, port, n_img, out_dir, pass_images=0, injected=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
     batch = torch.randn(n_img, 16, 6)
-    full = parallel.sharded_vision(fake_vision, batch)
+    calls = []
+    collective = None
+    if injected:      # the shape of RowGather.collective(): `collective(full, local)` -- here gloo stands in for the C-ABI ncclAllGather, the index logic is the shared one
+        def collective(full, local):
+            calls.append(tuple(local.shape))
+            dist.all_gather_into_tensor(full, local)
+    full = parallel.sharded_vision(fake_vision, batch, pass_images=pass_images, collective=collective)
+    if injected:
+        assert len(calls) == (len(parallel.pass_groups(parallel.shard_range(n_img, rank, world)[2], pass_images)) if pass_images else 1)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), full.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -61,3 +69,23 @@ def test_shard_range_partition():
                 assert p == per and 0 <= v <= p
                 seen += list(range(s, s + v))
             assert seen == list(range(n))
+
+
+@pytest.mark.parametrize("world,n_img,pass_images,injected", [(2, 8, 2, False), (2, 7, 3, False), (3, 8, 1, False), (2, 8, 0, True), (2, 9, 2, True), (3, 5, 4, True)])
+def test_per_pass_all_gather_and_injected_collective(tmp_path, world, n_img, pass_images, injected):
+    """The all-gather issued per tower pass (async, overlapped with the next pass) reassembles the same `[B, tokens, hidden]` block as the single gather, for pass sizes
+    that do and do not divide the per-rank count, uneven batches included; and the `collective(full, local)` hook RowGather plugs the C-ABI ncclAllGather into goes
+    through the very same partition / padding / reassembly code (gloo stands in for RCCL, which needs GPUs)."""
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_img, str(tmp_path), pass_images, injected), nprocs=world, join=True)
+    torch.manual_seed(0)
+    want = fake_vision(torch.randn(n_img, 16, 6)).numpy()
+    for r in range(world):
+        got = np.load(tmp_path / f"r{r}.npy")
+        assert got.shape == want.shape and np.array_equal(got, want), f"rank {r}"
+
+
+def test_pass_groups():
+    assert parallel.pass_groups(7, 3) == [(0, 3), (3, 3), (6, 1)]
+    assert parallel.pass_groups(4, 0) == [(0, 1), (1, 1), (2, 1), (3, 1)]
+    assert parallel.pass_groups(4, 9) == [(0, 4)]
