@@ -377,6 +377,16 @@ int mllm_hip_gather_rows(const float *src, int64_t lds, int n_src_rows, const fl
  * destination row accumulates in that order.  `dst` has n_dst_rows rows; a source row whose index lies outside [0, n_dst_rows) is skipped. */
 int mllm_hip_scatter_add_rows(float *dst, int64_t ldd, int n_dst_rows, const float *src, int64_t lds, const float *idx, int R, int D, void *stream);
 
+/* F_TTMUL with a `[R,1,1,1]` right operand (CPUBinaryFunc.hpp; `expert_out * expert_weights_clip`, models/minicpm_moe/modeling_minicpm_moe.hpp:86): y[r][:] *= w[r] */
+int mllm_hip_scale_rows(float *y, int64_t ld, const float *w, int R, int D, void *stream);
+/* One sparse-MoE feed-forward block = MiniCPMMoE::Forward (models/minicpm_moe/modeling_minicpm_moe.hpp:52-105; models/ling, models/smallthinker route the same way), composed
+ * from the launchers above: router Linear (Q4_K rows `[n_experts][hidden]`) -> softmax -> top-k (per_tok) -> weights renormalised by their sequential sum -> per expert,
+ * ascending: gather its tokens, gate (w1) / up (w3) / down (w2) MLP on Q4_K rows `[inter][hidden]`, `[inter][hidden]`, `[hidden][inter]`, rows scaled by their routing
+ * weight, scatter-added into the zero-initialised `out [n_tok][hidden]`.  w1 / w3 / w2 are HOST arrays of n_experts device pointers.  The S * k routing pairs cross PCIe
+ * once (the reference reads `tokens_per_expert` on the host per expert, :76-78); the call synchronises `stream`.  Bit-identical to the reference's block. */
+int mllm_hip_moe_block(const float *x, float *out, int n_tok, int hidden, int inter, int n_experts, int per_tok, const void *router_q4k,
+                       const void *const *w1_q4k, const void *const *w3_q4k, const void *const *w2_q4k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 SO = os.path.join(HERE, "libmllm_hip.so")
-HIP_SOURCES = ["runtime.hip", "kernels_elem.hip", "kernels_linear.hip", "kernels_attn.hip", "kernels_decode.hip", "kernels_sample.hip", "kernels_image.hip", "kernels_n4.hip", "engine.hip"]
+HIP_SOURCES = ["runtime.hip", "kernels_elem.hip", "kernels_linear.hip", "kernels_attn.hip", "kernels_decode.hip", "kernels_sample.hip", "kernels_image.hip", "kernels_n4.hip", "moe.hip", "engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

@@ -368,8 +368,13 @@ __global__ __launch_bounds__(256) void binary_kernel(const float *__restrict__ a
     if (i < n) for (int64_t j = i; j < n && j < i + 4; ++j) y[j] = OP == 0 ? __fadd_rn(a[j], b[j]) : __fmul_rn(a[j], b[j]);
 }
 
-// CPUSoftMax (op/CPUSoftMax.cpp:28-65): one wave per row; exp through the same polynomial as the reference's vector path
+// CPUSoftMax (op/CPUSoftMax.cpp:28-65 -> mllm_vec_soft_max_f32, ActivationFunction.cpp:29-80), one wave per row, every bit the reference's:
+// the columns go through in chunks of 8 -- y = v_expf(x - max) per lane, the chunk's sum in the AVX2 hsum order ((v4+v0)+(v6+v2)) + ((v5+v1)+(v7+v3)) -- and the
+// chunk sums are added to the row sum one after the other; the < 8 trailing columns use libm's expf (glibc_expf) and join the sum one by one; y *= 1 / sum.
 __global__ __launch_bounds__(64) void softmax_kernel(const float *__restrict__ x, float *__restrict__ y, int n, const int *__restrict__ valid) {
+    __shared__ uint64_t tab[32];
+    expf_tab_store(tab, expf_tab_fetch());
+    __syncthreads();
     const int row = blockIdx.x, lane = threadIdx.x;
     const int v = valid ? valid[row] : n;
     const float *xr = x + (int64_t)row * n;
@@ -377,11 +382,28 @@ __global__ __launch_bounds__(64) void softmax_kernel(const float *__restrict__ x
     float mx = -INFINITY;
     for (int i = lane; i < v; i += 64) mx = fmaxf(mx, xr[i]);
     mx = wave_max(mx);
+    const int nfull = v & ~7;
     float sum = 0.0f;
-    for (int i = lane; i < v; i += 64) { const float e = v_expf(__fsub_rn(xr[i], mx)); yr[i] = e; sum += e; }
-    sum = wave_sum(sum);
+    for (int base = 0; base < nfull; base += 64) {      // eight chunks per pass, chunk g in lanes 8g .. 8g+7
+        const int i = base + lane;
+        float e = 0.0f;
+        if (i < nfull) { e = v_expf(__fsub_rn(xr[i], mx)); yr[i] = e; }
+        float t = __fadd_rn(e, __shfl_xor(e, 4));       // lanes 0..3 of the chunk: v[l+4] + v[l]
+        t = __fadd_rn(t, __shfl_xor(t, 2));             // lane 0: t0 + t2, lane 1: t1 + t3
+        t = __fadd_rn(t, __shfl_xor(t, 1));             // lane 0: (t0 + t2) + (t1 + t3)
+        const int chunks = min(8, (nfull - base) >> 3);
+        for (int g = 0; g < chunks; ++g) sum = __fadd_rn(sum, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), g * 8)));
+    }
+    const int ntail = v - nfull;
+    if (ntail > 0) {
+        float e = 0.0f;
+        if (lane < ntail) { e = glibc_expf(__fsub_rn(xr[nfull + lane], mx), tab); yr[nfull + lane] = e; }
+        for (int g = 0; g < ntail; ++g) sum = __fadd_rn(sum, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), g)));
+    }
     const float inv = __fdiv_rn(1.0f, sum);
-    for (int i = lane; i < v; i += 64) yr[i] = __fmul_rn(yr[i], inv);
+    // a lane rescales the columns it wrote itself (the same lane -> column map as above): no cross-lane visibility is needed
+    for (int i = lane; i < nfull; i += 64) yr[i] = __fmul_rn(yr[i], inv);
+    if (lane < ntail) yr[nfull + lane] = __fmul_rn(yr[nfull + lane], inv);
     for (int i = v + lane; i < n; i += 64) yr[i] = 0.0f;
 }
 

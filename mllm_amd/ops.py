@@ -365,3 +365,18 @@ def scatter_add_rows(dst, src, idx):
     D = dst.shape[-1]
     check(L.load().mllm_hip_scatter_add_rows(vp(dst), i64(D), C.c_int(dst.reshape(-1, D).shape[0]), vp(src), i64(D), vp(idx), C.c_int(idx.numel()), C.c_int(D), _stream()), "scatter_add_rows")
     return dst
+
+
+def moe_block(x, router_raw, w1_raw, w3_raw, w2_raw, inter, per_tok):
+    """MiniCPMMoE::Forward (models/minicpm_moe/modeling_minicpm_moe.hpp:52-105) on token rows x `[S][hidden]`: router / expert weights as the raw Q4_K bytes of the
+    .mllm (one array per expert)."""
+    x = _dev(x, torch.float32)
+    S, H = x.shape
+    E = len(w1_raw)
+    router = _dev(np.asarray(router_raw).view(np.uint8))
+    keep = [[_dev(np.asarray(w).view(np.uint8)) for w in ws] for ws in (w1_raw, w3_raw, w2_raw)]
+    arrs = [(C.c_void_p * E)(*[t.data_ptr() for t in ws]) for ws in keep]
+    out = torch.empty((S, H), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_moe_block(vp(x), vp(out), C.c_int(S), C.c_int(H), C.c_int(inter), C.c_int(E), C.c_int(per_tok), vp(router), arrs[0], arrs[1], arrs[2],
+                                      _stream()), "moe_block")
+    return out

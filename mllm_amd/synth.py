@@ -395,3 +395,32 @@ def llava_inputs(c: LLaVAConfig, n_text: int = 10):
     ids = np.concatenate([text[:3], [c.image_token_id], text[3:]]).astype(np.int32)
     img = np.random.default_rng(23).standard_normal((c.img, 3, c.img), dtype=np.float32)
     return ids, img
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a sparse-MoE feed-forward block (MiniCPM-MoE geometry; models/minicpm_moe/modeling_minicpm_moe.hpp:41-115, configuration_minicpm_moe.hpp:14-31)
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass
+class MoEConfig:
+    hidden: int = 256
+    inter: int = 512
+    experts: int = 4
+    per_tok: int = 2
+    base: str = "model.layers.0.mlp."
+
+
+def moe_tiny() -> MoEConfig:
+    return MoEConfig()
+
+
+def moe_tensors(c: MoEConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
+    yield c.base + "gate.weight", (c.experts, c.hidden), "w"
+    for e in range(c.experts):
+        p = f"{c.base}experts.{e}."
+        yield p + "w1.weight", (c.inter, c.hidden), "w"      # gate_proj
+        yield p + "w3.weight", (c.inter, c.hidden), "w"      # up_proj
+        yield p + "w2.weight", (c.hidden, c.inter), "w"      # down_proj
+
+
+def moe_input(c: MoEConfig, n_tok: int, seed: int = 17) -> np.ndarray:
+    return np.random.default_rng(seed).standard_normal((n_tok, c.hidden), dtype=np.float32)

@@ -489,7 +489,28 @@ def n4_golden():
         print(k, G[k].tolist() if G[k].size < 40 else G[k].shape)
 
 
+def moe_golden():
+    """the reference's own MiniCPMMoE block (ref_ops case moe) on reference-quantised synthetic weights: 4 experts, 2 per token, 37 tokens (every expert
+    receives tokens, some fewer than 16 rows, one more) and a single token (decode: two experts get one row, the others none)."""
+    c = synth.moe_tiny()
+    td, path = _ref_weights(synth.moe_tensors(c), mf.Q4_K)
+    G = {}
+    for tag, n in (("p", 37), ("d", 1)):
+        x = synth.moe_input(c, n, seed=17 + n)
+        (y,), _ = run_ops("moe", path, [[(x, (1, 1, n, c.hidden))]], p=(c.hidden, c.inter, c.experts, c.per_tok))
+        G["x_" + tag], G["y_" + tag] = x, y.reshape(n, c.hidden)
+    f = mf.MllmFile(path)
+    import hashlib
+    G["digest"] = np.frombuffer("".join(hashlib.sha256(f.raw(n).tobytes()).hexdigest()[:16] for n in sorted(f.names())).encode(), dtype=np.uint8)
+    f.close()
+    np.savez_compressed(os.path.join(GOLD, "moe.npz"), **G)
+    print("moe.npz", G["y_p"].shape, float(np.abs(G["y_p"]).max()))
+
+
 if __name__ == "__main__":
+    if "--moe" in sys.argv:
+        moe_golden()
+        sys.exit(0)
     if "--tinyllama-full" in sys.argv:
         tinyllama_full()
         sys.exit(0)

@@ -269,3 +269,34 @@ class LLaVA(CausalLM):
             at = int(np.nonzero(ids == c.image_token_id)[0][0])
             x = np.concatenate([x[:at], vis, x[at + 1:]])
         return self.body_forward(x)
+
+
+def moe_block(w: Weights, cfg, x):
+    """The reference's sparse-MoE feed-forward block, MiniCPMMoE::Forward (models/minicpm_moe/modeling_minicpm_moe.hpp:52-105), on token rows x [S, hidden]:
+    scores = softmax(gate(x)) (:58-59); top-k pairs per token in the function's pair order (:60, CPUTopkFunc.hpp:48-70); weights renormalised by their sequential sum
+    (:64, CPUSumFunc.hpp: `sum += x[d]` from 0, then CPUBinaryFunc's division); argsort of the flattened expert ids + bincount route the (token, slot) pairs to experts
+    (:67-69: std::sort on the id alone -- the order inside an expert's run is unspecified, and immaterial: a token meets an expert at most once, rows are independent);
+    per expert, ascending: gather its tokens (:83), gate / up / down MLP (:84), scale each row by its weight (:86), scatter_add into the zero-initialised output (:87)."""
+    S, H = x.shape
+    E, k, b = cfg.experts, cfg.per_tok, cfg.base
+    scores = orc.softmax(w.lin(x, b + "gate", E, bias=False))
+    tv, ti = orc.topk_rows(scores, k)
+    den = np.zeros(S, dtype=np.float32)
+    for d in range(k):
+        den = (den + tv[:, d]).astype(np.float32)
+    wn = (tv / den[:, None]).astype(np.float32)
+    flat_e = ti.reshape(-1).astype(np.int64)                  # pair j = token j // k, slot j % k
+    out = np.zeros((S, H), dtype=np.float32)
+    for e in range(E):
+        pairs = np.nonzero(flat_e == e)[0]
+        if pairs.size == 0:
+            continue
+        tok = pairs // k
+        p = f"{b}experts.{e}."
+        xe = x[tok]
+        g = orc.silu(w.lin(xe, p + "w1", cfg.inter, bias=False))
+        u = w.lin(xe, p + "w3", cfg.inter, bias=False)
+        y = w.lin((g * u).astype(np.float32), p + "w2", H, bias=False)
+        y = (y * wn.reshape(-1)[pairs][:, None]).astype(np.float32)
+        out = orc.scatter_add_rows(out, y, tok.astype(np.float32))
+    return out

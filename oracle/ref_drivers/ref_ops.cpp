@@ -17,6 +17,7 @@
 
 #include "models/qwen2_vl/configuration_qwen2_vl.hpp"
 #include "models/qwen2_vl/modeling_qwen2_vl.hpp"
+#include "models/minicpm_moe/modeling_minicpm_moe.hpp"
 #include "backends/cpu/CPUBackend.hpp"
 
 using namespace mllm;
@@ -272,6 +273,15 @@ int main(int argc, char **argv) {
         if (kind == "attn") model.reset(new QWen2Attention(cfg, cfg.names_config, base + cfg.names_config._attn_base_name));
         else if (kind == "mlp") model.reset(new QWen2MLP(cfg.hidden_size, cfg.intermediate_size, cfg.names_config, base + cfg.names_config._ffn_base_name));
         else model.reset(new QWen2Decoder(cfg, cfg.names_config, base));
+    } else if (kind == "moe") {
+        // the reference's own sparse-MoE block (models/minicpm_moe/modeling_minicpm_moe.hpp:41-115): router Linear -> softmax -> top-k -> renormalise -> argsort / bincount
+        // routing -> per expert gather, gate / up / down MLP, row scale, scatter_add.  p: hidden, inter, experts, experts per token
+        MiniCPMConfig cfg(64, "2B");
+        cfg.hidden_size = (int)p(0);
+        cfg.intermediate_size = (int)p(1);
+        cfg.num_experts = (int)p(2);
+        cfg.num_experts_per_tok = (int)p(3);
+        model.reset(new MiniCPMMoE(cfg, cfg.names_config, cfg.names_config.blk_name + "0." + cfg.names_config._ffn_base_name));
     } else {
         model.reset(new OpsModule(kind));
     }

@@ -84,6 +84,14 @@ def llava_file(cfg: synth.LLaVAConfig, cache_dir: str = "/tmp/mllm_amd_cache") -
     return path
 
 
+def moe_file(cfg: synth.MoEConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> str:
+    os.makedirs(cache_dir, exist_ok=True)
+    path = os.path.join(cache_dir, f"moe-h{cfg.hidden}-i{cfg.inter}-e{cfg.experts}-k{cfg.per_tok}-q4k.mllm")
+    if not os.path.exists(path):
+        build_q4k_file(path, synth.moe_tensors(cfg))
+    return path
+
+
 def write_fp32_mllm(path: str, specs) -> None:
     """The fp32 `.mllm` of the synthetic tensors -- the input of the reference's own `quantize` tool (oracle/make_golden.py)."""
     mf.write_mllm(path, ((n, mf.F32, synth.tensor_f32(n, s, k)) for n, s, k in specs))

@@ -137,3 +137,68 @@ def test_hip_n4_ops_at_model_sizes_match_the_restatement():
     gi = np.array([5, 499, 500, -3, 0], dtype=np.float32)
     want = np.zeros((5, 2048), dtype=np.float32); want[[0, 1, 4]] = src[[5, 499, 0]]
     assert eq(ops.gather_rows(src, gi), want)
+
+
+# ---- the whole sparse-MoE block: the reference's MiniCPMMoE module run by the reference (tests/golden/moe.npz) --------------------------------------
+def _moe_setup():
+    import hashlib
+
+    from mllm_amd import mllmfile as mf, synth
+    from oracle import models as om
+    from tests.fixtures import weights
+    cfg = synth.moe_tiny()
+    path = weights.moe_file(cfg)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "moe.npz"))
+    f = mf.MllmFile(path)
+    dig = "".join(hashlib.sha256(f.raw(n).tobytes()).hexdigest()[:16] for n in sorted(f.names()))
+    f.close()
+    assert dig.encode() == g["digest"].tobytes(), "the fixture quantiser's file differs from the one the reference's quantize wrote for the golden"
+    return cfg, path, g, om
+
+
+def test_moe_block_restatement_matches_the_reference_module():
+    """oracle.models.moe_block against the reference's own MiniCPMMoE::Forward (models/minicpm_moe/modeling_minicpm_moe.hpp:52-105), bit for bit: 37 tokens (prefill: every
+    expert has rows, fewer than 16 for some) and one token (decode: two experts with one row each)."""
+    cfg, path, g, om = _moe_setup()
+    w = om.Weights(path)
+    for tag in ("p", "d"):
+        y = om.moe_block(w, cfg, g["x_" + tag])
+        assert y.shape == g["y_" + tag].shape and np.array_equal(y, g["y_" + tag]), (tag, float(np.abs(y - g["y_" + tag]).max()))
+
+
+def test_moe_block_argument_checks():
+    from mllm_amd import lib
+    L = lib.load()
+    P = C.c_void_p(0x1000)
+    arr = (C.c_void_p * 2)(0x1000, 0x1000)
+    assert L.mllm_hip_moe_block(P, P, C.c_int(4), C.c_int(200), C.c_int(512), C.c_int(2), C.c_int(1), P, arr, arr, arr, None) == lib.ERR_SHAPE      # hidden not in super-blocks
+    assert L.mllm_hip_moe_block(P, P, C.c_int(4), C.c_int(256), C.c_int(512), C.c_int(2), C.c_int(3), P, arr, arr, arr, None) == lib.ERR_SHAPE      # more experts per token than experts
+    assert L.mllm_hip_moe_block(P, P, C.c_int(0), C.c_int(256), C.c_int(512), C.c_int(2), C.c_int(1), P, arr, arr, arr, None) == lib.OK
+    assert L.mllm_hip_moe_block(P, None, C.c_int(4), C.c_int(256), C.c_int(512), C.c_int(2), C.c_int(1), P, arr, arr, arr, None) == lib.ERR_ARG
+    assert L.mllm_hip_scale_rows(P, C.c_int64(6), P, C.c_int(3), C.c_int(6), None) == lib.ERR_SHAPE
+
+
+@pytest.mark.gpu
+def test_hip_moe_block_matches_the_reference_module():
+    """mllm_hip_moe_block against the reference's own MiniCPMMoE run (tests/golden/moe.npz), every output bit: the prefill case (37 tokens: experts with fewer and with
+    more than 16 rows, i.e. both the GEMV and the GEMM form of the expert Linears) and the decode case (one token); then, at a size the golden does not cover (8 experts,
+    3 per token, 300 tokens), against the restatement."""
+    from mllm_amd import mllmfile as mf, ops, synth
+    from tests.fixtures import weights
+    ops.require_gpu()
+    cfg, path, g, om = _moe_setup()
+
+    def run(cfg, path, x):
+        f = mf.MllmFile(path)
+        raw = lambda n: np.array(f.raw(n))
+        b = cfg.base
+        y = ops.moe_block(x, raw(b + "gate.weight"), [raw(f"{b}experts.{e}.w1.weight") for e in range(cfg.experts)], [raw(f"{b}experts.{e}.w3.weight") for e in range(cfg.experts)],
+                          [raw(f"{b}experts.{e}.w2.weight") for e in range(cfg.experts)], cfg.inter, cfg.per_tok).cpu().numpy()
+        f.close()
+        return y
+    for tag in ("p", "d"):
+        assert np.array_equal(run(cfg, path, g["x_" + tag]), g["y_" + tag]), tag
+    big = synth.MoEConfig(hidden=512, inter=768, experts=8, per_tok=3)
+    bpath = weights.moe_file(big)
+    x = synth.moe_input(big, 300, seed=5)
+    assert np.array_equal(run(big, bpath, x), om.moe_block(om.Weights(bpath), big, x))
