@@ -63,3 +63,27 @@ def test_reference_module_runs_through_the_adapter_on_the_null_device(tmp_path):
     assert reports[0]["live_device_blocks"] == reports[1]["live_device_blocks"], reports      # nothing accumulates over decode steps
     assert reports[1]["hip_ops_run"] > reports[0]["hip_ops_run"] > 600
     assert len(np.fromfile(str(tmp_path / "tokens.i32"), dtype=np.int32)) == 9
+
+
+def test_integration_doc_lists_every_registered_creator():
+    """INTEGRATION.md §4 is the adapter's registerOps(), row for row: every `creators_[KEY]` of integration/hip/HIPOps.cpp is named in §4, every C-ABI entry point an
+    Op class calls is named there too, and §4 names no HIP*Op class that does not exist."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "integration", "hip", "HIPOps.cpp")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 4. `registerOps()`"):doc.index("## 5. Build")]
+    keys = re.findall(r"creators_\[([A-Z0-9_]+)\]", src)
+    assert len(keys) >= 25
+    for k in keys:
+        assert f"`{k}`" in sec, f"creator {k} is registered but INTEGRATION.md §4 does not list it"
+    classes = set(re.findall(r"^class (HIP[A-Za-z0-9]+Op) ", src, flags=re.M)) - {"HIPOp"}
+    for c in re.findall(r"`(HIP[A-Za-z0-9]+Op)`", sec):
+        assert c in classes, f"INTEGRATION.md §4 names {c}, which integration/hip/HIPOps.cpp does not define"
+    for c in classes:
+        assert f"`{c}`" in sec, f"{c} is defined but INTEGRATION.md §4 does not describe it"
+    body = src[:src.index("void HIPBackend::registerOps")]
+    for fn in sorted(set(re.findall(r"\b(mllm_hip_[a-z0-9_]+)\(", body))):
+        if fn in ("mllm_hip_last_error", "mllm_hip_sync"):
+            continue
+        assert fn in doc, f"{fn} is called by the adapter but INTEGRATION.md does not mention it"
