@@ -20,6 +20,16 @@ struct DecodeLayer {
     const uint8_t *Wgu_raw, *Wdown_raw, *Wo_raw;       // the rows as stored on disk (the one-lane-per-super-block kernels dec_gateup_blk / dec_proj_blk)
 };
 
+// Weights the kernels behind the attention launch will stream, touched by workgroups the attention does not need (24 of 256 CUs hold a head): region r is read by the
+// later launch's workgroup g as [base[r] + g * bytes[r], + bytes[r]); the warming workgroup with blockIdx % 8 == g % 8 runs on the XCD whose L2 that workgroup will read
+// (consecutive launches place blockIdx b on XCD b % 8).  n == 0: off.  A speed matter only.
+struct WeightWarm {
+    static constexpr int MAXR = 4, GROUPS = 32;      // targets per XCD column: 8 x 32 = 256 workgroups of the later launches
+    const uint8_t *base[MAXR];
+    int bytes[MAXR], count[MAXR], n;
+    uint32_t *sink;
+};
+
 struct DecodeCtx {
     DecodeState *state;
     int H, I, heads, kv_heads, D, vocab, cache_limit, nsplit, max_parts;
@@ -33,10 +43,14 @@ struct DecodeCtx {
     float *cur_sin, *cur_cos;           // [D/2]: the row of the step about to run (refreshed by dec_next)
     uint16_t *kslab, *vslab;            // K: [layers][cache_limit][Hkv*D]; V transposed: [layers][Hkv*D][vt_ld]
     int vt_ld;
+    int n_layers;                       // entries of the DecodeLayer array handed to the launchers
+    const WeightWarm *warm_tab;         // device, [n_layers] (decode_warm_table), or nullptr: no warming workgroups in the attention launch
 };
 
 // raw Q4_K rows -> decode order: the nibble dwords of every super-block transposed so that a lane's 16 bytes are one column class (q4k_dot.h)
 int decode_order_q4k(const void *src, void *dst, int64_t n_blocks, hipStream_t st);
+int decode_attn_flags();
+int decode_warm_table(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, int flags, WeightWarm *host_out);
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st);
 int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st);
 

@@ -454,13 +454,24 @@ static int create_impl(M *m, const MllmFile &f) {
         d.Whead = (const uint8_t *)m->head.wd;
         d.x0 = m->h0; d.x1 = m->h1; d.qkv = m->qkv; d.act = m->act; d.logits = m->logits; d.fa_ws = (float *)m->fa_ws; d.part_val = m->part_val;
         d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos; d.cur_sin = m->cur_sin; d.cur_cos = m->cur_cos;
-        d.kslab = m->kslab; d.vslab = m->vslab; d.vt_ld = m->vt_ld; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
+        d.kslab = m->kslab; d.vslab = m->vslab; d.vt_ld = m->vt_ld; d.n_layers = c.layers; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
         for (auto &L : m->layers) {
             DecodeLayer dl;
             dl.in_norm = L.in_norm; dl.post_norm = L.post_norm; dl.Wqkv = (const uint8_t *)L.qkv.wd; dl.bqkv = L.qkv.bias; dl.qkv_N = L.qkv.N;
             dl.Wo = (const uint8_t *)L.o.wd; dl.Wgu = (const uint8_t *)L.gu.wd; dl.Wdown = (const uint8_t *)L.down.wd;
             dl.Wgu_raw = (const uint8_t *)L.gu.w; dl.Wdown_raw = (const uint8_t *)L.down.w; dl.Wo_raw = (const uint8_t *)L.o.w;
             m->dlayers.push_back(dl);
+        }
+        {      // the attention launch's weight-warming regions, one entry per layer (read when the model is created: the captured graph holds the pointer)
+            std::vector<WeightWarm> tab(m->dlayers.size());
+            const int fl = decode_attn_flags();
+            d.warm_tab = nullptr;
+            if ((fl & 1) && !(fl & 4) && decode_warm_table(d, m->dlayers.data(), (int)m->dlayers.size(), fl, tab.data()) > 0) {
+                WeightWarm *dev = nullptr;
+                EH(m->dalloc(&dev, tab.size() * sizeof(WeightWarm)));
+                HH(hipMemcpy(dev, tab.data(), tab.size() * sizeof(WeightWarm), hipMemcpyHostToDevice));
+                d.warm_tab = dev;
+            }
         }
         m->use_graph = getenv("MLLM_HIP_NO_GRAPH") == nullptr;
     }

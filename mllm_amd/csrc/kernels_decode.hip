@@ -731,18 +731,51 @@ __global__ __launch_bounds__(DEC_ATTN_NT) void dec_attn_kernel(const DecodeState
 // 12 waves: the walker's two register stages (a block each: 50 registers) need more than the 128 registers a 16-wave workgroup leaves a lane -- with 1024 threads the
 // allocator folded the two stages into one and the read-ahead was gone
 constexpr int DEC_PIPE_NT = 768;
+// warmer `slot` of the `nw` on XCD column `col` takes the targets g = col + 8 j, j = slot, slot + nw, ...; per target every region's bytes, 1 KiB per wave and request, as
+// LDS-DMA into a landing pad nobody reads (`pad`: 1 KiB per wave of the workgroup's dynamic LDS): no registers, no waits between the requests, nothing for the compiler to
+// keep alive -- with ordinary loads the eight 16-byte results per thread and their addresses pushed the kernel into spills and scratch
+__device__ __forceinline__ void warm_weights(const WeightWarm *__restrict__ wt, char *pad, int col, int slot, int nw) {
+    constexpr int NWV = DEC_PIPE_NT / 64;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const unsigned dst = (unsigned)(size_t)pad + (unsigned)wid * 1024u;
+    const int n = wt->n;
+    for (int j = slot; j < WeightWarm::GROUPS; j += nw) {
+        const int g = col + 8 * j;
+        for (int r = 0; r < n; ++r) {
+            const int bytes = wt->bytes[r];
+            if (g >= wt->count[r]) continue;
+            const uint8_t *src = wt->base[r] + (int64_t)g * bytes;
+            for (int o = wid * 1024; o < bytes; o += NWV * 1024) {
+                const int off = o + lane * 16;
+                glds16_dec(src + (off < bytes ? off : 0), dst);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 template <int D, int DS>
 __global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_pipe_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
                                                                     const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
-                                                                    float *__restrict__ out, int Hq, int Hkv, int cache_limit, int vt_ld, int flags) {
+                                                                    float *__restrict__ out, int Hq, int Hkv, int cache_limit, int vt_ld, int flags, int attn_groups,
+                                                                    const WeightWarm *__restrict__ ww) {
     constexpr int HALF = D / 2, DV = D / DS, NWK = (DV + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint16_t knew[D];
     __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
     const int gsize = Hq / Hkv, per_kv = gsize * DS;
     int kvh, sub;
-    if (flags & 1) { const int col = blockIdx.x & 7, idx = blockIdx.x >> 3; kvh = (idx / per_kv) * 8 + col; sub = idx % per_kv; }
-    else { kvh = blockIdx.x / per_kv; sub = blockIdx.x % per_kv; }
+    if (flags & 1) {
+        const int col = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        kvh = (idx / per_kv) * 8 + col; sub = idx % per_kv;
+        // warming workgroups (only when the layer has a table): the extra ones behind the attention's grid, and -- on an XCD column no K/V head lives on -- the attention slots too
+        const bool col_dead = col >= Hkv;
+        if (ww && (idx >= attn_groups || col_dead)) {
+            const int ext = (int)(gridDim.x >> 3) - attn_groups;
+            const int nw = ext + (col_dead ? attn_groups : 0), slot = idx >= attn_groups ? idx - attn_groups + (col_dead ? attn_groups : 0) : idx;
+            warm_weights(ww, smem, col, slot, nw);
+            return;
+        }
+    } else { kvh = blockIdx.x / per_kv; sub = blockIdx.x % per_kv; }
     if (kvh >= Hkv) return;
     const int gh = sub / DS, vdim0 = (sub % DS) * DV;
     const int head = kvh * gsize + gh;
@@ -1106,6 +1139,43 @@ int decode_order_q4k(const void *src, void *dst, int64_t n_blocks, hipStream_t s
     return MH_LAUNCH_OK("q4k_decode_order");
 }
 
+// the attention flags in force (option "attn_flags", else the default): bit 0 XCD placement of a K/V group's heads, bit 1 two-stage key fetch (un-pipelined kernel),
+// bit 2 keep the un-pipelined kernel, bit 3 dec_qkv warms the L2 with the cache rows, bits 4..7 weight-warming workgroups (decode_warm_table)
+int decode_attn_flags() { return option(OPT_ATTN_FLAGS) >= 0 ? option(OPT_ATTN_FLAGS) : 91; }
+// the table of warming regions of every layer (host side; the engine uploads it once): which rows the launches behind layer li's attention will stream, and how they
+// fall onto those launches' workgroups.  flags = the attention flags: bit 4 gate|up, bit 5 down, bit 6 o-projection, bit 7 the next layer's q|k|v.  Returns 0 when no layer has
+// a region (the caller then leaves DecodeCtx::warm_tab null).
+int decode_warm_table(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, int flags, WeightWarm *out) {
+    int any = 0;
+    for (int li = 0; li < n_layers; ++li) {
+        const DecodeLayer &L = layers[li];
+        WeightWarm ww{};
+        if (L.Wgu_raw && L.Wdown_raw && c.H % 256 == 0 && c.I % 256 == 0) {
+            const int nbH = c.H / 256, nbI = c.I / 256;
+            if ((flags & 16) && c.I % (GUB_PAIRS * GUB_WPB) == 0 && c.I / (GUB_PAIRS * GUB_WPB) <= 8 * WeightWarm::GROUPS) {      // dec_gateup_blk: workgroup g = pairs [g * 35, + 35)
+                const int per = GUB_PAIRS * GUB_WPB * nbH * 144, cnt = c.I / (GUB_PAIRS * GUB_WPB);
+                ww.base[ww.n] = L.Wgu_raw; ww.bytes[ww.n] = per; ww.count[ww.n] = cnt; ++ww.n;
+                ww.base[ww.n] = L.Wgu_raw + (int64_t)c.I * nbH * 144; ww.bytes[ww.n] = per; ww.count[ww.n] = cnt; ++ww.n;
+            }
+            if ((flags & 64) && L.Wo && (c.heads * c.D) % 256 == 0 && (c.heads * c.D) / 256 <= 8 && c.H % (PJ_ROWS1 * PJ_WPB1) == 0) {      // dec_proj (o): workgroup g = rows [g * 16, + 16) of the decode-order rows
+                const int per = PJ_ROWS1 * PJ_WPB1 * ((c.heads * c.D) / 256) * 144, cnt = c.H / (PJ_ROWS1 * PJ_WPB1);
+                if (cnt <= 8 * WeightWarm::GROUPS) { ww.base[ww.n] = L.Wo; ww.bytes[ww.n] = per; ww.count[ww.n] = cnt; ++ww.n; }
+            }
+            if ((flags & 128) && li + 1 < n_layers && nbH <= 8 && layers[li + 1].qkv_N % (QKV_ROWS * QKV_WPB) == 0) {      // the next layer's dec_qkv: workgroup g = rows [g * 16, + 16)
+                const int per = QKV_ROWS * QKV_WPB * nbH * 144, cnt = layers[li + 1].qkv_N / (QKV_ROWS * QKV_WPB);
+                if (cnt <= 8 * WeightWarm::GROUPS && ww.n < WeightWarm::MAXR) { ww.base[ww.n] = layers[li + 1].Wqkv; ww.bytes[ww.n] = per; ww.count[ww.n] = cnt; ++ww.n; }
+            }
+            if ((flags & 32) && ww.n < WeightWarm::MAXR) {      // dec_proj_blk (down): workgroup g = rows [g * rpw, + rpw)
+                const int rpw = std::max(1, std::min(512 / nbI, (c.H + 255) / 256)), cnt = (c.H + rpw - 1) / rpw;
+                if (cnt <= 8 * WeightWarm::GROUPS && c.H % rpw == 0) { ww.base[ww.n] = L.Wdown_raw; ww.bytes[ww.n] = rpw * nbI * 144; ww.count[ww.n] = cnt; ++ww.n; }
+            }
+        }
+        any += ww.n;
+        out[li] = ww;
+    }
+    return any;
+}
+
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st) {
     if ((c.D != 128 && c.D != 64) || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
     float *x = c.x0, *t = c.x1;
@@ -1115,7 +1185,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
     case 0:
     {
         // bit 3 of the attention flags (set by default): dec_qkv warms the L2 with the layer's cache rows for the attention launch that follows
-        const int aflags = option(OPT_ATTN_FLAGS) >= 0 ? option(OPT_ATTN_FLAGS) : 11;
+        const int aflags = decode_attn_flags();
         KvWarm kw{nullptr, nullptr, nullptr, c.kv_heads, c.D, c.kv_heads * c.D, c.vt_ld, c.cache_limit};
         if ((aflags & 8) && (aflags & 1) && c.kv_heads <= 8) {
             kw.kslab = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D;
@@ -1130,10 +1200,13 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
         // bit 0: XCD placement of a K/V group's heads, bit 1: two-stage key fetch (both neutral in time at T = 290..430, profiles/r02_attn_experiments.md;
         // the second keeps the fetched bytes near the algorithmic ones at short contexts)
-        const int flags = option(OPT_ATTN_FLAGS) >= 0 ? option(OPT_ATTN_FLAGS) : 11;
+        const int flags = decode_attn_flags();
         const int ds_env = option(OPT_ATTN_DS) > 0 ? option(OPT_ATTN_DS) : 0;     // workgroups per head (1, 2 or 4); 0 = default
         const int ds = ds_env == 1 || ds_env == 2 || ds_env == 4 ? ds_env : 2;
         const dim3 grid((flags & 1) ? dec_attn_grid(c.heads, c.kv_heads, ds) : c.heads * ds);
+        // the workgroups the attention does not need read this layer's gate|up (and o-projection) rows, so that the XCD L2s hold them when those launches arrive
+        const int attn_groups = (int)grid.x / 8;
+        const WeightWarm *ww = (flags & 1) && !(flags & 4) && c.warm_tab ? c.warm_tab + li : nullptr;
         // bit 2 of the flags (unset by default) keeps the un-pipelined kernel; caches beyond 2048 keys (more than 64 blocks: the carry is taken by one wave pass) stay on it too
         if (!(flags & 4) && c.cache_limit <= 2048 && (c.D == 128 || c.D == 64)) {
 #define DEC_PIPE_CASE(DD, DSV)                                                                                                                            \
@@ -1143,8 +1216,8 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         if (plds <= 160 * 1024 - 2 * DD * 2 - 64) {                                                                                                       \
             rc = allow_lds(dec_attn_pipe_kernel<DD, DSV>, plds);                                                                                          \
             if (rc) return rc;                                                                                                                            \
-            hipLaunchKernelGGL((dec_attn_pipe_kernel<DD, DSV>), grid, dim3(DEC_PIPE_NT), plds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, \
-                               c.heads, c.kv_heads, c.cache_limit, c.vt_ld, flags);                                                                       \
+            hipLaunchKernelGGL((dec_attn_pipe_kernel<DD, DSV>), dim3(grid.x + (ww ? 8 * std::max(8, WeightWarm::GROUPS - attn_groups) : 0)), dim3(DEC_PIPE_NT), plds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.fa_ws, \
+                               c.heads, c.kv_heads, c.cache_limit, c.vt_ld, flags, attn_groups, ww);                                                      \
             return MH_LAUNCH_OK("dec_attn_pipe");                                                                                                         \
         }                                                                                                                                                 \
     }

@@ -103,3 +103,27 @@ def test_pipelined_decode_attention_equals_the_unpipelined_kernel_over_a_long_co
             lib.set_option("attn_flags", -1)
     assert runs[7][0].tolist() == runs[3][0].tolist()
     assert np.array_equal(runs[7][1], runs[3][1]) and np.array_equal(runs[7][2], runs[3][2])
+
+
+def test_weight_warming_workgroups_change_nothing_but_time():
+    """The attention launch's warming workgroups (attn_flags bits 4 / 6: the CUs that hold no head read the layer's gate|up and o-projection rows through LDS-DMA into a
+    landing pad, so that the XCD L2s hold them when those launches arrive) at the 2B shape -- where every region of decode_warm_table exists -- against the same model
+    without them: identical ids over 200 steps and bit-identical logits of the step behind them."""
+    from tests.fixtures import weights
+    cfg = synth.qwen2vl_2b()
+    path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
+    pix, grid, ids = synth.qwen2vl_inputs(cfg, (32, 32), 24)
+    runs = {}
+    for flags in (11, 91, 251):
+        lib.set_option("attn_flags", flags)
+        try:
+            m = lib.Qwen2VL(cfg, path)
+            tok, _, _ = m.prefill(ids, pix, grid, want_logits=False)
+            toks, _ = m.generate(tok, 200)
+            _, lg, _ = m.decode(int(toks[-1]))
+            runs[flags] = (toks.copy(), lg.copy())
+            m.close()
+        finally:
+            lib.set_option("attn_flags", -1)
+    for flags in (91, 251):
+        assert runs[flags][0].tolist() == runs[11][0].tolist() and np.array_equal(runs[flags][1], runs[11][1]), flags
