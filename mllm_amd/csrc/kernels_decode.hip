@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__
     __syncthreads();
     Q40Act<BPL> A;
     q40_load_act<BPL, 16>(A, xq, xdd, nullptr, sub);
-    float *ts = reinterpret_cast<float *>(smem + (((size_t)K * 5 + (size_t)K / 32 * 4 + 15) & ~(size_t)15)) + wid * q40_tab_floats(nblk), *td = ts + 8 * nblk * 8;
+    float *ts = reinterpret_cast<float *>(smem + (((size_t)K * 5 + (size_t)K / 32 * 4 + 15) & ~(size_t)15)) + wid * q40_tab_floats(nblk), *td = ts + 8 * q40_ts_stride(nblk);
     float best = -INFINITY;
     int besti = 0x7fffffff;
     for (int base = row0; base < row1; base += 8) {
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int rl = 4 * u + rsel;
-            q40_emit<BPL, 16>(q[u], dw[u], A, sub, ts + (size_t)rl * nblk * 8, td + (size_t)rl * nblk);
+            q40_emit<BPL, 16>(q[u], dw[u], A, sub, ts + (size_t)rl * q40_ts_stride(nblk), td + (size_t)rl * q40_td_stride(nblk));
         }
         wave_lds_fence();
         const float acc = q40_chain(ts, td, nblk, min(8, row1 - base), lane);

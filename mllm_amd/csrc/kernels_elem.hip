@@ -276,6 +276,109 @@ __global__ __launch_bounds__(256) void norm_kernel(const float *__restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// A18 LayerNorm as ONE launch for rows of NCH * 256 values (the towers' 1024 / 1280): a workgroup takes four rows, wave r owns row r.
+// Every wave fetches its row into registers (NCH x 16 bytes per lane, all requests out at once; lane l holds values 4l..4l+3 of each 256-block -- the layout the Q8_K
+// quantiser and the GEMM operand packer want) and parks it in LDS; lanes 0..3 of wave 0 walk the rows' `sum += x[d]` chains (the reference's order: one lane per row),
+// the 16-byte LDS reads issued five ahead of their use, one per four links; the waves centre their rows from their registers (c = x - mean is order-free) and park them
+// again; wave 0 walks `ssq = fma(c, c, ssq)` the same way; then each wave normalises, quantises and packs its own row from its registers.
+// Against ln_stats_kernel + norm_kernel<true>: one launch instead of two, one read of x instead of two, 256 workgroups instead of 64.  What bounds it is the walk: a lone
+// wave's dependent add issues every 6.6 cycles and every instruction placed between two links (a read, a counted wait) costs its own issue on top -- 12 cycles per link
+// measured.  Tried and slower: the chain on a wave-uniform accumulator fed by `v_readlane_b32` from the row's registers (no LDS, no barrier, 2 instructions per link):
+// 23.8 us against 19.7.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int LNF_ROWS = 4;
+typedef float lnf_f32x4 __attribute__((ext_vector_type(4)));
+__host__ __device__ constexpr size_t lnf_lds_bytes(int dim) { return ((size_t)LNF_ROWS * (dim + 4) + 32) * sizeof(float); }
+template <bool SQ>
+__device__ __forceinline__ float lnf_step(float acc, const lnf_f32x4 (&cur)[4], lnf_f32x4 (&nxt)[4], const float *nxt_src) {
+    // 16 chain links on `cur`, the four reads of `nxt` placed one per four links
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        nxt[q] = *reinterpret_cast<const lnf_f32x4 *>(nxt_src + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = SQ ? __fmaf_rn(cur[q][e], cur[q][e], acc) : __fadd_rn(acc, cur[q][e]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // four VALU
+    }
+    return acc;
+}
+template <bool SQ>
+__device__ __forceinline__ float lnf_walk(const float *rp, int dim) {
+    // rp: the lane's row in LDS (16-byte aligned); reads run one step (16 values) ahead and over-read 16 values behind the row (slack the caller provides)
+    float acc = 0.0f;
+    lnf_f32x4 A[4], B[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) A[q] = *reinterpret_cast<const lnf_f32x4 *>(rp + 4 * q);
+    for (int k = 0; k < dim; k += 32) {
+        acc = lnf_step<SQ>(acc, A, B, rp + k + 16);
+        acc = lnf_step<SQ>(acc, B, A, rp + k + 32);
+    }
+    return acc;
+}
+template <int NCH>
+__global__ __launch_bounds__(64 * LNF_ROWS) void ln_fused_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ y,
+                                                                 int8_t *__restrict__ qs, float *__restrict__ qd, int16_t *__restrict__ bsums, uint8_t *__restrict__ pack,
+                                                                 int M, float eps) {
+    constexpr int dim = NCH * 256, pitch = dim + 4;
+    extern __shared__ __attribute__((aligned(16))) char lnf_smem[];
+    float *rows = reinterpret_cast<float *>(lnf_smem);
+    float *mean_s = rows + LNF_ROWS * pitch + 16, *std_s = mean_s + LNF_ROWS;      // behind the 16 floats of over-read slack
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = blockIdx.x * LNF_ROWS + wid;
+    const size_t tb = pack ? q4kp_tile_blocks(M, NCH) : 0;
+    if (blockIdx.x * LNF_ROWS >= M) {      // padding rows of the last 32-row tile of the packed operand: zeros
+        if (pack)
+            for (int blk = 0; blk < NCH; ++blk) wave_quant_pack(make_float4(0, 0, 0, 0), lane, false, pack, tb, NCH, row, blk);
+        return;
+    }
+    const bool live = row < M;
+    const float *xr = x + (int64_t)min(row, M - 1) * dim;
+    float4 v[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) v[c] = *reinterpret_cast<const float4 *>(xr + c * 256 + lane * 4);
+    float *mine = rows + wid * pitch;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4 *>(mine + c * 256 + lane * 4) = v[c];
+    __syncthreads();
+    const float *rp = rows + (lane & (LNF_ROWS - 1)) * pitch;
+    if (wid == 0 && lane < LNF_ROWS) mean_s[lane] = lnf_walk<false>(rp, dim) / (float)dim;
+    __syncthreads();
+    const float mean = mean_s[wid];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        v[c].x = __fsub_rn(v[c].x, mean); v[c].y = __fsub_rn(v[c].y, mean); v[c].z = __fsub_rn(v[c].z, mean); v[c].w = __fsub_rn(v[c].w, mean);
+        *reinterpret_cast<float4 *>(mine + c * 256 + lane * 4) = v[c];
+    }
+    __syncthreads();
+    if (wid == 0 && lane < LNF_ROWS) std_s[lane] = sqrtf(lnf_walk<true>(rp, dim) / (float)dim + eps);
+    __syncthreads();
+    const float sd = std_s[wid];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int d0 = c * 256 + lane * 4;
+        const float4 ww = *reinterpret_cast<const float4 *>(w + d0);
+        float4 o;
+        o.x = __fdiv_rn(__fmul_rn(ww.x, v[c].x), sd);
+        o.y = __fdiv_rn(__fmul_rn(ww.y, v[c].y), sd);
+        o.z = __fdiv_rn(__fmul_rn(ww.z, v[c].z), sd);
+        o.w = __fdiv_rn(__fmul_rn(ww.w, v[c].w), sd);
+        if (b) {
+            const float4 bb = *reinterpret_cast<const float4 *>(b + d0);
+            o.x = __fadd_rn(o.x, bb.x); o.y = __fadd_rn(o.y, bb.y); o.z = __fadd_rn(o.z, bb.z); o.w = __fadd_rn(o.w, bb.w);
+        }
+        if (!live) { if (pack) wave_quant_pack(make_float4(0, 0, 0, 0), lane, false, pack, tb, NCH, row, c); continue; }
+        if (y) *reinterpret_cast<float4 *>(y + (int64_t)row * dim + d0) = o;
+        if (qs) {
+            const int64_t gblk = (int64_t)row * NCH + c;
+            wave_quant_q8k(o, lane, qs + gblk * 256, qd + gblk, bsums + gblk * 16);
+        }
+        if (pack) wave_quant_pack(o, lane, true, pack, tb, NCH, row, c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // A14: x/(1+exp(-x)) with the reference's AVX2 polynomial expf, one fp32 lane of it
 // (compute/ActivationFunction.hpp:96-134 mllm_v_expf, :137-146 mllm_v_silu): same constants, same fma placement.
 // ------------------------------------------------------------------------------------------------------------------
@@ -620,6 +723,15 @@ static int layernorm_impl(const float *x, const float *w, const float *b, float 
     if ((qs || pack) && dim % 256 != 0) return MLLM_HIP_ERR_SHAPE;
     if (qs && (!d || !bsums)) return MLLM_HIP_ERR_SHAPE;
     if (!qs && !y && !pack) return MLLM_HIP_ERR_ARG;
+    if (dim % 256 == 0 && dim / 256 <= 8 && option(OPT_NO_LNF) <= 0) {      // rows of 256 .. 2048 values: the whole op in one launch
+        const int rows = pack ? (M + 31) & ~31 : M;
+        const dim3 grid((rows + LNF_ROWS - 1) / LNF_ROWS), block(64 * LNF_ROWS);
+        const size_t lds = lnf_lds_bytes(dim);
+#define LNF_CASE(N) case N: hipLaunchKernelGGL(ln_fused_kernel<N>, grid, block, lds, as_stream(stream), x, w, b, y, qs, d, bsums, pack, M, eps); break;
+        switch (dim / 256) { LNF_CASE(1) LNF_CASE(2) LNF_CASE(3) LNF_CASE(4) LNF_CASE(5) LNF_CASE(6) LNF_CASE(7) LNF_CASE(8) }
+#undef LNF_CASE
+        return MH_LAUNCH_OK("layernorm_fused");
+    }
     // per-row (mean, rms) scratch: grown on demand, owned by the library (stream-ordered use only)
     static float *stats = nullptr;
     static int stats_rows = 0;

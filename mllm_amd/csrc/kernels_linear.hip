@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict
     constexpr int nblk = BPL * LPR;
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, wid = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wid;
-    float *ts = reinterpret_cast<float *>(q40_smem) + wid * q40_tab_floats(nblk), *td = ts + 8 * nblk * 8;
+    float *ts = reinterpret_cast<float *>(q40_smem) + wid * q40_tab_floats(nblk), *td = ts + 8 * q40_ts_stride(nblk);
     Q40Act<BPL> A;
     q40_load_act<BPL, LPR>(A, xqs, nullptr, xd, sub);
     const int row0 = wave * rows_per_wave, row1 = min(N, row0 + rows_per_wave);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict
 #pragma unroll
         for (int u = 0; u < NPASS; ++u) {
             const int rl = RPW * u + rsel;
-            q40_emit<BPL, LPR>(q[u], dw[u], A, sub, ts + (size_t)rl * nblk * 8, td + (size_t)rl * nblk);
+            q40_emit<BPL, LPR>(q[u], dw[u], A, sub, ts + (size_t)rl * q40_ts_stride(nblk), td + (size_t)rl * q40_td_stride(nblk));
         }
         wave_lds_fence();
         const float acc = q40_chain(ts, td, nblk, min(8, row1 - base), lane);

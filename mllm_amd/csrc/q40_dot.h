@@ -22,7 +22,10 @@ __device__ __forceinline__ void q40_load_act(Q40Act<BPL> &A, const int8_t *xqs, 
         A.yb8[b] = make_int4(8 * dot4(A.xb[b].x, one, 0), 8 * dot4(A.xb[b].y, one, 0), 8 * dot4(A.xb[b].z, one, 0), 8 * dot4(A.xb[b].w, one, 0));
     }
 }
-// table of one wave: ts[rows][nblk][8] floats then td[rows][nblk]
+// table of one wave: ts[rows][nblk][8] floats then td[rows][nblk], each row padded by 8 floats: with the bare pitches (8 * nblk and nblk floats, multiples of 64 and 16
+// dwords at K = 1536) the eight rows a chain step reads at once fell into the same eight LDS banks -- SQ_LDS_BANK_CONFLICT was 12 us of dec_head's 35 (profiles/r03)
+__host__ __device__ constexpr int q40_ts_stride(int nblk) { return nblk * 8 + 8; }
+__host__ __device__ constexpr int q40_td_stride(int nblk) { return nblk + 8; }
 template <int BPL, int LPR>
 __device__ __forceinline__ void q40_emit(const uint4 (&q)[BPL], const uint16_t (&dw)[BPL], const Q40Act<BPL> &A, int sub, float *ts_row, float *td_row) {
 #pragma unroll
@@ -48,7 +51,7 @@ __device__ __forceinline__ float q40_chain(const float *ts, const float *td, int
     const int cls = (c & 1) * 4 + bitrev2(c >> 1);
     float acc = 0.0f;
     if (rr < nrows) {
-        const float *s = ts + (size_t)rr * nblk * 8 + cls, *d = td + (size_t)rr * nblk;
+        const float *s = ts + (size_t)rr * q40_ts_stride(nblk) + cls, *d = td + (size_t)rr * q40_td_stride(nblk);
 #pragma unroll 8
         for (int i = 0; i < nblk; ++i) acc = __fmaf_rn(d[i], s[i * 8], acc);
     }
@@ -57,6 +60,6 @@ __device__ __forceinline__ float q40_chain(const float *ts, const float *td, int
     acc += MH_DPPF(0.0f, acc, DPP_HALF_MIRROR, 0xF);
     return acc;
 }
-constexpr size_t q40_tab_floats(int nblk) { return (size_t)8 * nblk * 9; }   // per wave: 8 rows x (8 sums + 1 scale) per block
+constexpr size_t q40_tab_floats(int nblk) { return (size_t)8 * (q40_ts_stride(nblk) + q40_td_stride(nblk)); }   // per wave: 8 rows x (8 sums + 1 scale) per block, padded rows
 
 }  // namespace mllm_hip
