@@ -116,6 +116,10 @@ int mllm_hip_quantize_q8k_packed_silu_mul(const float *gu, void *xpack, int M, i
 int mllm_hip_linear_q4kp_packed(const void *Wpacked, const float *bias, const void *xpack, void *y, int y_dtype, int64_t ldy,
                                 const float *residual, int M, int N, int K, void *stream);
 int mllm_hip_linear_f32(const float *W, const float *bias, const float *x, float *y, int64_t ldy, int M, int N, int K, void *stream);
+/* F_MM on BHSD operands, the eager-attention form (backends/cpu/op/CPUMatmulFunc.hpp:155-172 -> compute/GemmFp.hpp:104-150 gemm_fp32, :233-283 gemm_fp32_fp16):
+ * per head c[M][N] = a[M][K] b[K][N], all contiguous ([heads][M][K], [heads][K][N], [heads][M][N]); b_dtype MLLM_HIP_F32 or MLLM_HIP_F16.  Elements of full 8 x 8 tiles are one
+ * fma chain over K from zero, elements of edge tiles per-256-block partial sums added up -- the reference's x86 micro-kernel / scalar split, bit for bit. */
+int mllm_hip_gemm_f32_bhsd(const float *a, const void *b, int b_dtype, float *c, int heads, int M, int N, int K, void *stream);
 /* one-call forms = CPULinear::execute (backends/cpu/op/CPULinear.cpp:98-234): fp32 x in, quantise, dot, bias.
  * `workspace` must hold mllm_hip_linear_workspace_bytes(wdtype, M, K) bytes of device memory. */
 size_t mllm_hip_linear_workspace_bytes(int wdtype, int M, int K);

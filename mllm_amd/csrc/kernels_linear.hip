@@ -679,6 +679,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             if (c == i * F32_TN + j && m0 + i < M && n0 + j < N) y[(int64_t)(m0 + i) * ldy + n0 + j] = bias ? acc[i][j] + bias[n0 + j] : acc[i][j];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// A7, eager-attention form: gemm_fp32 / gemm_fp32_fp16 (compute/GemmFp.hpp:104-150, :233-283) per head on BHSD operands.  One thread per output element (the
+// reference's order leaves every element its own chain over K); 64 consecutive columns per wave, so the row of B is one coalesced read and A's value a broadcast.
+// Non-default path (attn_implementation = "eager"): written for parity, not tuned.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool B16>
+__global__ __launch_bounds__(256) void gemm_f32_bhsd_kernel(const float *__restrict__ a, const void *__restrict__ bv, float *__restrict__ c, int M, int N, int K) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6), h = blockIdx.z;
+    if (i >= M || j >= N) return;
+    const float *A = a + ((int64_t)h * M + i) * K;
+    const float *B32 = reinterpret_cast<const float *>(bv) + (int64_t)h * K * N + j;
+    const uint16_t *B16p = reinterpret_cast<const uint16_t *>(bv) + (int64_t)h * K * N + j;
+    auto bval = [&](int k) -> float { return B16 ? h2f(B16p[(int64_t)k * N]) : B32[(int64_t)k * N]; };
+    float acc = 0.0f;
+    if (i < M - M % 8 && j < N - N % 8) {      // a full 8 x 8 tile: the AVX micro-kernel's chain, carried through C across the K blocks
+        for (int k = 0; k < K; ++k) acc = __fmaf_rn(A[k], bval(k), acc);
+    } else {                                   // edge tiles: the scalar path, one partial sum per 256-wide K block
+        for (int k0 = 0; k0 < K; k0 += 256) {
+            float sum = 0.0f;
+            const int k1 = min(k0 + 256, K);
+            for (int k = k0; k < k1; ++k) sum = __fmaf_rn(A[k], bval(k), sum);
+            acc = __fadd_rn(acc, sum);
+        }
+    }
+    c[((int64_t)h * M + i) * N + j] = acc;
+}
+
 static int launch_gemv_q4k(const void *W, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums, void *y, int y_f16,
                            const float *residual, int N, int K, hipStream_t st) {
     const int nb = K / 256;
@@ -832,6 +859,17 @@ extern "C" int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, c
     return MLLM_HIP_OK;
 }
 
+extern "C" int mllm_hip_gemm_f32_bhsd(const float *a, const void *b, int b_dtype, float *c, int heads, int M, int N, int K, void *stream) {
+    if (heads < 0 || M < 0 || N < 0 || K <= 0) return MLLM_HIP_ERR_SHAPE;
+    if (b_dtype != MLLM_HIP_F32 && b_dtype != MLLM_HIP_F16) return MLLM_HIP_ERR_DTYPE;
+    if (heads == 0 || M == 0 || N == 0) return MLLM_HIP_OK;
+    if (!a || !b || !c) return MLLM_HIP_ERR_ARG;
+    if (heads > 65535 || (M + 3) / 4 > 65535) return MLLM_HIP_ERR_SHAPE;
+    const dim3 grid((N + 63) / 64, (M + 3) / 4, heads);
+    if (b_dtype == MLLM_HIP_F16) hipLaunchKernelGGL(gemm_f32_bhsd_kernel<true>, grid, dim3(256), 0, as_stream(stream), a, b, c, M, N, K);
+    else hipLaunchKernelGGL(gemm_f32_bhsd_kernel<false>, grid, dim3(256), 0, as_stream(stream), a, b, c, M, N, K);
+    return MH_LAUNCH_OK("gemm_f32_bhsd");
+}
 extern "C" int mllm_hip_linear_f32(const float *W, const float *bias, const float *x, float *y, int64_t ldy, int M, int N, int K, void *stream) {
     if (K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
     if (M <= 0) return MLLM_HIP_OK;

@@ -101,6 +101,19 @@ def linear_f32(W, x, bias=None):
     return y
 
 
+def gemm_f32_bhsd(a, b):
+    """F_MM on BHSD operands (CPUMatmulFunc.hpp:155-172 -> GemmFp.hpp:104-150): a [heads, M, K] fp32, b [heads, K, N] fp32 or fp16 -> [heads, M, N] fp32."""
+    a = _dev(a, torch.float32)
+    b16 = (b.dtype == torch.float16) if isinstance(b, torch.Tensor) else (np.asarray(b).dtype == np.float16)
+    b = _dev(b, torch.float16 if b16 else torch.float32)
+    H, M, K = a.shape
+    N = b.shape[2]
+    assert tuple(b.shape) == (H, K, N)
+    c = torch.empty((H, M, N), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_gemm_f32_bhsd(vp(a), vp(b), C.c_int(L.F16 if b16 else L.F32), vp(c), C.c_int(H), C.c_int(M), C.c_int(N), C.c_int(K), _stream()), "gemm_f32_bhsd")
+    return c
+
+
 def embedding_q40(ids, W_raw, vocab, hidden):
     Wqs, Wd = repack_q40(W_raw, vocab * hidden // 32)
     ids = _dev(np.asarray(ids, dtype=np.float32))

@@ -507,7 +507,28 @@ def moe_golden():
     print("moe.npz", G["y_p"].shape, float(np.abs(G["y_p"]).max()))
 
 
+def mm_bhsd_golden():
+    """The eager-attention form of F_MM (CPUMatmulFunc.hpp:123-172 -> compute/GemmFp.hpp:104-150, x86 path) run by the reference itself on BHSD tensors (ref_ops case
+    mm_bhsd): q k^T with rows / columns that do not fill the 8 x 8 micro-kernel, p v, a contraction longer than one 256-wide K block on edge tiles, and all-full tiles."""
+    r = np.random.default_rng(53)
+    pn = quantize_file([("dummy.weight", np.zeros(32, dtype=np.float32))], target="F32")
+    G = {}
+    # name: heads, M, N, K, transpose-the-right-operand-first
+    # (the reference's own BHSD (SEQUENCE, DIMENSION) transpose asserts on non-square operands -- CPUTransposeFunc.hpp:172 -- so the right operand is handed over as [K][N]; tr stays in the driver for a reference that fixes it)
+    cases = {"qk": (3, 21, 21, 64, 0), "pv": (3, 21, 64, 21, 0), "long": (2, 10, 17, 300, 0), "full": (2, 16, 24, 40, 0), "deep": (1, 24, 16, 600, 0)}
+    for name, (H, M, N, K, tr) in cases.items():
+        a = r.standard_normal((H, M, K), dtype=np.float32)
+        b = r.standard_normal((H, N, K) if tr else (H, K, N), dtype=np.float32)
+        (y,), _ = run_ops("mm_bhsd", pn, [[(a, (1, H, M, K)), (b, (1, H, N, K) if tr else (1, H, K, N))]], p=(tr,))
+        G[name + "_a"], G[name + "_b"], G[name + "_y"], G[name + "_p"] = a, b, y.reshape(H, M, N), np.array([H, M, N, K, tr])
+    np.savez_compressed(os.path.join(GOLD, "mm_bhsd.npz"), **G)
+    print("mm_bhsd.npz", {k: v.shape for k, v in G.items() if k.endswith("_y")})
+
+
 if __name__ == "__main__":
+    if "--mm-bhsd" in sys.argv:
+        mm_bhsd_golden()
+        sys.exit(0)
     if "--moe" in sys.argv:
         moe_golden()
         sys.exit(0)

@@ -463,3 +463,16 @@ def qwen2vl_preprocess(rgb_u8):
     x = stb_resize_bspline(x, nh, nw)                                                  # fetch_image: always resampled, even at equal size
     x = ((x - QWEN2VL_MEAN) / QWEN2VL_STD).astype(np.float32)                          # NormalizeImages(means, stds)
     return qwen2vl_patchify(np.ascontiguousarray(x.transpose(2, 0, 1)))
+
+
+def gemm_fp32_bhsd(a, b):
+    """F_MM on BHSD operands (CPUMatmulFunc.hpp:155-172 -> compute/GemmFp.hpp:104-150 / :233-283): a [heads, M, K] fp32, b [heads, K, N] fp32 or fp16 -> [heads, M, N]."""
+    a = _f32(a)
+    b16 = np.asarray(b).dtype == np.float16
+    b = np.ascontiguousarray(b, dtype=np.float16 if b16 else np.float32)
+    H, M, K = a.shape
+    N = b.shape[2]
+    assert b.shape == (H, K, N)
+    c = np.empty((H, M, N), dtype=np.float32)
+    lib().orc_gemm_fp32_bhsd(_p(a), b.ctypes.data_as(C.c_void_p), C.c_int(int(b16)), _p(c), C.c_int(H), C.c_int(M), C.c_int(N), C.c_int(K))
+    return c

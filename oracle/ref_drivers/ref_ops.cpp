@@ -68,7 +68,7 @@ public:
             RoPEConfig cfg = {{"rope_theta", p(1)}, {"max_position_embeddings", (int)p(2)}, {"rope_scaling", sc}};
             l0 = RoPE((int)p(0), cfg, "rope");
         }
-        else if (k == "fa2") {}
+        else if (k == "fa2" || k == "mm_bhsd") {}
         // ---- N4: ops of the other model families
         else if (k == "swmask") l0 = SlidingWindowMask((int)p(0), "mask");                       // p: window, heads, keys
         else if (k == "ntkrope") {                                                                // p: theta, max_pos, original max_pos, heads, D, then D/2 long and D/2 short factors
@@ -131,6 +131,12 @@ public:
         }
         if (kind == "gather_rows") return {in[0].clip(in[1], SEQUENCE)};       // Tensor.cpp:580 -> CPUClipTensorFunc
         if (kind == "fuyu_gather") return {Tensor::fuyu_gather_embd(in[0], in[1], in[2])};   // CPUFuyuGatherEmbdFunc.hpp:45-62
+        if (kind == "mm_bhsd") {     // the eager-attention form of F_MM (CPUMatmulFunc.hpp:123-172 -> compute/GemmFp.hpp:104-150): p = transpose the right operand first (q k^T) or not (p v)
+            auto a = in[0].transpose(Chl::HEAD, Chl::SEQUENCE);      // BSHD -> BHSD, a data move (CPUTransposeFunc.hpp:129-160)
+            auto b = in[1].transpose(Chl::HEAD, Chl::SEQUENCE);
+            if (p(0) != 0) b = b.transpose(Chl::SEQUENCE, Chl::DIMENSION);      // BHSD -> BHDS (:167-185)
+            return {Tensor::mm(a, b)};
+        }
         if (kind == "fa2") {
             // in: q [1,1,Sq,Hq*D], k,v [1,1,Sk,Hkv*D] all fp32 (the vision / fp32-KV path, FlashAttention2.hpp:87)
             auto q = in[0].view(-1, (int)p(0), -1, (int)p(2));

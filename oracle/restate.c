@@ -683,3 +683,35 @@ void orc_conv2d_patch(const float *img, int H, int C, int Wd, const float *Wt, i
 /* A20: elementwise (CPUBinaryFunc.hpp F_TTADD / F_TTMUL) */
 void orc_add(const float *a, const float *b, float *y, int n) { for (int i = 0; i < n; ++i) y[i] = a[i] + b[i]; }
 void orc_mul(const float *a, const float *b, float *y, int n) { for (int i = 0; i < n; ++i) y[i] = a[i] * b[i]; }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * A7, eager-attention form of F_MM: gemm_fp32 / gemm_fp32_fp16 (compute/GemmFp.hpp:104-150, :233-283, x86 path) as CPUmmFunction::execute calls it per (batch, head) on
+ * BHSD operands (op/CPUMatmulFunc.hpp:155-172; C is zeroed first, :158).  A [M][K], B [K][N] (fp32, or fp16 when b16 != 0), C [M][N].
+ * The K axis goes in blocks of 256.  An 8 x 8 tile that is full (row block and column block both complete) runs the AVX micro-kernel: C is loaded, one fmadd per k, stored --
+ * over the K blocks that is ONE fma chain over all of K starting from 0.  Elements of edge tiles take the scalar path: per K block `sum = 0; sum += a * b` (contracted to an
+ * fma by the reference's build, -mfma with GCC's default -ffp-contract=fast) and `C += sum`.
+ * ---------------------------------------------------------------------------------------------------------- */
+void orc_gemm_fp32_bhsd(const float *a, const void *b, int b16, float *c, int heads, int M, int N, int K) {
+    const int mfull = M - M % 8, nfull = N - N % 8;
+    for (int h = 0; h < heads; ++h) {
+        const float *A = a + (size_t)h * M * K;
+        const float *B32 = (const float *)b + (size_t)h * K * N;
+        const uint16_t *B16 = (const uint16_t *)b + (size_t)h * K * N;
+        float *C = c + (size_t)h * M * N;
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < N; ++j) {
+                float acc = 0.0f;
+                if (i < mfull && j < nfull) {
+                    for (int k = 0; k < K; ++k) acc = fmaf(A[(size_t)i * K + k], b16 ? orc_f16_to_f32(B16[(size_t)k * N + j]) : B32[(size_t)k * N + j], acc);
+                } else {
+                    for (int k0 = 0; k0 < K; k0 += 256) {
+                        float sum = 0.0f;
+                        const int k1 = k0 + 256 < K ? k0 + 256 : K;
+                        for (int k = k0; k < k1; ++k) sum = fmaf(A[(size_t)i * K + k], b16 ? orc_f16_to_f32(B16[(size_t)k * N + j]) : B32[(size_t)k * N + j], sum);
+                        acc = acc + sum;
+                    }
+                }
+                C[(size_t)i * N + j] = acc;
+            }
+    }
+}

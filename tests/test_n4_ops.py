@@ -202,3 +202,52 @@ def test_hip_moe_block_matches_the_reference_module():
     bpath = weights.moe_file(big)
     x = synth.moe_input(big, 300, seed=5)
     assert np.array_equal(run(big, bpath, x), om.moe_block(om.Weights(bpath), big, x))
+
+
+# ---- A7, the eager-attention form of F_MM (CPUMatmulFunc.hpp:155-172 -> compute/GemmFp.hpp:104-150): tests/golden/mm_bhsd.npz is the reference's own Tensor::mm on BHSD tensors ----
+MM_CASES = ("qk", "pv", "long", "full", "deep")
+
+
+def test_gemm_fp32_bhsd_restatement_matches_the_reference():
+    """oracle.gemm_fp32_bhsd against Tensor::mm on BHSD operands as the reference computes it: q k^T and p v shapes whose rows and columns do not fill the 8 x 8 micro-kernel
+    (full tiles: one fma chain over K; edge tiles: per-256-block partial sums), K beyond one block on both kinds of tile."""
+    from oracle import oracle as orc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mm_bhsd.npz"))
+    for n in MM_CASES:
+        c = orc.gemm_fp32_bhsd(g[n + "_a"], g[n + "_b"])
+        assert np.array_equal(c, g[n + "_y"]), n
+    # the split matters: one chain over all of K differs from block partial sums on the deep edge case
+    a, b = g["deep_a"], g["deep_b"]
+    H, M, K = a.shape
+    N = b.shape[2]
+    pad_a = np.concatenate([a, np.zeros((H, 1, K), np.float32)], axis=1)          # one more row: M = 25 turns rows 24.. into an edge tile, rows 0..23 stay full
+    assert np.array_equal(orc.gemm_fp32_bhsd(pad_a, b)[:, :M], g["deep_y"])
+
+
+def test_gemm_f32_bhsd_argument_checks():
+    from mllm_amd import lib
+    L = lib.load()
+    P = C.c_void_p(0x1000)
+    assert L.mllm_hip_gemm_f32_bhsd(P, P, C.c_int(lib.Q4_K), P, C.c_int(1), C.c_int(4), C.c_int(4), C.c_int(4), None) == lib.ERR_DTYPE
+    assert L.mllm_hip_gemm_f32_bhsd(P, P, C.c_int(lib.F32), P, C.c_int(1), C.c_int(4), C.c_int(4), C.c_int(0), None) == lib.ERR_SHAPE
+    assert L.mllm_hip_gemm_f32_bhsd(P, P, C.c_int(lib.F32), P, C.c_int(0), C.c_int(4), C.c_int(4), C.c_int(4), None) == lib.OK
+    assert L.mllm_hip_gemm_f32_bhsd(P, None, C.c_int(lib.F32), P, C.c_int(1), C.c_int(4), C.c_int(4), C.c_int(4), None) == lib.ERR_ARG
+
+
+@pytest.mark.gpu
+def test_hip_gemm_f32_bhsd_matches_the_reference():
+    """mllm_hip_gemm_f32_bhsd against the reference's Tensor::mm on BHSD tensors (tests/golden/mm_bhsd.npz), every bit; then an attention-sized pair (12 heads, 300 x 300 x 128
+    and 300 x 128 x 300) with fp32 and with fp16 right operands (gemm_fp32_fp16: the fp16 K/V cache of the eager branch) against the restatement."""
+    from mllm_amd import ops
+    from oracle import oracle as orc
+    ops.require_gpu()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mm_bhsd.npz"))
+    for n in MM_CASES:
+        assert np.array_equal(ops.gemm_f32_bhsd(g[n + "_a"], g[n + "_b"]).cpu().numpy(), g[n + "_y"]), n
+    r = np.random.default_rng(77)
+    for (H, M, N, K) in ((12, 300, 300, 128), (12, 300, 128, 300), (2, 1, 555, 128)):
+        a = r.standard_normal((H, M, K), dtype=np.float32)
+        b = r.standard_normal((H, K, N), dtype=np.float32)
+        assert np.array_equal(ops.gemm_f32_bhsd(a, b).cpu().numpy(), orc.gemm_fp32_bhsd(a, b)), (H, M, N, K)
+        b16 = b.astype(np.float16)
+        assert np.array_equal(ops.gemm_f32_bhsd(a, b16).cpu().numpy(), orc.gemm_fp32_bhsd(a, b16)), (H, M, N, K, "f16")
