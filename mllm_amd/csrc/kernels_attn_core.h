@@ -635,7 +635,7 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
     static_assert(NP >= 2, "the pipeline needs at least two producer waves");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float scale = 1.0f / sqrtf((float)D);
-    const int nkv = Sk - 1;                                  // keys whose value comes from the slab; the appended token (key Sk - 1) is walked from vnew
+    // (every key's value, the appended token's included, is met inside its block: the producers patch vnew into the parked slice)
     const int nblkS = (Sk + FP_B - 1) / FP_B;                // blocks with scores
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -728,6 +728,8 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
             if (j < Sk) {
                 const float e = glibc_expf(((hf ? excl : s) - incl) * scale, L.etab);
                 (hf ? L.c : L.p)[j] = e;
+            } else {
+                (hf ? L.c : L.p)[j] = hf ? 1.0f : 0.0f;      // behind the last key: o * 1 and + 0 * v leave the walk's accumulators as they are, so every block is walked as a full one
             }
             unsigned long long mv = __ballot(moved && hf == 0);
             mv = (mv | (mv >> 1)) & 0x3333333333333333ull; mv = (mv | (mv >> 2)) & 0x0f0f0f0f0f0f0f0full; mv = (mv | (mv >> 4)) & 0x00ff00ff00ff00ffull;
@@ -739,6 +741,10 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
                 const int vi = lane + 64 * i;
                 if (vi < DV * G::ROWV) *reinterpret_cast<pipe_u32x4 *>(region + (size_t)(vi / G::ROWV) * G::VPITCH + (vi % G::ROWV) * 16) = R.v[i];
             }
+            // the appended token's value row is not in the slab yet (and another workgroup may be storing it right now): its column of the parked slice comes from vnew,
+            // so the walk meets it inside its block like any other key (c and p of key Sk - 1 are the reference's rescale-then-add of the new token)
+            if (tnew >= b * FP_B && tnew < (b + 1) * FP_B)
+                for (int d = lane; d < DV; d += 64) *reinterpret_cast<uint16_t *>(region + (size_t)d * G::VPITCH + 2 * (tnew - b * FP_B)) = vnew[d];
             // (s_waitcnt lgkmcnt(0) covers the whole wave's stores: the wave executes it as one instruction)
             if (lane == 0) lds_publish_u32(&L.rm[b].x, 1u);
             if (b == pw) { STAMPT(10, (NWK + 1) * 64); STAMPT(13, (NWK + 5) * 64); }
@@ -749,7 +755,7 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
         // instruction per six cycles whatever its kind, so the walk is priced by instructions per key -- per block: 32 fma, 13 LDS reads, one READY / moved-bits
         // check and the loop, instead of that per 16 keys.
         float o = 0.0f;
-        const int nblkV = (nkv + FP_B - 1) / FP_B;
+        const int nblkV = nblkS;      // every block is walked as a full one (p = 0, c = 1 behind the last key; the appended key's value patched into its block)
         struct Stage { u32x4 v[4]; f32x4 p[8]; uint32_t m; };
         Stage SA, SB;
         const bool active = tid < DV;
@@ -761,46 +767,6 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
 #pragma unroll
             for (int q4 = 0; q4 < 8; ++q4) S.p[q4] = *reinterpret_cast<const f32x4 *>(L.p + FP_B * b + 4 * q4);
             S.m = L.rm[b].y;
-        };
-        auto proc = [&](int b, const Stage &S) {
-            const uint32_t m32 = (uint32_t)__builtin_amdgcn_readfirstlane(S.m);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k0 = FP_B * b + 16 * h;
-                if (k0 >= nkv) break;
-                const unsigned w[8] = {S.v[2 * h][0], S.v[2 * h][1], S.v[2 * h][2], S.v[2 * h][3], S.v[2 * h + 1][0], S.v[2 * h + 1][1], S.v[2 * h + 1][2], S.v[2 * h + 1][3]};
-                const int m16 = (int)((m32 >> (16 * h)) & 0xffff);
-                if (m16 == 0 && k0 + 16 <= nkv) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) o = __fmaf_rn(S.p[4 * h + (k >> 2)][k & 3], h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff))), o);
-                } else if (k0 + 16 <= nkv) {
-                    // some maximum moved inside these 16 keys: c is exactly 1.0f wherever it did not, so the rescale needs no select
-                    f32x4 cq[4];
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + k0 + 4 * q4);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        o = o * cq[k >> 2][k & 3];
-                        o = __fmaf_rn(S.p[4 * h + (k >> 2)][k & 3], h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff))), o);
-                    }
-                } else {
-                    f32x4 cq[4];
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + k0 + 4 * q4);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const bool in = k0 + k < nkv;            // keys past the end: c = 1, p = 0, v = 0
-                        const float vk = h2f((uint16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffff)));
-                        o = o * (in ? cq[k >> 2][k & 3] : 1.0f);
-                        o = __fmaf_rn(in ? S.p[4 * h + (k >> 2)][k & 3] : 0.0f, in ? vk : 0.0f, o);
-                    }
-                }
-            }
-            STAMPB(b);
-            if (nblkS > NP) {      // this wave has left the block: its region may be overwritten (only a cache of more than NP blocks reuses regions)
-                if (lane == 0) L.walked[wid] = (uint32_t)(b + 1);
-                asm volatile("" ::: "memory");
-            }
         };
         // Order inside an iteration: (1) this block's stage is waited for -- `landed` names its last-requested registers, and LDS returns a wave's reads in order --,
         // (2) the next block's reads are issued, (3) the 32-long chain runs on registers that need no further wait.  In the common case (no maximum moved inside the
@@ -815,11 +781,31 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
                 o = __fmaf_rn(S.p[k >> 2][k & 3], h2f((uint16_t)((k & 1) ? (wk >> 16) : (wk & 0xffff))), o);
             }
         };
+        // the chain of a block in which some maximum moved: per 16 keys either the plain chain or (rescale, fma) per key -- c is exactly 1.0f wherever the maximum did not move
+        auto rescaled = [&](const Stage &S, uint32_t m32, const f32x4 (&cq)[8]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (((m32 >> (16 * h)) & 0xffff) == 0) {
+#pragma unroll
+                    for (int k = 16 * h; k < 16 * h + 16; ++k) {
+                        const unsigned wk = S.v[k >> 3][(k >> 1) & 3];
+                        o = __fmaf_rn(S.p[k >> 2][k & 3], h2f((uint16_t)((k & 1) ? (wk >> 16) : (wk & 0xffff))), o);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 16 * h; k < 16 * h + 16; ++k) {
+                        const unsigned wk = S.v[k >> 3][(k >> 1) & 3];
+                        o = o * cq[k >> 2][k & 3];
+                        o = __fmaf_rn(S.p[k >> 2][k & 3], h2f((uint16_t)((k & 1) ? (wk >> 16) : (wk & 0xffff))), o);
+                    }
+                }
+            }
+        };
         auto turn = [&](int b, const Stage &Scur, Stage &Snext) {      // block b is in Scur; block b + 1 exists and goes to Snext
             landed(Scur);
             ensure(b + 1);
             const uint32_t m32 = (uint32_t)__builtin_amdgcn_readfirstlane(Scur.m);
-            if (m32 == 0 && FP_B * (b + 1) <= nkv) {
+            if (m32 == 0) {
                 rd(b + 1, Snext);
                 chain32(Scur);
 #pragma unroll
@@ -831,28 +817,41 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
                 L.walked[wid] = (uint32_t)(b + 1);      // every lane stores the same word: neither a uniform branch nor an EXEC write (both are scheduling boundaries
                                                         // and would cut the block the interleave lives in)
             } else {
-                asm volatile("" ::: "memory");      // keeps the two arms from sharing a prefix: the common arm's reads must stay inside its block to be interleaved
+                // some maximum moved: the block's 32 c values and the next block's stage are requested together (21 reads, issued while the first of them travel).  (The
+                // first form read c behind the next block's 13 reads and once per half, each time waiting out the LDS latency: 0.5 us per such block against 0.2.)
+                asm volatile("" ::: "memory");      // keeps the arms from sharing a prefix: the common arm's reads must stay inside its block to be interleaved
+                f32x4 cq[8];
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + FP_B * b + 4 * q4);
                 rd(b + 1, Snext);
-                proc(b, Scur);
+                rescaled(Scur, m32, cq);
+                STAMPB(b);
+                L.walked[wid] = (uint32_t)(b + 1);
             }
         };
-        if (nblkV > 0) { ensure(0); rd(0, SA); }
+        auto last = [&](int b, const Stage &S) {      // the final block: nothing to request behind it
+            landed(S);
+            const uint32_t m32 = (uint32_t)__builtin_amdgcn_readfirstlane(S.m);
+            if (m32 == 0) chain32(S);
+            else {
+                f32x4 cq[8];
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + FP_B * b + 4 * q4);
+                rescaled(S, m32, cq);
+            }
+            STAMPB(b);
+        };
+        ensure(0);
+        rd(0, SA);
         STAMP(2);
         int b = 0;
         for (; b + 2 < nblkV; b += 2) {
             turn(b, SA, SB);
             turn(b + 1, SB, SA);
         }
-        if (b + 1 < nblkV) { turn(b, SA, SB); landed(SB); proc(b + 1, SB); }
-        else if (b < nblkV) { landed(SA); proc(b, SA); }
+        if (b + 1 < nblkV) { turn(b, SA, SB); last(b + 1, SB); }
+        else last(b, SA);
         STAMP(3);
-        if (vnew) {   // the appended token: rescale (always a multiply in the reference), then its value row
-            ensure(nblkS - 1);
-            if (active) {
-                o = o * L.c[Sk - 1];
-                o = __fmaf_rn(L.p[Sk - 1], h2f(vnew[tid]), o);
-            }
-        }
         if (active) L.ob[tid] = o;
     } else if (lane == 0) {
         // ---------------------------------------------------------------- logsum lane --------------------------------------------------------------
@@ -866,30 +865,22 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
             S.m = L.rm[b].y;
         };
         auto landed = [&](const SStage &S) { asm volatile("" : : "v"(S.p[7]), "v"(S.m) : "memory"); };
-        auto general = [&](int b, const SStage &S) {
-            const int j0 = FP_B * b, ns = min(FP_B, Sk - j0);
+        auto rescaled = [&](const SStage &S, const f32x4 (&cq)[8]) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (16 * h >= ns) break;
-                if (((S.m >> (16 * h)) & 0xffff) == 0 && 16 * h + 16 <= ns) {
+                if (((S.m >> (16 * h)) & 0xffff) == 0) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) lsum = lsum + S.p[4 * h + (k >> 2)][k & 3];
+                    for (int k = 16 * h; k < 16 * h + 16; ++k) lsum = lsum + S.p[k >> 2][k & 3];
                 } else {
-                    f32x4 cq[4];
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + j0 + 16 * h + 4 * q4);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const bool in = 16 * h + k < ns;
-                        lsum = __fmaf_rn(lsum, in ? cq[k >> 2][k & 3] : 1.0f, in ? S.p[4 * h + (k >> 2)][k & 3] : 0.0f);
-                    }
+                    for (int k = 16 * h; k < 16 * h + 16; ++k) lsum = __fmaf_rn(lsum, cq[k >> 2][k & 3], S.p[k >> 2][k & 3]);
                 }
             }
         };
         auto turn = [&](int b, const SStage &Scur, SStage &Snext) {      // block b is in Scur; block b + 1 exists and goes to Snext
             landed(Scur);
             ensure(b + 1);
-            if (Scur.m == 0 && FP_B * (b + 1) <= Sk) {
+            if (Scur.m == 0) {
                 rd(b + 1, Snext);
 #pragma unroll
                 for (int k = 0; k < 32; ++k) lsum = lsum + Scur.p[k >> 2][k & 3];
@@ -898,10 +889,25 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
                     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-            } else {
+            } else {      // some maximum moved: the block's c values and the next stage requested together (see the walker)
                 asm volatile("" ::: "memory");
+                f32x4 cq[8];
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + FP_B * b + 4 * q4);
                 rd(b + 1, Snext);
-                general(b, Scur);
+                rescaled(Scur, cq);
+            }
+        };
+        auto last = [&](int b, const SStage &S) {
+            landed(S);
+            if (S.m == 0) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) lsum = lsum + S.p[k >> 2][k & 3];
+            } else {
+                f32x4 cq[8];
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + FP_B * b + 4 * q4);
+                rescaled(S, cq);
             }
         };
         ensure(0);
@@ -911,8 +917,8 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
             turn(b, A, B);
             turn(b + 1, B, A);
         }
-        if (b + 1 < nblkS) { turn(b, A, B); landed(B); general(b + 1, B); }
-        else { landed(A); general(b, A); }
+        if (b + 1 < nblkS) { turn(b, A, B); last(b + 1, B); }
+        else last(b, A);
         *L.lsum = lsum;
         STAMPT(7, NWK * 64);
     }
