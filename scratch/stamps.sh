@@ -2,7 +2,7 @@
 # diagnostic build with in-kernel stamps into a scratch .so (never the production library); extra -D flags via $1
 set -e
 cd "$(dirname "$0")/../mllm_amd/csrc"
-mkdir -p /tmp/stampobj
+rm -rf /tmp/stampobj; mkdir -p /tmp/stampobj
 for f in runtime kernels_elem kernels_linear kernels_attn kernels_decode kernels_sample kernels_image kernels_n4 moe engine; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DMLLM_HIP_STAMPS $1 -c $f.hip -o /tmp/stampobj/$f.o &
 done
