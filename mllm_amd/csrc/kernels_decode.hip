@@ -44,8 +44,10 @@ namespace mllm_hip {
 #endif
 constexpr bool g_nt = MLLM_HIP_NT != 0;
 
-#ifdef MLLM_HIP_STAMPS
+#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB)
 __device__ unsigned long long g_stamps[8192 * 16];
+#endif
+#ifdef MLLM_HIP_STAMPS
 #define STAMP(i)                                                                                         \
     do {                                                                                                 \
         if (threadIdx.x == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 8192) {                                                     \
@@ -84,6 +86,12 @@ __device__ unsigned long long g_stamps[8192 * 16];
 #define STAMPV(i, v)
 #define STAMPT(i, t)
 #define STAMPB(i)
+#endif
+// stamps of the gate|up GEMV only (diagnostic build with -DMLLM_HIP_STAMPS_GUB: scratch/stamps_gub.py); the attention's stamps stay silent in that build
+#if defined(MLLM_HIP_STAMPS_GUB)
+#define GSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) mllm_hip::g_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GSTAMP(i)
 #endif
 }  // namespace mllm_hip
 #include "q4k_dot.h"
@@ -504,6 +512,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
     float2 *tab = reinterpret_cast<float2 *>(stage + 2 * half);
     float *outv = reinterpret_cast<float *>(stage + 2 * half + (size_t)2 * PAIRS * nb * Q4K_SLOTS * 8);
     float4 xv[NV], wv[NV];
+    GSTAMP(0);
     load_rows2<NV, WPB>(xv, wv, x, norm_w, K);
     __builtin_amdgcn_sched_barrier(0);
 #if MLLM_HIP_GUB_DMA_FIRST
@@ -522,7 +531,12 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
     }
     __builtin_amdgcn_sched_barrier(0);
 #endif
+#if defined(MLLM_HIP_STAMPS_GUB)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (diagnostic build: the activation row and, in the DMA-first order, the weight rows have landed)
+    GSTAMP(1);
+#endif
     wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
+    GSTAMP(2);
 #if !MLLM_HIP_GUB_DMA_FIRST
     // ---- the wave's rows: two contiguous runs of PAIRS * nb super-blocks -> LDS (global_load_lds_dwordx4, 1 KiB per instruction) ----------------
     const int run = PAIRS * nb * 144;
@@ -540,12 +554,14 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    GSTAMP(3);
     // ---- lane l: super-block (region = gate / up, pair, b) ------------------------------------------------------------------------------------
     const int region = lane >= PAIRS * nb, within = lane - (region ? PAIRS * nb : 0), pair = within / nb, b = within - pair * nb;
     if (live && lane < 2 * PAIRS * nb) {
         blk_emit(stage + (size_t)region * half + (size_t)within * 144, a, b, tab + ((size_t)(2 * pair + region) * nb + b) * Q4K_SLOTS);
     }
     wave_lds_fence();
+    GSTAMP(4);
 #pragma unroll
     for (int p = 0; p < 2 * PAIRS; p += 4) {
         const int nr = 2 * PAIRS - p < 4 ? 2 * PAIRS - p : 4;
@@ -553,10 +569,12 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
         if ((lane & 15) == 8 && (lane >> 4) < nr) outv[p + (lane >> 4)] = res;
     }
     wave_lds_fence();
+    GSTAMP(5);
     if (live && lane < PAIRS) {
         const float g = outv[2 * lane], u = outv[2 * lane + 1];
         act[p0 + lane] = (g / (1.0f + v_expf_dec(0.0f - g))) * u;   // mllm_v_silu then F_TTMUL
     }
+    GSTAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -991,7 +1009,7 @@ __global__ void dec_advance_kernel(DecodeState *state, const int *tok, int *hist
     state->T += 1;
     state->step += 1;
 }
-#ifdef MLLM_HIP_STAMPS
+#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB)
 }  // namespace mllm_hip
 extern "C" int mllm_hip_debug_read_stamps(unsigned long long *host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(mllm_hip::g_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
