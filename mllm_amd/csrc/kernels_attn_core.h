@@ -895,7 +895,14 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
 #pragma unroll
                 for (int q4 = 0; q4 < 8; ++q4) cq[q4] = *reinterpret_cast<const f32x4 *>(L.c + FP_B * b + 4 * q4);
                 rd(b + 1, Snext);
-                rescaled(Scur, cq);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) lsum = __fmaf_rn(lsum, cq[k >> 2][k & 3], Scur.p[k >> 2][k & 3]);      // c = 1.0f where nothing moved: lsum * 1 + p
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
         };
         auto last = [&](int b, const SStage &S) {
