@@ -276,85 +276,66 @@ __global__ __launch_bounds__(256) void norm_kernel(const float *__restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// A18 LayerNorm as ONE launch for rows of NCH * 256 values (the towers' 1024 / 1280): a workgroup takes four rows, wave r owns row r.
-// Every wave fetches its row into registers (NCH x 16 bytes per lane, all requests out at once; lane l holds values 4l..4l+3 of each 256-block -- the layout the Q8_K
-// quantiser and the GEMM operand packer want) and parks it in LDS; lanes 0..3 of wave 0 walk the rows' `sum += x[d]` chains (the reference's order: one lane per row),
-// the 16-byte LDS reads issued five ahead of their use, one per four links; the waves centre their rows from their registers (c = x - mean is order-free) and park them
-// again; wave 0 walks `ssq = fma(c, c, ssq)` the same way; then each wave normalises, quantises and packs its own row from its registers.
-// Against ln_stats_kernel + norm_kernel<true>: one launch instead of two, one read of x instead of two, 256 workgroups instead of 64.  What bounds it is the walk: a lone
-// wave's dependent add issues every 6.6 cycles and every instruction placed between two links (a read, a counted wait) costs its own issue on top -- 12 cycles per link
-// measured.  Tried and slower: the chain on a wave-uniform accumulator fed by `v_readlane_b32` from the row's registers (no LDS, no barrier, 2 instructions per link):
-// 23.8 us against 19.7.
+// A18 LayerNorm as ONE launch for rows of NCH * 256 values (the towers' 1024 / 1280): a wave owns a row from fetch to packed GEMM operand -- no LDS, no barrier.
+// The wave fetches its row into registers (NCH x 16 bytes per lane, all requests out at once; lane l holds values 4l..4l+3 of each 256-block -- the layout the Q8_K
+// quantiser and the GEMM operand packer want) and, through its own strip of LDS, a second copy in the walk layout: lane l holds the 4 NCH CONSECUTIVE values behind
+// 4 NCH l.  The reference's `sum += x[d]` is one chain over the row in index order.  Here the accumulator TRAVELS: a hop moves all lanes' accumulators one lane up
+// (`v_mov_b32_dpp wave_ror:1`), then every lane adds its own values, so after hop h lane h holds exactly the reference's partial sum through its last value (what the other
+// lanes compute meanwhile is overwritten by what arrives) and after 64 hops lane 63 holds the row's.  One dependent instruction per value plus one hop per 4 NCH values, no
+// LDS read and no wait in the chain's way.  `ssq = fma(c, c, ssq)` the same way.  Then the wave normalises, quantises and packs its row from its registers.
+// Measured on the tower's 1024 x 1280 rows: ln_stats_kernel + norm_kernel<true> 25.2 us; this kernel with lanes 0..3 of one wave walking four LDS-parked rows (reads five
+// ahead, one per four links) 19.7 us; with a wave-uniform chain fed by `v_readlane_b32` 23.8 us; the travelling accumulator hopping every four values (the pack layout,
+// no LDS at all) 17.6 us -- a wave-wide DPP hop costs about three plain links --; this form 15.7 us: 2,560 links at 9.6 cycles, against about 8 for a bare dependent fp32 add.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int LNF_ROWS = 4;
-typedef float lnf_f32x4 __attribute__((ext_vector_type(4)));
-__host__ __device__ constexpr size_t lnf_lds_bytes(int dim) { return ((size_t)LNF_ROWS * (dim + 4) + 32) * sizeof(float); }
-template <bool SQ>
-__device__ __forceinline__ float lnf_step(float acc, const lnf_f32x4 (&cur)[4], lnf_f32x4 (&nxt)[4], const float *nxt_src) {
-    // 16 chain links on `cur`, the four reads of `nxt` placed one per four links
+constexpr int LNF_ROWS = 4;      // waves per workgroup (nothing is shared between them)
+constexpr int DPP_WAVE_ROR1 = 0x13C;
+// one pass over the row in the walk layout (lane l holds values 4 NCH l .. 4 NCH l + 4 NCH - 1): 64 hops, each the hop itself plus 4 NCH dependent links
+template <int NCH, bool SQ>
+__device__ __forceinline__ float lnf_walk(const float4 (&u)[NCH]) {
+    float acc = 0.0f;      // lane 63's zero is what lane 0 takes in on the first hop
+#pragma unroll 4      // (one hop per trip: 17.0 us, four: 15.7, sixteen: 15.6)
+    for (int h = 0; h < 64; ++h) {
+        acc = MH_DPPF(0.0f, acc, DPP_WAVE_ROR1, 0xF);      // lane l + 1 takes lane l's accumulator, lane 0 lane 63's
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        nxt[q] = *reinterpret_cast<const lnf_f32x4 *>(nxt_src + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = SQ ? __fmaf_rn(cur[q][e], cur[q][e], acc) : __fadd_rn(acc, cur[q][e]);
+        for (int j = 0; j < NCH; ++j) {
+            if (SQ) { acc = __fmaf_rn(u[j].x, u[j].x, acc); acc = __fmaf_rn(u[j].y, u[j].y, acc); acc = __fmaf_rn(u[j].z, u[j].z, acc); acc = __fmaf_rn(u[j].w, u[j].w, acc); }
+            else { acc = __fadd_rn(acc, u[j].x); acc = __fadd_rn(acc, u[j].y); acc = __fadd_rn(acc, u[j].z); acc = __fadd_rn(acc, u[j].w); }
+        }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // four VALU
-    }
-    return acc;
-}
-template <bool SQ>
-__device__ __forceinline__ float lnf_walk(const float *rp, int dim) {
-    // rp: the lane's row in LDS (16-byte aligned); reads run one step (16 values) ahead and over-read 16 values behind the row (slack the caller provides)
-    float acc = 0.0f;
-    lnf_f32x4 A[4], B[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) A[q] = *reinterpret_cast<const lnf_f32x4 *>(rp + 4 * q);
-    for (int k = 0; k < dim; k += 32) {
-        acc = lnf_step<SQ>(acc, A, B, rp + k + 16);
-        acc = lnf_step<SQ>(acc, B, A, rp + k + 32);
-    }
-    return acc;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
 }
 template <int NCH>
 __global__ __launch_bounds__(64 * LNF_ROWS) void ln_fused_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ y,
                                                                  int8_t *__restrict__ qs, float *__restrict__ qd, int16_t *__restrict__ bsums, uint8_t *__restrict__ pack,
                                                                  int M, float eps) {
-    constexpr int dim = NCH * 256, pitch = dim + 4;
+    constexpr int dim = NCH * 256;
     extern __shared__ __attribute__((aligned(16))) char lnf_smem[];
-    float *rows = reinterpret_cast<float *>(lnf_smem);
-    float *mean_s = rows + LNF_ROWS * pitch + 16, *std_s = mean_s + LNF_ROWS;      // behind the 16 floats of over-read slack
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = blockIdx.x * LNF_ROWS + wid;
     const size_t tb = pack ? q4kp_tile_blocks(M, NCH) : 0;
-    if (blockIdx.x * LNF_ROWS >= M) {      // padding rows of the last 32-row tile of the packed operand: zeros
+    if (row >= M) {      // padding rows of the last 32-row tile of the packed operand: zeros
         if (pack)
             for (int blk = 0; blk < NCH; ++blk) wave_quant_pack(make_float4(0, 0, 0, 0), lane, false, pack, tb, NCH, row, blk);
         return;
     }
-    const bool live = row < M;
-    const float *xr = x + (int64_t)min(row, M - 1) * dim;
-    float4 v[NCH];
+    const float *xr = x + (int64_t)row * dim;
+    float4 v[NCH], u[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) v[c] = *reinterpret_cast<const float4 *>(xr + c * 256 + lane * 4);
-    float *mine = rows + wid * pitch;
+    // the same row once more in the walk layout, through the wave's own LDS strip (only this wave touches it: no barrier, the wave's LDS operations complete in order)
+    float *mine = reinterpret_cast<float *>(lnf_smem) + wid * dim;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4 *>(mine + c * 256 + lane * 4) = v[c];
-    __syncthreads();
-    const float *rp = rows + (lane & (LNF_ROWS - 1)) * pitch;
-    if (wid == 0 && lane < LNF_ROWS) mean_s[lane] = lnf_walk<false>(rp, dim) / (float)dim;
-    __syncthreads();
-    const float mean = mean_s[wid];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own stores have completed; nothing may be moved across
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) u[j] = *reinterpret_cast<const float4 *>(mine + 4 * NCH * lane + 4 * j);
+    const float mean = lnf_walk<NCH, false>(u) / (float)dim;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         v[c].x = __fsub_rn(v[c].x, mean); v[c].y = __fsub_rn(v[c].y, mean); v[c].z = __fsub_rn(v[c].z, mean); v[c].w = __fsub_rn(v[c].w, mean);
-        *reinterpret_cast<float4 *>(mine + c * 256 + lane * 4) = v[c];
+        u[c].x = __fsub_rn(u[c].x, mean); u[c].y = __fsub_rn(u[c].y, mean); u[c].z = __fsub_rn(u[c].z, mean); u[c].w = __fsub_rn(u[c].w, mean);
     }
-    __syncthreads();
-    if (wid == 0 && lane < LNF_ROWS) std_s[lane] = sqrtf(lnf_walk<true>(rp, dim) / (float)dim + eps);
-    __syncthreads();
-    const float sd = std_s[wid];
+    const float sd = sqrtf(lnf_walk<NCH, true>(u) / (float)dim + eps);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int d0 = c * 256 + lane * 4;
@@ -368,7 +349,6 @@ __global__ __launch_bounds__(64 * LNF_ROWS) void ln_fused_kernel(const float *__
             const float4 bb = *reinterpret_cast<const float4 *>(b + d0);
             o.x = __fadd_rn(o.x, bb.x); o.y = __fadd_rn(o.y, bb.y); o.z = __fadd_rn(o.z, bb.z); o.w = __fadd_rn(o.w, bb.w);
         }
-        if (!live) { if (pack) wave_quant_pack(make_float4(0, 0, 0, 0), lane, false, pack, tb, NCH, row, c); continue; }
         if (y) *reinterpret_cast<float4 *>(y + (int64_t)row * dim + d0) = o;
         if (qs) {
             const int64_t gblk = (int64_t)row * NCH + c;
@@ -726,7 +706,7 @@ static int layernorm_impl(const float *x, const float *w, const float *b, float 
     if (dim % 256 == 0 && dim / 256 <= 8 && option(OPT_NO_LNF) <= 0) {      // rows of 256 .. 2048 values: the whole op in one launch
         const int rows = pack ? (M + 31) & ~31 : M;
         const dim3 grid((rows + LNF_ROWS - 1) / LNF_ROWS), block(64 * LNF_ROWS);
-        const size_t lds = lnf_lds_bytes(dim);
+        const size_t lds = (size_t)LNF_ROWS * dim * sizeof(float);
 #define LNF_CASE(N) case N: hipLaunchKernelGGL(ln_fused_kernel<N>, grid, block, lds, as_stream(stream), x, w, b, y, qs, d, bsums, pack, M, eps); break;
         switch (dim / 256) { LNF_CASE(1) LNF_CASE(2) LNF_CASE(3) LNF_CASE(4) LNF_CASE(5) LNF_CASE(6) LNF_CASE(7) LNF_CASE(8) }
 #undef LNF_CASE
