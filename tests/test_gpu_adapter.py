@@ -68,3 +68,34 @@ def test_reference_module_text_only_prompt(tiny, tiny_gold, tmp_path):
     assert report["cpu_fallback_ops"] == 0, report
     assert toks.tolist() == g["tokens_text"].tolist()
     assert np.array_equal(logits, g["logits_text"]), float(np.max(np.abs(logits - g["logits_text"])))
+
+
+def test_reference_module_at_the_2b_geometry(tmp_path):
+    """The same, at BASELINE's geometry: the reference's Qwen2VLModel (28 layers, hidden 1536, 32 vision blocks) on the Q4_K file through the adapter, 448 x 448 image + 24 tokens
+    prefilled, 64 decode steps: ids equal the reference's CPU run (tests/golden/qwen2vl_2b_ref.npz) and so do its sampled logits (top 64 + every 97th) at steps 0, 16, 32, 48, 64;
+    no Op falls back.  The driver's report carries the reference's own Module::profiling() numbers (25 ms TTFT, 163 tok/s on the first run: the frontend's per-Op host work,
+    630 Ops per token, is the time -- the resident engine behind the same C ABI does 1,118 tok/s)."""
+    if not os.path.exists(DRIVER):
+        pytest.skip("oracle/_ref/ref_hip_qwen2vl was not built (make -f oracle/Makefile.ref, container only)")
+    from mllm_amd import synth
+    from tests.fixtures import weights
+    cfg = synth.qwen2vl_2b()
+    path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "qwen2vl_2b_ref.npz"))
+    pix, grid, ids = synth.qwen2vl_inputs(cfg, (32, 32), 24)
+    steps = len(g["tokens"])
+    td = str(tmp_path)
+    ids.astype(np.int32).tofile(os.path.join(td, "ids.i32"))
+    pix.astype(np.float32).tofile(os.path.join(td, "pix.f32"))
+    cmd = [DRIVER, "--model", path, "--ids", os.path.join(td, "ids.i32"), "--steps", str(steps), "--threads", "4", "--out", td, "--cfg", _cfg_string(cfg), "--dump-every", "16",
+           "--pix", os.path.join(td, "pix.f32"), "--grid", ",".join(str(int(x)) for x in grid)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
+    report = json.loads(next(l for l in out.stdout.splitlines() if l.startswith('{"backend"')))
+    print("adapter report (2B):", report)
+    assert report["cpu_fallback_ops"] == 0 and report["refused"] == [], report
+    toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
+    assert toks.tolist() == g["tokens"].tolist()
+    for i, s in enumerate(g["steps"]):
+        lg = np.fromfile(os.path.join(td, f"logits_{int(s)}.f32"), dtype=np.float32)
+        assert np.array_equal(lg[g["top_idx"][i]], g["top_val"][i]) and np.array_equal(lg[::97], g["strided"][i]), int(s)
