@@ -50,15 +50,31 @@ void HIPBackend::release(const void *p) {
     for (auto s = shadows_.begin(); s != shadows_.end();) s = inside(s->first) ? shadows_.erase(s) : std::next(s);
     for (auto s = vision_.begin(); s != vision_.end();) s = inside(s->first) ? vision_.erase(s) : std::next(s);
     if (mrope_key_.pos && inside(mrope_key_.pos)) mrope_key_ = MropeKey();
-    if (it->second.pooled) check(mllm_hip_pool_free((void *)lo, stream_), "mllm_hip_pool_free");
-    else check(mllm_hip_free((void *)lo), "mllm_hip_free");
+    if (it->second.pooled) {
+        if (idle_bytes_ + it->second.size <= kIdleLimit) { idle_[it->second.size].push_back((void *)lo); idle_bytes_ += it->second.size; }
+        else check(mllm_hip_pool_free((void *)lo, stream_), "mllm_hip_pool_free");
+    } else check(mllm_hip_free((void *)lo), "mllm_hip_free");
     blocks_.erase(it);
 }
+void HIPBackend::drain_idle() {
+    for (auto &kv : idle_)
+        for (void *p : kv.second) (void)mllm_hip_pool_free(p, stream_);
+    idle_.clear();
+    idle_bytes_ = 0;
+}
+HIPBackend::~HIPBackend() { drain_idle(); }
 void HIPBackend::alloc_device(DeviceMemory &mem, DataType) {
     mem.type = MEM_TYPE_GENERIC;
     mem.handle = nullptr;
     if (mem.size_in_bytes == 0) return;      // the trace pass allocates shapeless placeholders (CPUBackend.cpp:318-349): nothing behind them
-    check(mllm_hip_pool_alloc(&mem.handle, mem.size_in_bytes, stream_), "mllm_hip_pool_alloc");
+    auto idle = idle_.find(mem.size_in_bytes);
+    if (idle != idle_.end() && !idle->second.empty()) {
+        mem.handle = idle->second.back();
+        idle->second.pop_back();
+        idle_bytes_ -= mem.size_in_bytes;
+    } else {
+        check(mllm_hip_pool_alloc(&mem.handle, mem.size_in_bytes, stream_), "mllm_hip_pool_alloc");
+    }
     blocks_[(uintptr_t)mem.handle] = Block{mem.size_in_bytes, 1, true};
 }
 void HIPBackend::free_device(DeviceMemory &mem) {

@@ -71,7 +71,7 @@ public:
     using OpCreator = std::function<Op *(HIPBackend *, const OpParam &, const std::string &)>;
 
     explicit HIPBackend(int device = 0);
-    ~HIPBackend() override = default;
+    ~HIPBackend() override;
 
     // ---- device memory (mllm/Backend.hpp:60-73): DeviceMemory{handle, MEM_TYPE_GENERIC, size_in_bytes} (mllm/TensorImpl.hpp:23-45) on a stream-ordered pool ----
     void alloc_device(DeviceMemory &mem, DataType dtype) override;
@@ -137,6 +137,12 @@ private:
     std::map<OpType, OpCreator> creators_;
     void *stream_ = nullptr;
     std::map<uintptr_t, Block> blocks_;
+    // activation blocks the frontend has released, kept by size: a decode step asks for the same few hundred sizes again, in the same order, on the same stream (reuse is
+    // stream-ordered like the pool's own), so the step's allocations cost a map lookup instead of a hipMallocAsync / hipFreeAsync pair each
+    std::unordered_map<size_t, std::vector<void *>> idle_;
+    size_t idle_bytes_ = 0;
+    static constexpr size_t kIdleLimit = (size_t)1 << 30;
+    void drain_idle();
     void *scratch_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes_[6] = {0, 0, 0, 0, 0, 0};
     void *lut_gelu_ = nullptr, *lut_qgelu_ = nullptr;
