@@ -210,6 +210,11 @@ int mllm_hip_store_f16(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, 
 /* same values, transposed: out[c * ldo + s].  The resident engine keeps its V slab as [Hkv*D][cache rows] so that the sequential
  * P.V walk of __fa2_decode (FlashAttention2.hpp:1075-1110) reads one dim's values contiguously in key order. */
 int mllm_hip_store_f16_t(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *stream);
+/* what sits between the fused q|k|v projection and the prefill attention, in one launch: rows [S][(Hq + 2 Hkv) D] fp32 -> q rotated in place, k rotated and stored as fp16 into
+ * k_rows[s * ldk + h * D + d] (the KVCache append, CPUKVCache.cpp:253-275), v stored as fp16 transposed into v_t[(h * D + d) * ldv + s]; the same arithmetic as
+ * mllm_hip_rope_apply (twice) + mllm_hip_store_f16_t, element for element */
+int mllm_hip_qkv_rope_append(float *qkv, int64_t ldq, const float *sin_t, const float *cos_t, int ld_tab, uint16_t *k_rows, int64_t ldk, uint16_t *v_t, int64_t ldv,
+                             int S, int Hq, int Hkv, int D, void *stream);
 
 /* ---- A13: flash_attention_2_forward (compute/FlashAttention2.hpp:2236-2284; fp16-KV impl :1212, fp32-KV impl :87).
  *      O = softmax(Q K^T / sqrt(D) + causal) V, GQA kv_head = q_head / (Hq/Hkv), causal offset Sk - Sq, fp32 accumulate.

@@ -864,9 +864,7 @@ static int forward_llm(M *m, int S, const float *pos3) {
         EH(q_rmsnorm(m, h, L.in_norm, m->xq, S, H, c.rms_eps));
         EH(lin(m, L.qkv, m->xq, m->qkv, MLLM_HIP_F32, m->QKV, nullptr, S));
         // q_rope in place; k_rope -> fp16 slab rows [T0, T0+S); v -> fp16 slab (KVCache zero-copy append)
-        EH(mllm_hip_rope_apply(m->qkv, m->QKV, m->rope_sin, m->rope_cos, half, m->qkv, MLLM_HIP_F32, m->QKV, S, c.heads, D, st));
-        EH(mllm_hip_rope_apply(m->qkv + m->HD, m->QKV, m->rope_sin, m->rope_cos, half, kl + (size_t)T0 * m->KVD, MLLM_HIP_F16, m->KVD, S, c.kv_heads, D, st));
-        EH(mllm_hip_store_f16_t(m->qkv + m->HD + m->KVD, m->QKV, vl + T0, m->vt_ld, S, m->KVD, st));
+        EH(mllm_hip_qkv_rope_append(m->qkv, m->QKV, m->rope_sin, m->rope_cos, half, kl + (size_t)T0 * m->KVD, m->KVD, vl + T0, m->vt_ld, S, c.heads, c.kv_heads, D, st));
         EH(mllm_hip_fa2_vt(m->qkv, m->QKV, kl, m->KVD, vl, m->vt_ld, m->attn, m->HD, S, T0 + S, c.heads, c.kv_heads, D, 1, st));
         EH(q_quant(m, m->attn, m->xq, S, m->HD));
         EH(lin(m, L.o, m->xq, h2, MLLM_HIP_F32, H, h, S));                          // tmp = o_proj(attn) + x

@@ -643,6 +643,31 @@ __global__ __launch_bounds__(256) void store_f16_t_kernel(const float *__restric
         out[(int64_t)c * ldo + s_] = f2h(x[(int64_t)s_ * ldx + c]);
     }
 }
+// the three steps between the fused q|k|v projection and the prefill attention in one launch: q rotated in place (fp32), k rotated into its fp16 slab rows (KVCache append,
+// CPUKVCache.cpp:253-275), v into the transposed fp16 slab -- the arithmetic of rope_apply_kernel / store_f16_t_kernel, element for element
+__global__ __launch_bounds__(256) void qkv_rope_append_kernel(float *__restrict__ qkv, int64_t ldq, const float *__restrict__ sin_t, const float *__restrict__ cos_t, int ld_tab,
+                                                              uint16_t *__restrict__ kout, int64_t ldk, uint16_t *__restrict__ vout, int64_t ldv, int S, int Hq, int Hkv, int D) {
+    const int half = D >> 1;
+    const int64_t nq = (int64_t)S * Hq * half, nk = (int64_t)S * Hkv * half, nv = (int64_t)S * Hkv * D;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nq + nk + nv; t += (int64_t)gridDim.x * 256) {
+        if (t < nq + nk) {
+            const bool isk = t >= nq;
+            const int64_t u = isk ? t - nq : t;
+            const int H = isk ? Hkv : Hq;
+            const int d = (int)(u % half), h = (int)((u / half) % H), s_ = (int)(u / ((int64_t)half * H));
+            float *x = qkv + (int64_t)s_ * ldq + (isk ? Hq * D : 0) + h * D + d;
+            const float a = x[0], b = x[half];
+            const float sv = sin_t[(int64_t)s_ * ld_tab + d], cv = cos_t[(int64_t)s_ * ld_tab + d];
+            const float v1 = __fmaf_rn(a, cv, -__fmul_rn(b, sv)), v2 = __fmaf_rn(a, sv, __fmul_rn(b, cv));
+            if (isk) { uint16_t *o = kout + (int64_t)s_ * ldk + h * D + d; o[0] = f2h(v1); o[half] = f2h(v2); }
+            else { x[0] = v1; x[half] = v2; }
+        } else {
+            const int64_t u = t - nq - nk;
+            const int c = (int)(u / S), s_ = (int)(u % S);
+            vout[(int64_t)c * ldv + s_] = f2h(qkv[(int64_t)s_ * ldq + (Hq + Hkv) * D + c]);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void store_f16_kernel(const float *__restrict__ x, int64_t ldx, uint16_t *__restrict__ out, int64_t ldo, int S, int n) {
     const int64_t total = (int64_t)S * n;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -897,6 +922,15 @@ extern "C" int mllm_hip_rope_apply(const float *x, int64_t ldx, const float *sin
         hipLaunchKernelGGL(rope_apply_kernel<false>, dim3(g), dim3(256), 0, as_stream(stream), x, ldx, sin_t, cos_t, ld_tab, out, ldo, S, H, D);
     else return MLLM_HIP_ERR_DTYPE;
     return MH_LAUNCH_OK("rope_apply");
+}
+extern "C" int mllm_hip_qkv_rope_append(float *qkv, int64_t ldq, const float *sin_t, const float *cos_t, int ld_tab, uint16_t *k_rows, int64_t ldk, uint16_t *v_t, int64_t ldv,
+                                       int S, int Hq, int Hkv, int D, void *stream) {
+    if (D <= 0 || D % 2 || Hq <= 0 || Hkv <= 0 || ldq < (int64_t)(Hq + 2 * Hkv) * D) return MLLM_HIP_ERR_SHAPE;
+    if (S <= 0) return MLLM_HIP_OK;
+    if (!qkv || !sin_t || !cos_t || !k_rows || !v_t) return MLLM_HIP_ERR_ARG;
+    const int64_t n = (int64_t)S * (Hq + Hkv) * (D / 2) + (int64_t)S * Hkv * D;
+    hipLaunchKernelGGL(qkv_rope_append_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), qkv, ldq, sin_t, cos_t, ld_tab, k_rows, ldk, v_t, ldv, S, Hq, Hkv, D);
+    return MH_LAUNCH_OK("qkv_rope_append");
 }
 extern "C" int mllm_hip_store_f16(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *stream) {
     if (S <= 0 || n <= 0) return MLLM_HIP_OK;

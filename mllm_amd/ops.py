@@ -227,6 +227,17 @@ def rope_apply(x, S, H, D, sin_t, cos_t, out_f16=False):
     return out
 
 
+def qkv_rope_append(qkv, S, Hq, Hkv, D, sin_t, cos_t, vt_ld):
+    """mllm_hip_qkv_rope_append on rows [S][(Hq + 2 Hkv) D]: returns (q rotated fp32 [S][Hq D], k fp16 [S][Hkv D], v fp16 transposed [Hkv D][vt_ld])."""
+    qkv, sin_t, cos_t = _dev(qkv, torch.float32).clone(), _dev(sin_t, torch.float32), _dev(cos_t, torch.float32)
+    W = (Hq + 2 * Hkv) * D
+    k = torch.zeros((S, Hkv * D), dtype=torch.float16, device="cuda")
+    vt = torch.zeros((Hkv * D, vt_ld), dtype=torch.float16, device="cuda")
+    check(L.load().mllm_hip_qkv_rope_append(vp(qkv), i64(W), vp(sin_t), vp(cos_t), C.c_int(sin_t.shape[-1]), vp(k), i64(Hkv * D), vp(vt), i64(vt_ld), C.c_int(S), C.c_int(Hq),
+                                            C.c_int(Hkv), C.c_int(D), _stream()), "qkv_rope_append")
+    return qkv[:, :Hq * D].contiguous(), k, vt
+
+
 def flash_attention2(q, k, v, Sq, Sk, Hq, Hkv, D, causal, sk_dev=None):
     """Tensor::flash_attention2_forward: q fp32 [Sq][Hq*D]; k, v fp16 or fp32 [Sk][Hkv*D]."""
     q = _dev(q, torch.float32)

@@ -233,6 +233,22 @@ def test_activations_bit_exact(ops_gold):
     assert eq(ops.quickgelu(x), orc.quickgelu(x))
 
 
+def test_qkv_rope_append_equals_the_separate_launches():
+    """mllm_hip_qkv_rope_append (q rotated in place, k rotated into fp16 rows, v into the transposed fp16 slab: one launch) against mllm_hip_rope_apply twice + the fp16 stores,
+    and against the restatement of the rotary, on a GQA shape with a ragged row count."""
+    r = rng(61)
+    S, Hq, Hkv, D = 37, 12, 2, 128
+    qkv = r.standard_normal((S, (Hq + 2 * Hkv) * D)).astype(np.float32)
+    sin_t, cos_t = orc.rope_table_hf(1000000.0, D, 64)
+    sin_t, cos_t = np.ascontiguousarray(sin_t[5:5 + S, :D // 2]), np.ascontiguousarray(cos_t[5:5 + S, :D // 2])
+    q, k, vt = ops.qkv_rope_append(qkv, S, Hq, Hkv, D, sin_t, cos_t, 64)
+    q_ref = ops.rope_apply(np.ascontiguousarray(qkv[:, :Hq * D]), S, Hq, D, sin_t, cos_t)
+    k_ref = ops.rope_apply(np.ascontiguousarray(qkv[:, Hq * D:(Hq + Hkv) * D]), S, Hkv, D, sin_t, cos_t, out_f16=True)
+    assert eq(q, q_ref.cpu().numpy()) and np.array_equal(k.cpu().numpy().view(np.uint16), k_ref.cpu().numpy().view(np.uint16))
+    v16 = qkv[:, (Hq + Hkv) * D:].astype(np.float16)
+    assert np.array_equal(vt.cpu().numpy()[:, :S].view(np.uint16), np.ascontiguousarray(v16.T).view(np.uint16)) and not vt.cpu().numpy()[:, S:].any()
+
+
 def test_silu_mul_add_mul_bit_exact():
     r = rng(10)
     gu = r.standard_normal((5, 2 * 8960)).astype(np.float32) * 2
