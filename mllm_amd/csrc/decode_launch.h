@@ -52,6 +52,7 @@ int decode_order_q4k(const void *src, void *dst, int64_t n_blocks, hipStream_t s
 int decode_attn_flags();
 int decode_warm_table(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, int flags, WeightWarm *host_out);
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st);
+int argmax_row_launch(const DecodeCtx &c, const float *logits, int n, int *out, hipStream_t st);      // first-maximum argmax over the chip, partials in c.part_val / c.part_idx
 int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st);
 
 }  // namespace mllm_hip

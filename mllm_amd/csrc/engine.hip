@@ -883,7 +883,7 @@ static int forward_llm(M *m, int S, const float *pos3) {
         EH(mllm_hip_rmsnorm(h + (size_t)(S - 1) * H, m->final_norm, nullptr, m->xq.qs, m->xq.d, m->xq.bs, 1, H, c.final_eps, 0, st));
         EH(mllm_hip_linear_q4k_q8k(m->head.w, nullptr, m->xq.qs, m->xq.d, m->xq.bs, m->logits, MLLM_HIP_F32, c.vocab, nullptr, 1, c.vocab, H, st));
     }
-    EH(mllm_hip_argmax(m->logits, c.vocab, m->tok_dev, st));
+    EH(argmax_row_launch(m->dctx, m->logits, c.vocab, m->tok_dev, st));
     m->cache_len = T0 + S;
     return 0;
 }

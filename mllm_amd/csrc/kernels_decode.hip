@@ -999,15 +999,45 @@ __global__ __launch_bounds__(256) void dec_next_kernel(DecodeState *__restrict__
         state->step += 1;
     }
 }
-__global__ void dec_advance_kernel(DecodeState *state, const int *tok, int *history, const float *tab_sin, const float *tab_cos, float *cur_sin,
-                                   float *cur_cos, int half, int max_rows) {
-    const int nxt = min(state->step + 1, max_rows - 1);
-    for (int i = 0; i < half; ++i) { cur_sin[i] = tab_sin[(int64_t)nxt * half + i]; cur_cos[i] = tab_cos[(int64_t)nxt * half + i]; }
-    const int t = *tok;
-    if (history) history[state->step] = t;
-    state->token = t;
-    state->T += 1;
-    state->step += 1;
+// first-maximum argmax of a row spread over the chip: workgroup b scans its slice and leaves (value, index); dec_next_kernel (decode) or argmax_final_kernel folds the
+// partials with the same tie rule (equal values: the smaller index).  The single-workgroup mllm_hip_argmax took 47 us on the 151,936 logits -- 7 % of a Qwen1.5-0.5B token.
+__global__ __launch_bounds__(256) void argmax_parts_kernel(const float *__restrict__ x, int n, float *__restrict__ part_val, int *__restrict__ part_idx) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int per = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + 3) & ~3;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) { const float v = x[i]; if (v > best) { best = v; besti = i; } }      // a thread's indices ascend: strict > keeps the first
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(besti, m, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        part_val[blockIdx.x] = best;
+        part_idx[blockIdx.x] = besti;
+    }
+}
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float *__restrict__ part_val, const int *__restrict__ part_idx, int nparts, int *__restrict__ out) {
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int i = threadIdx.x; i < nparts; i += 64) {
+        const float v = part_val[i];
+        const int ix = part_idx[i];
+        if (v > best || (v == best && ix < besti)) { best = v; besti = ix; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(besti, m, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (threadIdx.x == 0) *out = besti;
 }
 #if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB)
 }  // namespace mllm_hip
@@ -1268,6 +1298,26 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
     return MLLM_HIP_ERR_ARG;
 }
 
+// argmax of the logits row with the engine's partials scratch: nparts workgroups, then the fold (prefill: into *out; decode: dec_next_kernel folds and advances the state)
+static int argmax_parts_count(const DecodeCtx &c) { return std::max(1, std::min(c.max_parts, 128)); }
+int argmax_row_launch(const DecodeCtx &c, const float *logits, int n, int *out, hipStream_t st) {
+    const int np = argmax_parts_count(c);
+    hipLaunchKernelGGL(argmax_parts_kernel, dim3(np), dim3(256), 0, st, logits, n, c.part_val, c.part_idx);
+    int rc = MH_LAUNCH_OK("argmax_parts");
+    if (rc) return rc;
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(64), 0, st, c.part_val, c.part_idx, np, out);
+    return MH_LAUNCH_OK("argmax_final");
+}
+static int argmax_and_advance(const DecodeCtx &c, hipStream_t st) {
+    const int np = argmax_parts_count(c);
+    hipLaunchKernelGGL(argmax_parts_kernel, dim3(np), dim3(256), 0, st, c.logits, c.vocab, c.part_val, c.part_idx);
+    int rc = MH_LAUNCH_OK("argmax_parts");
+    if (rc) return rc;
+    hipLaunchKernelGGL(dec_next_kernel, dim3(1), dim3(256), 0, st, c.state, c.part_val, c.part_idx, np, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos, c.D / 2,
+                       c.cache_limit);
+    return MH_LAUNCH_OK("dec_next");
+}
+
 int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st) {
     float *x = c.x0;
     int rc = 0;
@@ -1279,10 +1329,8 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
     if (c.Whead) {
         // Linear lm_head (LLaMA-style models): model.norm -> Q8_K -> Q4_K rows, the same fused kernel as the q|k|v projection; then argmax
         NS_DISPATCH(c.H, rc = launch_norm_gemv<NS>(c, c.final_norm, c.final_eps, c.Whead, nullptr, c.vocab, false, x, x, c.logits, st));
-        if (!rc) rc = mllm_hip_argmax(c.logits, c.vocab, c.tok_dev, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, st, c.state, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos, c.D / 2, c.cache_limit);
-        return MH_LAUNCH_OK("dec_advance");
+        return argmax_and_advance(c, st);
     }
     // tied lm_head + argmax
     if (c.H % 512 != 0 || c.H / 512 > 8) {
@@ -1290,10 +1338,8 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
         rc = mllm_hip_rmsnorm(x, c.final_norm, c.normed, nullptr, nullptr, nullptr, 1, c.H, c.final_eps, 0, st);
         if (!rc) rc = mllm_hip_quantize_q80(c.normed, c.x80_qs, c.x80_d, 1, c.H, st);
         if (!rc) rc = mllm_hip_linear_q40_q80(c.emb_qs, c.emb_d, nullptr, c.x80_qs, c.x80_d, c.logits, c.vocab, 1, c.vocab, c.H, st);
-        if (!rc) rc = mllm_hip_argmax(c.logits, c.vocab, c.tok_dev, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, st, c.state, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos, c.D / 2, c.cache_limit);
-        return MH_LAUNCH_OK("dec_advance");
+        return argmax_and_advance(c, st);
     }
     const int head_wpc = option(OPT_HEAD_WPC) > 0 ? option(OPT_HEAD_WPC) : 8;   // waves per CU the row split aims at
     const int target_waves = 256 * head_wpc;
