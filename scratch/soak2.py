@@ -11,7 +11,7 @@ imgs = np.random.default_rng(1).standard_normal((6, 1024, cfg.patch_elems)).asty
 out = torch.empty((6 * 256, cfg.hidden), dtype=torch.float32, device='cuda')
 ref = refv = None
 t0 = time.time(); mem = None
-for it in range(8):
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     m.clear_kvcache()
     tok, _, _ = m.prefill(ids, pix, grid, want_logits=False)
     toks, _ = m.generate(tok, 500)
@@ -24,4 +24,4 @@ for it in range(8):
     free, total = torch.cuda.mem_get_info()
     if it == 4: mem = free
     if it > 4: assert abs(free - mem) < (64 << 20), ('device memory moved', free, mem)
-print('8 x (image prefill + 500 tokens + batched vision) identical, memory steady, %.1f s' % (time.time() - t0))
+print('%d x (image prefill + 500 tokens + batched vision) identical, memory steady, %.1f s' % (it + 1, time.time() - t0))
