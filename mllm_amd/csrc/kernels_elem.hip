@@ -46,6 +46,9 @@ __device__ __forceinline__ void wave_quant_q8k(float4 v, int lane, int8_t *qs_bl
 // sub-block half = (l >> 3) & 1, column class t = l & 7 -> 4 fp16 at fragment (t, p = j >> 1, h = j & 1), element half*4.
 // Rows m >= M of the last 32-row tile are written as zeros (live == false).
 typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
+#ifndef QP_WAVES
+#define QP_WAVES 8      // rows per workgroup of the quantise + pack launches (a 32-row tile is 4 workgroups)
+#endif
 __device__ __forceinline__ void wave_quant_pack(float4 v, int lane, bool live, uint8_t *pack, size_t tb, int nb, int m, int i) {
     float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
     float amax = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
@@ -78,12 +81,14 @@ __device__ __forceinline__ void wave_quant_pack(float4 v, int lane, bool live, u
     }
     if (lane == 0) *reinterpret_cast<float *>(pack + tb * (Q4KP_W_PER_BLK + Q4KP_M_PER_BLK) + (tile * 32 + mi) * 4) = dd;
 }
-__global__ __launch_bounds__(256) void quantize_q8k_pack_kernel(const float *__restrict__ x, uint8_t *__restrict__ pack, int M, int nb) {
+__global__ __launch_bounds__(64 * QP_WAVES) void quantize_q8k_pack_kernel(const float *__restrict__ x, uint8_t *__restrict__ pack, int M, int nb) {
     const int lane = threadIdx.x & 63;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t blk = (int64_t)blockIdx.x * QP_WAVES + (threadIdx.x >> 6);
     const int Mp = (M + 31) & ~31;
     if (blk >= (int64_t)Mp * nb) return;
-    const int m = (int)(blk / nb), i = (int)(blk % nb);
+    // the waves of a workgroup take CONSECUTIVE ROWS of one 256-block: in the packed operand a row owns 16 bytes of every 512-byte fragment row, so the
+    // workgroup's stores fill whole 64-byte lines together (with consecutive blocks of one row per workgroup every store touched a line of its own)
+    const int mi = (int)(blk & 31), i = (int)((blk >> 5) % nb), m = (int)((blk >> 5) / nb) * 32 + mi;
     const bool live = m < M;
     float4 v = make_float4(0, 0, 0, 0);
     if (live) v = reinterpret_cast<const float4 *>(x + ((int64_t)m * nb + i) * 256)[lane];
@@ -410,13 +415,13 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const float *__restrict__
 // computed in registers and quantised at once -- one launch and one fp32 round trip through HBM less per MLP.
 //   ACT 1: v = lut[f16(x)] (GELU / QuickGELU LUT, A18);  ACT 2: v = silu(gate) * up on a fused [M][2 K] gate|up row (A14 + F_TTMUL)
 template <int ACT>
-__global__ __launch_bounds__(256) void quantize_q8k_pack_act_kernel(const float *__restrict__ x, const uint16_t *__restrict__ lut, uint8_t *__restrict__ pack,
+__global__ __launch_bounds__(64 * QP_WAVES) void quantize_q8k_pack_act_kernel(const float *__restrict__ x, const uint16_t *__restrict__ lut, uint8_t *__restrict__ pack,
                                                                     int M, int nb) {
     const int lane = threadIdx.x & 63;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t blk = (int64_t)blockIdx.x * QP_WAVES + (threadIdx.x >> 6);
     const int Mp = (M + 31) & ~31;
     if (blk >= (int64_t)Mp * nb) return;
-    const int m = (int)(blk / nb), i = (int)(blk % nb);
+    const int mi = (int)(blk & 31), i = (int)((blk >> 5) % nb), m = (int)((blk >> 5) / nb) * 32 + mi;      // consecutive rows of one block per workgroup (see above)
     const bool live = m < M;
     float4 v = make_float4(0, 0, 0, 0);
     if (live) {
@@ -774,7 +779,7 @@ extern "C" int mllm_hip_quantize_q8k_packed(const float *x, void *xpack, int M, 
     if (M == 0) return MLLM_HIP_OK;
     const int nb = K / 256;
     const int64_t blocks = (int64_t)((M + 31) & ~31) * nb;
-    hipLaunchKernelGGL(quantize_q8k_pack_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, as_stream(stream), x, (uint8_t *)xpack, M, nb);
+    hipLaunchKernelGGL(quantize_q8k_pack_kernel, dim3((unsigned)((blocks + QP_WAVES - 1) / QP_WAVES)), dim3(64 * QP_WAVES), 0, as_stream(stream), x, (uint8_t *)xpack, M, nb);
     return MH_LAUNCH_OK("quantize_q8k_packed");
 }
 extern "C" int mllm_hip_quantize_q8k_packed_act(const float *x, const uint16_t *lut, void *xpack, int M, int K, void *stream) {
@@ -782,7 +787,7 @@ extern "C" int mllm_hip_quantize_q8k_packed_act(const float *x, const uint16_t *
     if (M == 0) return MLLM_HIP_OK;
     const int nb = K / 256;
     const int64_t blocks = (int64_t)((M + 31) & ~31) * nb;
-    hipLaunchKernelGGL(quantize_q8k_pack_act_kernel<1>, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, as_stream(stream), x, lut, (uint8_t *)xpack, M, nb);
+    hipLaunchKernelGGL(quantize_q8k_pack_act_kernel<1>, dim3((unsigned)((blocks + QP_WAVES - 1) / QP_WAVES)), dim3(64 * QP_WAVES), 0, as_stream(stream), x, lut, (uint8_t *)xpack, M, nb);
     return MH_LAUNCH_OK("quantize_q8k_packed_act");
 }
 extern "C" int mllm_hip_quantize_q8k_packed_silu_mul(const float *gu, void *xpack, int M, int I, void *stream) {
@@ -790,7 +795,7 @@ extern "C" int mllm_hip_quantize_q8k_packed_silu_mul(const float *gu, void *xpac
     if (M == 0) return MLLM_HIP_OK;
     const int nb = I / 256;
     const int64_t blocks = (int64_t)((M + 31) & ~31) * nb;
-    hipLaunchKernelGGL(quantize_q8k_pack_act_kernel<2>, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, as_stream(stream), gu, (const uint16_t *)nullptr, (uint8_t *)xpack, M, nb);
+    hipLaunchKernelGGL(quantize_q8k_pack_act_kernel<2>, dim3((unsigned)((blocks + QP_WAVES - 1) / QP_WAVES)), dim3(64 * QP_WAVES), 0, as_stream(stream), gu, (const uint16_t *)nullptr, (uint8_t *)xpack, M, nb);
     return MH_LAUNCH_OK("quantize_q8k_packed_silu_mul");
 }
 extern "C" int mllm_hip_debug_ln_stats(const float *x, float *stats, int M, int dim, float eps, void *stream) {
