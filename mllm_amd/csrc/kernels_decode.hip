@@ -999,46 +999,6 @@ __global__ __launch_bounds__(256) void dec_next_kernel(DecodeState *__restrict__
         state->step += 1;
     }
 }
-// first-maximum argmax of a row spread over the chip: workgroup b scans its slice and leaves (value, index); dec_next_kernel (decode) or argmax_final_kernel folds the
-// partials with the same tie rule (equal values: the smaller index).  The single-workgroup mllm_hip_argmax took 47 us on the 151,936 logits -- 7 % of a Qwen1.5-0.5B token.
-__global__ __launch_bounds__(256) void argmax_parts_kernel(const float *__restrict__ x, int n, float *__restrict__ part_val, int *__restrict__ part_idx) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
-    const int per = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + 3) & ~3;
-    const int lo = blockIdx.x * per, hi = min(n, lo + per);
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) { const float v = x[i]; if (v > best) { best = v; besti = i; } }      // a thread's indices ascend: strict > keeps the first
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(best, m, 64);
-        const int oi = __shfl_xor(besti, m, 64);
-        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-    }
-    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
-        part_val[blockIdx.x] = best;
-        part_idx[blockIdx.x] = besti;
-    }
-}
-__global__ __launch_bounds__(64) void argmax_final_kernel(const float *__restrict__ part_val, const int *__restrict__ part_idx, int nparts, int *__restrict__ out) {
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int i = threadIdx.x; i < nparts; i += 64) {
-        const float v = part_val[i];
-        const int ix = part_idx[i];
-        if (v > best || (v == best && ix < besti)) { best = v; besti = ix; }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(best, m, 64);
-        const int oi = __shfl_xor(besti, m, 64);
-        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-    }
-    if (threadIdx.x == 0) *out = besti;
-}
 #if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB)
 }  // namespace mllm_hip
 extern "C" int mllm_hip_debug_read_stamps(unsigned long long *host, int n) {
@@ -1302,16 +1262,12 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
 static int argmax_parts_count(const DecodeCtx &c) { return std::max(1, std::min(c.max_parts, 128)); }
 int argmax_row_launch(const DecodeCtx &c, const float *logits, int n, int *out, hipStream_t st) {
     const int np = argmax_parts_count(c);
-    hipLaunchKernelGGL(argmax_parts_kernel, dim3(np), dim3(256), 0, st, logits, n, c.part_val, c.part_idx);
-    int rc = MH_LAUNCH_OK("argmax_parts");
-    if (rc) return rc;
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(64), 0, st, c.part_val, c.part_idx, np, out);
-    return MH_LAUNCH_OK("argmax_final");
+    const int rc = argmax_parts_launch(logits, n, c.part_val, c.part_idx, np, st);
+    return rc ? rc : argmax_final_launch(c.part_val, c.part_idx, np, out, st);
 }
 static int argmax_and_advance(const DecodeCtx &c, hipStream_t st) {
     const int np = argmax_parts_count(c);
-    hipLaunchKernelGGL(argmax_parts_kernel, dim3(np), dim3(256), 0, st, c.logits, c.vocab, c.part_val, c.part_idx);
-    int rc = MH_LAUNCH_OK("argmax_parts");
+    int rc = argmax_parts_launch(c.logits, c.vocab, c.part_val, c.part_idx, np, st);
     if (rc) return rc;
     hipLaunchKernelGGL(dec_next_kernel, dim3(1), dim3(256), 0, st, c.state, c.part_val, c.part_idx, np, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos, c.D / 2,
                        c.cache_limit);

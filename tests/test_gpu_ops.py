@@ -270,6 +270,18 @@ def test_softmax_argmax_index_put(ops_gold):
     x = rng(12).standard_normal(151936).astype(np.float32)
     x[77] = x[150000] = 9.5                                   # tie: first index wins (std::max_element)
     assert ops.argmax(x) == 77
+    # the chip-wide form (rows of 16384 values and more): ties inside one workgroup's slice, across slices, a ragged last slice holding the maximum, a constant row
+    for n in (16384, 50001, 151936):
+        r = rng(200 + n % 97)
+        y = r.standard_normal(n).astype(np.float32)
+        assert ops.argmax(y) == int(np.argmax(y)), n
+        y[n - 1] = 11.0
+        assert ops.argmax(y) == n - 1, n
+        y[n // 2] = y[n // 2 + 3] = 11.0
+        assert ops.argmax(y) == n // 2, n
+        y[5] = 11.0
+        assert ops.argmax(y) == 5, n
+        assert ops.argmax(np.full(n, -3.5, dtype=np.float32)) == 0, n
     dst = rng(13).standard_normal((10, 64)).astype(np.float32)
     val = rng(14).standard_normal((3, 64)).astype(np.float32)
     out = ops.index_put_rows(dst, val, [7, 0, 4]).cpu().numpy()
