@@ -28,6 +28,8 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 // first-maximum argmax over the chip (kernels_elem.hip): nparts workgroups leave (value, index) partials, a fold picks the largest value and, among equals, the smallest index
 int argmax_parts_launch(const float *x, int n, float *part_val, int *part_idx, int nparts, hipStream_t st);
 int argmax_final_launch(const float *part_val, const int *part_idx, int nparts, int *out, hipStream_t st);
+// kernels_decode.hip: a whole M = 1 Linear on raw Q4_K rows in one launch; returns 1 when the shape is not covered
+int dec_linear_row_q4k(const void *Wraw, const float *x, const float *addend, float *y, int N, int K, hipStream_t st);
 enum Option { OPT_VISION_BATCH, OPT_TIME_LAYERS, OPT_NO_GUB, OPT_NO_PJB, OPT_PJB_MIN_NS, OPT_ATTN_FLAGS, OPT_ATTN_DS, OPT_HEAD_WPC, OPT_GEMM_ORDER, OPT_NO_LNF, OPT_COUNT };
 int option(Option o);
 

@@ -1097,7 +1097,7 @@ static int launch_proj(const uint8_t *W, const uint8_t *Wraw, const float *xin, 
     const int pjb_min_ns = option(OPT_PJB_MIN_NS) >= 0 ? option(OPT_PJB_MIN_NS) : 3;   // short rows: the 8-lane kernel is faster
     {
         const int nb = K >> 8;
-        const int rpw = std::max(1, std::min(512 / nb, (N + 255) / 256));
+        const int rpw = std::max(1, std::min(std::min(512 / nb, 32), (N + 255) / 256));
         if (NS >= pjb_min_ns && NS <= 5 && Wraw && !pjb_off && N >= rpw) {
             constexpr int BW = 8, NQ = NS;
             const size_t blds = pjb_lds_bytes(K, rpw);
@@ -1116,6 +1116,26 @@ static int launch_proj(const uint8_t *W, const uint8_t *Wraw, const float *xin, 
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, xin, W, residual, y, N, K);
     return MH_LAUNCH_OK("dec_proj");
+}
+
+// one activation row through a Linear with raw Q4_K rows in ONE launch (Q8_K of the row in the prologue, one lane per super-block, + addend[n] -- a bias or a residual):
+// what mllm_hip_linear uses for M == 1 instead of a quantiser launch and a GEMV launch.  Returns 1 when the shape is not covered (the caller keeps its two launches).
+int dec_linear_row_q4k(const void *Wraw, const float *x, const float *addend, float *y, int N, int K, hipStream_t st) {
+    if (K <= 0 || K % 256 || N <= 0) return 1;
+    const int nb = K >> 8, nsr = (nb + 7) / 8;
+    const int rpw = std::max(1, std::min(std::min(512 / nb, 32), (N + 255) / 256));      // eight waves walk four rows' chains each: at most 32 rows per workgroup
+    if (nsr > 5 || N < rpw) return 1;
+    const size_t lds = pjb_lds_bytes(K, rpw);
+#define ROW_CASE(NSV)                                                                                                                                     \
+    case NSV: {                                                                                                                                           \
+        auto bk = dec_proj_blk_kernel<8, NSV>;                                                                                                            \
+        const int rc = allow_lds(bk, lds);                                                                                                                \
+        if (rc) return rc;                                                                                                                                \
+        hipLaunchKernelGGL(bk, dim3((N + rpw - 1) / rpw), dim3(512), lds, st, x, (const uint8_t *)Wraw, addend, y, N, K, rpw);                            \
+    } break;
+    switch (nsr) { ROW_CASE(1) ROW_CASE(2) ROW_CASE(3) ROW_CASE(4) ROW_CASE(5) }
+#undef ROW_CASE
+    return MH_LAUNCH_OK("dec_proj_blk");
 }
 
 #define NS_DISPATCH(K, CALL)                           \

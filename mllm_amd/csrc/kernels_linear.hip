@@ -901,6 +901,10 @@ extern "C" int mllm_hip_linear(const void *W, int wdtype, const float *bias, con
         int8_t *qs = (int8_t *)ws;
         float *d = (float *)(ws + align256((size_t)M * K));
         int16_t *bs = (int16_t *)(ws + align256((size_t)M * K) + align256((size_t)M * (K / 256) * 4));
+        if (M == 1 && y_dtype == MLLM_HIP_F32) {      // one row: quantiser and GEMV in one launch (same arithmetic: the fused decode kernel)
+            const int one = dec_linear_row_q4k(W, x, bias, (float *)y, N, K, as_stream(stream));
+            if (one <= 0) return one;
+        }
         int rc = mllm_hip_quantize_q8k(x, qs, d, bs, M, K, stream);
         if (rc) return rc;
         return mllm_hip_linear_q4k_q8k(W, bias, qs, d, bs, y, y_dtype, ldy, nullptr, M, N, K, stream);

@@ -73,7 +73,7 @@ def test_reference_module_text_only_prompt(tiny, tiny_gold, tmp_path):
 def test_reference_module_at_the_2b_geometry(tmp_path):
     """The same, at BASELINE's geometry: the reference's Qwen2VLModel (28 layers, hidden 1536, 32 vision blocks) on the Q4_K file through the adapter, 448 x 448 image + 24 tokens
     prefilled, 64 decode steps: ids equal the reference's CPU run (tests/golden/qwen2vl_2b_ref.npz) and so do its sampled logits (top 64 + every 97th) at steps 0, 16, 32, 48, 64;
-    no Op falls back.  The driver's report carries the reference's own Module::profiling() numbers (21 ms TTFT, 373 tok/s: the frontend's per-Op host work, 630 Ops per token,
+    no Op falls back.  The driver's report carries the reference's own Module::profiling() numbers (21 ms TTFT, 466 tok/s: the frontend's per-Op host work, 630 Ops per token,
     is the time -- the resident engine behind the same C ABI does 1,118 tok/s)."""
     if not os.path.exists(DRIVER):
         pytest.skip("oracle/_ref/ref_hip_qwen2vl was not built (make -f oracle/Makefile.ref, container only)")

@@ -68,7 +68,9 @@ def _q4k_case(M, K, N, seed, bias=True):
     return quantlib.quantize(lib.Q4_K, W), x, b
 
 
-@pytest.mark.parametrize("M,K,N", [(1, 1536, 2048), (1, 8960, 1536), (1, 256, 64), (1, 1280, 3840), (3, 512, 96), (1, 11008, 128)])
+# M = 1 goes through the one-launch form (dec_linear_row_q4k: up to 32 rows per workgroup, the last workgroup re-doing rows of its neighbour); K beyond 10240 and M = 3 the two-launch one
+@pytest.mark.parametrize("M,K,N", [(1, 1536, 2048), (1, 8960, 1536), (1, 256, 64), (1, 1280, 3840), (3, 512, 96), (1, 11008, 128), (1, 1536, 8960), (1, 1536, 8950), (1, 512, 1000),
+                                   (1, 256, 8229), (1, 2560, 31), (1, 256, 1)])
 def test_linear_q4k_gemv_vs_oracle(M, K, N):
     Wq, x, b = _q4k_case(M, K, N, K + N)
     y = ops.linear_q4k(Wq, x, N, bias=b)
