@@ -706,10 +706,7 @@ static int vision_blocks(M *m, int N, int NB, float ln_eps, const uint16_t *lut,
         EH(q_layernorm(m, x, B.n1w, B.n1b, m->vxq, R, V, ln_eps));
         EH(lin(m, B.qkv, m->vxq, m->vqkv, MLLM_HIP_F32, 3 * V, nullptr, R));
         // q and k are columns [0, 2V) of the same rows: one launch over 2 * heads heads rotates both in place (per image: the table rows are its token positions)
-        for (int b = 0; rope && b < NB; ++b) {
-            float *qkv = m->vqkv + (size_t)b * N * 3 * V;
-            EH(mllm_hip_rope_apply(qkv, 3 * V, m->vsin, m->vcos, VD / 2, qkv, MLLM_HIP_F32, 3 * V, N, 2 * c.v_heads, VD, st));
-        }
+        if (rope) EH(rope_apply_periodic(m->vqkv, 3 * V, m->vsin, m->vcos, VD / 2, R, N, 2 * c.v_heads, VD, st));      // every image of the pass: row r takes table row r % N
         if (N >= 4) {
             EH(mllm_hip_fa2_batch(m->vqkv, 3 * V, m->vqkv + V, 3 * V, m->vqkv + 2 * V, 3 * V, MLLM_HIP_F32, m->vattn, V, N, N, c.v_heads, c.v_heads, VD, 0, NB,
                                   (int64_t)N * 3 * V, (int64_t)N * 3 * V, (int64_t)N * 3 * V, (int64_t)N * V, st));

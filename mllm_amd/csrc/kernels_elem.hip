@@ -665,15 +665,17 @@ __global__ __launch_bounds__(256) void repack_q40_kernel(const uint8_t *__restri
 // contraction turns `a*c - b*s` into fma(a, c, -(b*s)) and `a*s + b*c` into fma(a, s, b*c).
 template <bool OUT_F16>
 __global__ __launch_bounds__(256) void rope_apply_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ sin_t, const float *__restrict__ cos_t,
-                                                         int ld_tab, void *__restrict__ out, int64_t ldo, int S, int H, int D) {
+                                                         int ld_tab, void *__restrict__ out, int64_t ldo, int S, int H, int D, int period) {
+    // period > 0: row s takes table row s % period (the images of a vision pass share one table: one launch rotates them all)
     const int half = D >> 1;
     const int64_t total = (int64_t)S * H * half;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int d = (int)(t % half);
         const int h = (int)((t / half) % H);
         const int s = (int)(t / ((int64_t)half * H));
+        const int ts = period > 0 ? s % period : s;
         const float a = x[(int64_t)s * ldx + h * D + d], b = x[(int64_t)s * ldx + h * D + d + half];
-        const float sv = sin_t[(int64_t)s * ld_tab + d], cv = cos_t[(int64_t)s * ld_tab + d];
+        const float sv = sin_t[(int64_t)ts * ld_tab + d], cv = cos_t[(int64_t)ts * ld_tab + d];
         const float v1 = __fmaf_rn(a, cv, -__fmul_rn(b, sv));
         const float v2 = __fmaf_rn(a, sv, __fmul_rn(b, cv));
         const int64_t o = (int64_t)s * ldo + h * D + d;
@@ -985,12 +987,20 @@ extern "C" int mllm_hip_rope_apply(const float *x, int64_t ldx, const float *sin
     if (S <= 0) return MLLM_HIP_OK;
     const int g = grid_for((int64_t)S * H * (D / 2), 256);
     if (out_dtype == MLLM_HIP_F16)
-        hipLaunchKernelGGL(rope_apply_kernel<true>, dim3(g), dim3(256), 0, as_stream(stream), x, ldx, sin_t, cos_t, ld_tab, out, ldo, S, H, D);
+        hipLaunchKernelGGL(rope_apply_kernel<true>, dim3(g), dim3(256), 0, as_stream(stream), x, ldx, sin_t, cos_t, ld_tab, out, ldo, S, H, D, 0);
     else if (out_dtype == MLLM_HIP_F32)
-        hipLaunchKernelGGL(rope_apply_kernel<false>, dim3(g), dim3(256), 0, as_stream(stream), x, ldx, sin_t, cos_t, ld_tab, out, ldo, S, H, D);
+        hipLaunchKernelGGL(rope_apply_kernel<false>, dim3(g), dim3(256), 0, as_stream(stream), x, ldx, sin_t, cos_t, ld_tab, out, ldo, S, H, D, 0);
     else return MLLM_HIP_ERR_DTYPE;
     return MH_LAUNCH_OK("rope_apply");
 }
+namespace mllm_hip {
+// fp32 in place over `rows` rows whose table row is (row % period): the images of one vision pass in one launch
+int rope_apply_periodic(float *x, int64_t ldx, const float *sin_t, const float *cos_t, int ld_tab, int rows, int period, int H, int D, hipStream_t st) {
+    if (rows <= 0) return MLLM_HIP_OK;
+    hipLaunchKernelGGL(rope_apply_kernel<false>, dim3(grid_for((int64_t)rows * H * (D / 2), 256)), dim3(256), 0, st, x, ldx, sin_t, cos_t, ld_tab, (void *)x, ldx, rows, H, D, period);
+    return MH_LAUNCH_OK("rope_apply_periodic");
+}
+}  // namespace mllm_hip
 extern "C" int mllm_hip_qkv_rope_append(float *qkv, int64_t ldq, const float *sin_t, const float *cos_t, int ld_tab, uint16_t *k_rows, int64_t ldk, uint16_t *v_t, int64_t ldv,
                                        int S, int Hq, int Hkv, int D, void *stream) {
     if (D <= 0 || D % 2 || Hq <= 0 || Hkv <= 0 || ldq < (int64_t)(Hq + 2 * Hkv) * D) return MLLM_HIP_ERR_SHAPE;
