@@ -946,10 +946,74 @@ extern "C" int mllm_hip_argmax(const float *x, int n, int *out_index, void *stre
     if (e != hipSuccess && !rc) { set_error("hipFreeAsync", e, __FILE__, __LINE__); rc = MLLM_HIP_ERR_HIP; }
     return rc;
 }
+namespace mllm_hip {
+// the same selection over a slice, and over candidates that carry their own ids (ids == nullptr: the position is the id): workgroup b takes positions
+// [b * per, (b + 1) * per) and leaves its k best as (value, id), best first; slots it cannot fill get id 0x7fffffff, which no later stage accepts as a candidate.
+// The k best of the row are among the k best of every slice, and both stages order equal values by ascending id, so two stages select what the single workgroup does.
+template <int NT>
+__global__ __launch_bounds__(NT) void topk_slice_kernel(const float *__restrict__ x, const int *__restrict__ ids, int n, int per, int k, float *__restrict__ out_val,
+                                                        int *__restrict__ out_idx) {
+    __shared__ float sv[NT / 64];
+    __shared__ int si[NT / 64], sp[NT / 64];
+    __shared__ int taken[64];
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    float *ov_ = out_val + (int64_t)blockIdx.x * k;
+    int *oi_ = out_idx + (int64_t)blockIdx.x * k;
+    for (int r = 0; r < k; ++r) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff, bp = -1;
+        for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
+            const float v = x[i];
+            const int id = ids ? ids[i] : i;
+            if (id == 0x7fffffff || v != v) continue;      // an unfilled slot of the stage before, or a NaN: never a candidate
+            if (bi == 0x7fffffff || v > best || (v == best && id < bi)) {
+                bool free = true;
+                for (int t = 0; t < r; ++t) free = free && taken[t] != i;
+                if (free) { best = v; bi = id; bp = i; }
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(best, m, 64);
+            const int oi = __shfl_xor(bi, m, 64), op = __shfl_xor(bp, m, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; bp = op; }
+        }
+        if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; sp[threadIdx.x >> 6] = bp; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < NT / 64; ++w)
+                if (si[w] != 0x7fffffff && (bi == 0x7fffffff || sv[w] > best || (sv[w] == best && si[w] < bi))) { best = sv[w]; bi = si[w]; bp = sp[w]; }
+            taken[r] = bp;
+            ov_[r] = best;
+            oi_[r] = bi;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace mllm_hip
 extern "C" int mllm_hip_topk(const float *x, int n, int k, float *out_val, int *out_idx, void *stream) {
     if (n <= 0 || k <= 0 || k > 64 || k > n) return MLLM_HIP_ERR_SHAPE;
-    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n, k, out_val, out_idx);
-    return MH_LAUNCH_OK("topk");
+    hipStream_t st = as_stream(stream);
+    if (n < 16384) {
+        hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, x, n, k, out_val, out_idx);
+        return MH_LAUNCH_OK("topk");
+    }
+    // a vocabulary row: 128 slices leave their k best each, one workgroup picks the row's k best among those (k rounds over 128 k candidates instead of over n values)
+    constexpr int NP = 128;
+    const int per = (n + NP - 1) / NP;
+    void *scr = nullptr;
+    MH_CHECK(hipMallocAsync(&scr, (size_t)NP * k * 8, st));
+    float *cv = (float *)scr;
+    int *ci = (int *)(cv + (size_t)NP * k);
+    hipLaunchKernelGGL(topk_slice_kernel<256>, dim3(NP), dim3(256), 0, st, x, (const int *)nullptr, n, per, k, cv, ci);
+    int rc = MH_LAUNCH_OK("topk_slices");
+    if (!rc) {
+        hipLaunchKernelGGL(topk_slice_kernel<1024>, dim3(1), dim3(1024), 0, st, (const float *)cv, (const int *)ci, NP * k, NP * k, k, out_val, out_idx);
+        rc = MH_LAUNCH_OK("topk_final");
+    }
+    const hipError_t e = hipFreeAsync(scr, st);
+    if (e != hipSuccess && !rc) { set_error("hipFreeAsync", e, __FILE__, __LINE__); rc = MLLM_HIP_ERR_HIP; }
+    return rc;
 }
 // Host part of the same method (Generate.cpp:69-87): softmax with temperature over the k candidates, in the reference's mixed float /
 // double arithmetic with the host's libm exp (the reference runs it on the host too), then the renormalisation by the float sum.

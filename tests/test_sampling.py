@@ -91,12 +91,18 @@ def test_topk_on_device_matches_partial_sort_order():
     from mllm_amd import ops
     ops.require_gpu()
     r = np.random.default_rng(4)
-    for n, k in ((151936, 5), (2048, 1), (1000, 64), (7, 7)):
+    # rows of 16384 values and more take two stages (128 slices leave their k best, one workgroup picks among those): ties that span slices, k = 64, a row length that
+    # leaves the last slices short or empty, -inf entries
+    for n, k in ((151936, 5), (2048, 1), (1000, 64), (7, 7), (151936, 64), (16384, 50), (16390, 64), (32000, 1)):
         x = r.standard_normal(n).astype(np.float32)
         x[r.integers(0, n, size=max(1, n // 50))] = x.max()          # ties at the top: ascending index among equal logits
         val, idx = ops.topk(x, k)
         want_idx, want_val, _ = orc.topk_sampling_probs(x, k, 0.7)
-        assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+        assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val), (n, k)
+    x = np.full(20000, -np.inf, dtype=np.float32)
+    x[[19999, 3, 12000]] = [1.0, 1.0, -2.0]
+    val, idx = ops.topk(x, 5)
+    assert idx.tolist() == [3, 19999, 12000, 0, 1] and val[:3].tolist() == [1.0, 1.0, -2.0] and np.isneginf(val[3:]).all()
 
 
 @pytest.mark.gpu
