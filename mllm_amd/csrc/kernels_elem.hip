@@ -953,24 +953,24 @@ namespace mllm_hip {
 template <int NT>
 __global__ __launch_bounds__(NT) void topk_slice_kernel(const float *__restrict__ x, const int *__restrict__ ids, int n, int per, int k, float *__restrict__ out_val,
                                                         int *__restrict__ out_idx) {
+    // the slice's values live in LDS for the k rounds; a selected value is replaced by NaN (never a candidate), as is the value of an unfilled slot of the stage before
+    extern __shared__ __attribute__((aligned(16))) char tk_smem[];
+    float *vals = reinterpret_cast<float *>(tk_smem);      // [per]
     __shared__ float sv[NT / 64];
     __shared__ int si[NT / 64], sp[NT / 64];
-    __shared__ int taken[64];
-    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    const int lo = blockIdx.x * per, cnt = max(0, min(n, lo + per) - lo);
     float *ov_ = out_val + (int64_t)blockIdx.x * k;
     int *oi_ = out_idx + (int64_t)blockIdx.x * k;
+    for (int i = threadIdx.x; i < cnt; i += NT) vals[i] = (ids && ids[lo + i] == 0x7fffffff) ? __int_as_float(0x7fc00000) : x[lo + i];
+    __syncthreads();
     for (int r = 0; r < k; ++r) {
         float best = -INFINITY;
         int bi = 0x7fffffff, bp = -1;
-        for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
-            const float v = x[i];
-            const int id = ids ? ids[i] : i;
-            if (id == 0x7fffffff || v != v) continue;      // an unfilled slot of the stage before, or a NaN: never a candidate
-            if (bi == 0x7fffffff || v > best || (v == best && id < bi)) {
-                bool free = true;
-                for (int t = 0; t < r; ++t) free = free && taken[t] != i;
-                if (free) { best = v; bi = id; bp = i; }
-            }
+        for (int i = threadIdx.x; i < cnt; i += NT) {
+            const float v = vals[i];
+            if (v != v) continue;
+            const int id = ids ? ids[lo + i] : lo + i;
+            if (bi == 0x7fffffff || v > best || (v == best && id < bi)) { best = v; bi = id; bp = i; }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(NT) void topk_slice_kernel(const float *__restrict_
         if (threadIdx.x == 0) {
             for (int w = 1; w < NT / 64; ++w)
                 if (si[w] != 0x7fffffff && (bi == 0x7fffffff || sv[w] > best || (sv[w] == best && si[w] < bi))) { best = sv[w]; bi = si[w]; bp = sp[w]; }
-            taken[r] = bp;
+            if (bp >= 0) vals[bp] = __int_as_float(0x7fc00000);
             ov_[r] = best;
             oi_[r] = bi;
         }
@@ -1005,10 +1005,11 @@ extern "C" int mllm_hip_topk(const float *x, int n, int k, float *out_val, int *
     MH_CHECK(hipMallocAsync(&scr, (size_t)NP * k * 8, st));
     float *cv = (float *)scr;
     int *ci = (int *)(cv + (size_t)NP * k);
-    hipLaunchKernelGGL(topk_slice_kernel<256>, dim3(NP), dim3(256), 0, st, x, (const int *)nullptr, n, per, k, cv, ci);
+    if (per > 8192) { (void)hipFreeAsync(scr, st); hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, x, n, k, out_val, out_idx); return MH_LAUNCH_OK("topk"); }      // rows beyond a million values
+    hipLaunchKernelGGL(topk_slice_kernel<256>, dim3(NP), dim3(256), (size_t)per * 4, st, x, (const int *)nullptr, n, per, k, cv, ci);
     int rc = MH_LAUNCH_OK("topk_slices");
     if (!rc) {
-        hipLaunchKernelGGL(topk_slice_kernel<1024>, dim3(1), dim3(1024), 0, st, (const float *)cv, (const int *)ci, NP * k, NP * k, k, out_val, out_idx);
+        hipLaunchKernelGGL(topk_slice_kernel<1024>, dim3(1), dim3(1024), (size_t)NP * k * 4, st, (const float *)cv, (const int *)ci, NP * k, NP * k, k, out_val, out_idx);
         rc = MH_LAUNCH_OK("topk_final");
     }
     const hipError_t e = hipFreeAsync(scr, st);
