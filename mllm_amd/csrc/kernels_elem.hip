@@ -495,6 +495,61 @@ __global__ __launch_bounds__(64) void softmax_kernel(const float *__restrict__ x
     for (int i = v + lane; i < n; i += 64) yr[i] = 0.0f;
 }
 
+// ---- the same softmax for ONE long row (a vocabulary: top-p sampling), spread over the chip.  What is order-free runs everywhere -- the maximum, y = v_expf(x - max) and
+// the sum of every 8-chunk in its hsum order --; the row sum is still the reference's: the chunk sums added one after the other, then the trailing columns.  One wave does
+// that with a travelling accumulator (lane l holds 16 consecutive chunk sums, a wave_ror hop between lanes: ln_fused_kernel's walk): 19 k dependent adds instead of the
+// 1.9 ms the single-wave kernel above spends on a 151,936-wide row.
+__global__ __launch_bounds__(256) void softmax_row_max_kernel(const float *__restrict__ x, int n, float *__restrict__ part) {
+    __shared__ float sv[4];
+    float mx = -INFINITY;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) mx = fmaxf(mx, x[i]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+}
+__global__ __launch_bounds__(256) void softmax_row_exp_kernel(const float *__restrict__ x, float *__restrict__ y, int n, const float *__restrict__ part, int nparts,
+                                                              float *__restrict__ chunk_sums) {
+    __shared__ uint64_t tab[32];
+    expf_tab_store(tab, expf_tab_fetch());
+    float mx = -INFINITY;
+    for (int i = 0; i < nparts; ++i) mx = fmaxf(mx, part[i]);
+    __syncthreads();
+    const int nfull = n & ~7;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ((n + 255) & ~255); i += gridDim.x * 256) {
+        float e = 0.0f;
+        if (i < nfull) { e = v_expf(__fsub_rn(x[i], mx)); y[i] = e; }
+        else if (i < n) y[i] = glibc_expf(__fsub_rn(x[i], mx), tab);      // the < 8 trailing columns: libm's expf
+        float t = __fadd_rn(e, __shfl_xor(e, 4));
+        t = __fadd_rn(t, __shfl_xor(t, 2));
+        t = __fadd_rn(t, __shfl_xor(t, 1));
+        if ((threadIdx.x & 7) == 0 && i < nfull) chunk_sums[i >> 3] = t;
+    }
+}
+constexpr int DPP_WAVE_ROR1_SM = 0x13C;
+__global__ __launch_bounds__(64) void softmax_row_sum_kernel(const float *__restrict__ chunk_sums, int nchunks, const float *__restrict__ y, int n, float *__restrict__ inv_out) {
+    const int lane = threadIdx.x;
+    float acc = 0.0f;
+    for (int base = 0; base < nchunks; base += 1024) {
+        float u[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int c = base + 16 * lane + j; u[j] = c < nchunks ? chunk_sums[c] : 0.0f; }      // + 0.0f behind the end leaves the sum as it is
+#pragma unroll 4
+        for (int h = 0; h < 64; ++h) {
+            acc = MH_DPPF(0.0f, acc, DPP_WAVE_ROR1_SM, 0xF);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = __fadd_rn(acc, u[j]);
+        }
+    }
+    float sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
+    for (int i = n & ~7; i < n; ++i) sum = __fadd_rn(sum, y[i]);
+    if (lane == 0) *inv_out = __fdiv_rn(1.0f, sum);
+}
+__global__ __launch_bounds__(256) void softmax_row_scale_kernel(float *__restrict__ y, int n, const float *__restrict__ inv) {
+    const float s = *inv;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = __fmul_rn(y[i], s);
+}
+
 __global__ __launch_bounds__(256) void index_put_rows_kernel(float *__restrict__ dst, const float *__restrict__ value, const int *__restrict__ idx, int dim) {
     const int r = blockIdx.x;
     const float4 *src = reinterpret_cast<const float4 *>(value + (int64_t)r * dim);
@@ -889,6 +944,23 @@ extern "C" int mllm_hip_mul(const float *a, const float *b, float *y, int64_t n,
 }
 extern "C" int mllm_hip_softmax(const float *x, float *y, int rows, int n, const int *valid, void *stream) {
     if (rows <= 0) return MLLM_HIP_OK;
+    hipStream_t st = as_stream(stream);
+    if (rows == 1 && !valid && n >= 16384) {      // one long row: the order-free parts over the chip, the row sum by one wave (same bits as softmax_kernel)
+        constexpr int NP = 128;
+        const int nchunks = n >> 3;
+        float *scr = nullptr;
+        MH_CHECK(hipMallocAsync((void **)&scr, ((size_t)NP + 4 + nchunks) * 4, st));
+        float *part = scr, *inv = scr + NP, *cs = scr + NP + 4;
+        int rc = MLLM_HIP_OK;
+        hipLaunchKernelGGL(softmax_row_max_kernel, dim3(NP), dim3(256), 0, st, x, n, part);
+        rc = MH_LAUNCH_OK("softmax_row_max");
+        if (!rc) { hipLaunchKernelGGL(softmax_row_exp_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, n, (const float *)part, NP, cs); rc = MH_LAUNCH_OK("softmax_row_exp"); }
+        if (!rc) { hipLaunchKernelGGL(softmax_row_sum_kernel, dim3(1), dim3(64), 0, st, (const float *)cs, nchunks, (const float *)y, n, inv); rc = MH_LAUNCH_OK("softmax_row_sum"); }
+        if (!rc) { hipLaunchKernelGGL(softmax_row_scale_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, y, n, (const float *)inv); rc = MH_LAUNCH_OK("softmax_row_scale"); }
+        const hipError_t e = hipFreeAsync(scr, st);
+        if (e != hipSuccess && !rc) { set_error("hipFreeAsync", e, __FILE__, __LINE__); rc = MLLM_HIP_ERR_HIP; }
+        return rc;
+    }
     hipLaunchKernelGGL(softmax_kernel, dim3(rows), dim3(64), 0, as_stream(stream), x, y, n, valid);
     return MH_LAUNCH_OK("softmax");
 }

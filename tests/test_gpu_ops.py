@@ -266,6 +266,9 @@ def test_softmax_argmax_index_put(ops_gold):
     assert np.array_equal(y.cpu().numpy(), g["sm_y"].reshape(6, 24))       # every bit: chunk sums in the hsum order, libm expf on the < 8 trailing columns
     yv = ops.softmax(g["sm_x"].reshape(6, 24), valid=[1, 5, 24, 7, 8, 9])
     assert np.array_equal(yv.cpu().numpy(), orc.softmax(g["sm_x"].reshape(6, 24), valid=[1, 5, 24, 7, 8, 9]))
+    for n in (16384, 151936, 50003):                                       # one long row: the chip-wide form (order-free parts everywhere, the row sum by one wave)
+        xs = (rng(60 + n % 89).standard_normal((1, n)) * 4).astype(np.float32)
+        assert np.array_equal(ops.softmax(xs).cpu().numpy(), orc.softmax(xs)), n
     for n in (4, 67, 200, 1031):                                           # widths with full passes, a partial pass and a tail
         xs = (rng(40 + n).standard_normal((5, n)) * 4).astype(np.float32)
         assert np.array_equal(ops.softmax(xs).cpu().numpy(), orc.softmax(xs)), n
