@@ -3,6 +3,8 @@ import sys
 sys.path.insert(0, '.')
 import numpy as np
 from mllm_amd import lib, synth
+import os
+if os.environ.get('MLLM_SO'): lib.SO_PATH = os.environ['MLLM_SO']
 from tests.fixtures import weights
 cfg = synth.qwen2vl_2b(); path = weights.qwen2vl_file(cfg)
 pix, grid, ids = synth.qwen2vl_inputs(cfg, (32, 32), 24)
