@@ -244,9 +244,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
             for (int t = 0; t < 8; ++t) l = __fmaf_rn(l, Cc[lane * 8 + t], Sm[lane * 8 + t]);
             l_s[lane] = l;
         }
+        // which key tiles saw some row's maximum move: one 8-lane LDS read, folded into a wave-uniform mask (the per-tile `if (moved_any[t])` paid an LDS round trip in front
+        // of every tile's MFMAs)
+        const unsigned moved_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)__ballot(lane < 8 && moved_any[lane & 7] != 0));
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            if (moved_any[t]) {
+            if ((moved_mask >> t) & 1u) {
 #pragma unroll
                 for (int j = 0; j < TPW; ++j) {
                     const int rh = min(wid + 4 * j, NT16 - 1) & 1;
