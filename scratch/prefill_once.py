@@ -2,6 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mllm_amd import lib, synth
+if os.environ.get('MLLM_SO'): lib.SO_PATH = os.environ['MLLM_SO']
 from tests.fixtures import weights
 cfg = synth.qwen2vl_2b()
 m = lib.Qwen2VL(cfg, weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache")))
