@@ -11,6 +11,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,7 @@
 #include "backends/cpu/CPUBackend.hpp"
 
 #include "HIPBackend.hpp"
+#include "HIPQwen2VLEngine.hpp"
 
 using namespace mllm;
 
@@ -52,7 +54,7 @@ static std::vector<int> parse_ints(const std::string &s) {
 
 int main(int argc, char **argv) {
     std::string model_path, ids_path, pix_path, out_dir = ".", grid_s = "1,32,32", cfg_s;
-    int steps = 8, threads = 8, dump_every = 1;
+    int steps = 8, threads = 8, dump_every = 1, engine = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i], v = argv[i + 1];
         if (k == "--model") model_path = v;
@@ -64,6 +66,7 @@ int main(int argc, char **argv) {
         else if (k == "--out") out_dir = v;
         else if (k == "--cfg") cfg_s = v;
         else if (k == "--dump-every") dump_every = std::stoi(v);
+        else if (k == "--engine") engine = std::stoi(v);      // 1: the Module of HIPQwen2VLEngine.hpp (the resident engine behind the reference's frontend) instead of the Op-by-Op adapter
     }
     CPUBackend::cpu_threads = threads;
     Module::initBackend(MLLM_CPU);
@@ -86,10 +89,6 @@ int main(int argc, char **argv) {
         config.vision_end_token_id = cv[10];
         config.video_token_id = cv[11];
     }
-    auto model = Qwen2VLModel(config);
-    model.to(MLLM_HIP_BACKEND_TYPE);      // examples/demo_qwen.cpp:57
-    model.load(model_path);               // :59 -- every Op::load goes through Backend::load_from_file
-    hip->sync();
 
     auto ids = read_file<int32_t>(ids_path);
     auto grid = parse_ints(grid_s);
@@ -127,6 +126,7 @@ int main(int argc, char **argv) {
 
     std::vector<int32_t> tokens;
     std::vector<double> ms;
+    auto drive = [&](auto &model) {
     for (int step = 0; step < steps; ++step) {
         model.get_position_ids(input);
         auto t0 = std::chrono::steady_clock::now();
@@ -148,6 +148,19 @@ int main(int argc, char **argv) {
         if (input.size() > 3) input[3].cpu();
         chatPostProcessing((unsigned)best, input[0], {&input[1], &input[2]});
     }
+    };
+    std::unique_ptr<Qwen2VLModel> graph_model;
+    std::unique_ptr<HIPQwen2VLEngine> engine_model;
+    if (engine) {
+        engine_model = std::make_unique<HIPQwen2VLEngine>(config, model_path);
+        drive(*engine_model);
+    } else {
+        graph_model = std::make_unique<Qwen2VLModel>(config);
+        graph_model->to(MLLM_HIP_BACKEND_TYPE);      // examples/demo_qwen.cpp:57
+        graph_model->load(model_path);               // :59 -- every Op::load goes through Backend::load_from_file
+        hip->sync();
+        drive(*graph_model);
+    }
     write_file<int32_t>(out_dir + "/tokens.i32", tokens.data(), tokens.size());
     double dec = 0;
     for (size_t i = 1; i < ms.size(); ++i) dec += ms[i];
@@ -160,6 +173,6 @@ int main(int argc, char **argv) {
            ids.size(), ms[0], ms.size() - 1, ms.size() > 1 ? dec / (ms.size() - 1) : 0.0,
            ms.size() > 1 ? 1000.0 * (ms.size() - 1) / dec : 0.0, hip->ops_run(), hip->refused().size(), refused.c_str(), hip->live_blocks());
     fflush(stdout);
-    model.profiling();
+    if (engine) engine_model->profiling(); else graph_model->profiling();
     return 0;
 }

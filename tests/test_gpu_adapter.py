@@ -21,9 +21,10 @@ def _cfg_string(c):
             f"{c.vision_end_token_id},{c.video_token_id}")
 
 
-def _run(td, cfg, path, ids, steps, pix=None, grid=None):
+def _run(td, cfg, path, ids, steps, pix=None, grid=None, engine=0):
     ids.astype(np.int32).tofile(os.path.join(td, "ids.i32"))
-    cmd = [DRIVER, "--model", path, "--ids", os.path.join(td, "ids.i32"), "--steps", str(steps), "--threads", "4", "--out", td, "--cfg", _cfg_string(cfg), "--dump-every", "1"]
+    cmd = [DRIVER, "--model", path, "--ids", os.path.join(td, "ids.i32"), "--steps", str(steps), "--threads", "4", "--out", td, "--cfg", _cfg_string(cfg), "--dump-every", "1",
+           "--engine", str(engine)]
     if pix is not None:
         pix.astype(np.float32).tofile(os.path.join(td, "pix.f32"))
         cmd += ["--pix", os.path.join(td, "pix.f32"), "--grid", ",".join(str(int(g)) for g in grid)]
@@ -99,3 +100,37 @@ def test_reference_module_at_the_2b_geometry(tmp_path):
     for i, s in enumerate(g["steps"]):
         lg = np.fromfile(os.path.join(td, f"logits_{int(s)}.f32"), dtype=np.float32)
         assert np.array_equal(lg[g["top_idx"][i]], g["top_val"][i]) and np.array_equal(lg[::97], g["strided"][i]), int(s)
+
+
+def test_engine_module_behind_the_reference_frontend(tiny, tiny_gold, tmp_path):
+    """integration/hip/HIPQwen2VLEngine.hpp: a mllm::Module with Qwen2VLModel's calling convention whose Forward is the resident engine (mllm_hip_model_*), driven by the same
+    demo loop (model(input) -> host argmax -> chatPostProcessing): ids and every logit of every step equal the reference's CPU run, image + text and text only; then the 2B
+    geometry: ids and sampled logits, and the reference's own profiling() of that run."""
+    from mllm_amd import synth
+    from tests.fixtures import weights
+    cfg, path = tiny
+    g = tiny_gold
+    pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
+    report, toks, logits = _run(str(tmp_path), cfg, path, ids, len(g["tokens"]), pix, grid, engine=1)
+    assert toks.tolist() == g["tokens"].tolist() and np.array_equal(logits, g["logits"])
+    report, toks, logits = _run(str(tmp_path), cfg, path, g["ids_text"], len(g["tokens_text"]), engine=1)
+    assert toks.tolist() == g["tokens_text"].tolist() and np.array_equal(logits, g["logits_text"])
+    big = synth.qwen2vl_2b()
+    bpath = weights.qwen2vl_file(big, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
+    gb = np.load(os.path.join(ROOT, "tests", "golden", "qwen2vl_2b_ref.npz"))
+    pix, grid, ids = synth.qwen2vl_inputs(big, (32, 32), 24)
+    steps = len(gb["tokens"])
+    td = str(tmp_path)
+    ids.astype(np.int32).tofile(os.path.join(td, "ids.i32"))
+    pix.astype(np.float32).tofile(os.path.join(td, "pix.f32"))
+    cmd = [DRIVER, "--model", bpath, "--ids", os.path.join(td, "ids.i32"), "--steps", str(steps), "--threads", "4", "--out", td, "--cfg", _cfg_string(big), "--dump-every", "16",
+           "--pix", os.path.join(td, "pix.f32"), "--grid", ",".join(str(int(x)) for x in grid), "--engine", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
+    report = json.loads(next(l for l in out.stdout.splitlines() if l.startswith('{"backend"')))
+    print("engine Module report (2B):", report)
+    toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
+    assert toks.tolist() == gb["tokens"].tolist()
+    for i, s_ in enumerate(gb["steps"]):
+        lg = np.fromfile(os.path.join(td, f"logits_{int(s_)}.f32"), dtype=np.float32)
+        assert np.array_equal(lg[gb["top_idx"][i]], gb["top_val"][i]) and np.array_equal(lg[::97], gb["strided"][i]), int(s_)
