@@ -37,6 +37,16 @@ namespace mllm_hip {
 // 32w .. 32w+31.  K and V chunks are staged in LDS as fp32 (K pitch D+1, transposed-slab V pitch 33: conflict-free operand reads).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int FA_R = 32, FA_KCH = 32;
+#ifndef FA_PVG
+#define FA_PVG 2      // key tiles whose P V operands are requested together (4: one register too many for D = 80 under the three-workgroups-per-CU cap)
+#endif
+// diagnostic build only (-DFA_STAMPS, scratch/fa_stamps.py): s_memtime at the phase boundaries of chunks 4..7 of workgroup 0, wave 0
+#ifdef FA_STAMPS
+__device__ unsigned long long g_fa_stamps[64];
+#define FA_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && chunk0 >= 4 * FA_KCH && chunk0 < 8 * FA_KCH) g_fa_stamps[(chunk0 / FA_KCH - 4) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FA_STAMP(i)
+#endif
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 
 // (head sizes up to 80 fit 168 registers and 44 KiB of LDS: three workgroups per CU, whose barrier / softmax / fetch phases run under each other's MFMAs)
@@ -165,10 +175,13 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
     };
     fetch(0);
     for (int chunk0 = 0; chunk0 < klim; chunk0 += FA_KCH) {
+        FA_STAMP(0);
         __syncthreads();                       // the previous chunk's P V has finished with Ks / Vs / P
+        FA_STAMP(1);
         park();
         if (tid < 8) moved_any[tid] = 0;
         __syncthreads();
+        FA_STAMP(2);
         if (chunk0 + FA_KCH < klim) fetch(chunk0 + FA_KCH);
         // ---- scores: wave w owns chains w and w + 4 -- the pair the reference's fold adds first -- and hands their sum to the fold ------------------
         {
@@ -185,7 +198,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
 #pragma unroll
             for (int i = 0; i < 16; ++i) Part[(wid * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 33 + col] = acc[0][i] + acc[1][i];
         }
+        FA_STAMP(3);
         __syncthreads();
+        FA_STAMP(4);
         // ---- fold the chains, mask, softmax of (row, key tile) ----------------------------------------------------------------------
         {
             const int row = tid >> 3, tile = tid & 7;
@@ -236,7 +251,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
             __builtin_amdgcn_wave_barrier();
             if (tile == 7) m_in[row] = incl;
         }
+        FA_STAMP(5);
         __syncthreads();
+        FA_STAMP(6);
         // ---- logsum per row (32 lanes of the last wave), P V per dim tile ----------------------------------------------------------------
         if (wid == 3 && lane < 32) {
             float l = l_s[lane];
@@ -247,26 +264,40 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
         // which key tiles saw some row's maximum move: one 8-lane LDS read, folded into a wave-uniform mask (the per-tile `if (moved_any[t])` paid an LDS round trip in front
         // of every tile's MFMAs)
         const unsigned moved_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)__ballot(lane < 8 && moved_any[lane & 7] != 0));
+        // the MFMA operands of FA_PVG key tiles at a time are requested before the first of their MFMAs (left inside the tile loop, each tile's reads sat behind the previous
+        // tile's rescale branch and every MFMA waited out an LDS round trip: 2,300 cycles per chunk for 24 MFMAs -- scratch/fa_stamps.py); the next group's reads travel
+        // while this group's MFMAs run
+        const int rh0 = wid & 1;      // every tile of this wave has the same row half: tile ids w, w + 4, ...
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if ((moved_mask >> t) & 1u) {
+        for (int hh = 0; hh < 8 / FA_PVG; ++hh) {
+            float pop[FA_PVG], vop[FA_PVG][TPW];
+#pragma unroll
+            for (int tt = 0; tt < FA_PVG; ++tt) {
+                const int key = 4 * (FA_PVG * hh + tt) + q4;
+                pop[tt] = P[(16 * rh0 + c16) * 33 + key];
 #pragma unroll
                 for (int j = 0; j < TPW; ++j) {
-                    const int rh = min(wid + 4 * j, NT16 - 1) & 1;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) oacc[j][i] = oacc[j][i] * Cc[(16 * rh + 4 * q4 + i) * 8 + t];
+                    const int dd = 16 * (min(wid + 4 * j, NT16 - 1) >> 1) + c16;
+                    vop[tt][j] = VT ? Vs[dd * 33 + key] : Vs[key * D + dd];
                 }
             }
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) {
+            for (int tt = 0; tt < FA_PVG; ++tt) {
+                const int t = FA_PVG * hh + tt;
+                if ((moved_mask >> t) & 1u) {
+#pragma unroll
+                    for (int j = 0; j < TPW; ++j) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) oacc[j][i] = oacc[j][i] * Cc[(16 * rh0 + 4 * q4 + i) * 8 + t];
+                    }
+                }
                 // a wave whose last tile id is past the end repeats the last tile (its result is not stored): no control flow around the MFMAs,
                 // which would make the compiler shuttle every accumulator through AGPR copies at each branch
-                const int tile = min(wid + 4 * j, NT16 - 1), rh = tile & 1, dt = tile >> 1;
-                const int key = 4 * t + q4, dd = 16 * dt + c16;
-                const float vb = VT ? Vs[dd * 33 + key] : Vs[key * D + dd];
-                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[(16 * rh + c16) * 33 + key], vb, oacc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pop[tt], vop[tt][j], oacc[j], 0, 0, 0);
             }
         }
+        FA_STAMP(7);
     }
     __syncthreads();
 #pragma unroll
@@ -402,3 +433,7 @@ extern "C" int mllm_hip_fa2_vt(const float *Q, int64_t ldq, const void *K, int64
     default: return MLLM_HIP_ERR_SHAPE;
     }
 }
+
+#ifdef FA_STAMPS
+extern "C" int mllm_hip_debug_read_fa_stamps(unsigned long long *host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(mllm_hip::g_fa_stamps), 64 * 8) == hipSuccess ? 0 : -1; }
+#endif
