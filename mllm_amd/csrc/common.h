@@ -164,9 +164,9 @@ static __device__ const uint64_t EXPF_TAB[32] = {
 __device__ __forceinline__ uint64_t expf_tab_fetch() { return EXPF_TAB[threadIdx.x & 31]; }   // issue early, store with expf_tab_store
 __device__ __forceinline__ void expf_tab_store(uint64_t *lds_tab, uint64_t v) { if (threadIdx.x < 32) lds_tab[threadIdx.x] = v; }
 __device__ __forceinline__ float glibc_expf(float x, const uint64_t *T) {
-    if (x < -0x1.9fe368p6f) return 0.0f;
-    if (x < -0x1.9d1d9ep6f) return 0x1p-149f;
-    if (x > 0x1.62e42ep6f) return __int_as_float(0x7f800000);
+    // the three range cases are selects behind the main path, not early returns: a return per lane is a divergent branch around everything that follows, and the five
+    // calls per (row, key tile) of the prefill softmax spent 1,500 cycles per chunk in it (scratch/fa_stamps.py).  Out of range the main path computes a value nobody
+    // takes (no operation in it traps).
     const double xd = (double)x, InvLn2N = 0x1.71547652b82fep+5, Shift = 0x1.8p+52;
     double kd = __fma_rn(InvLn2N, xd, Shift);
     const uint64_t ki = (uint64_t)__double_as_longlong(kd);
@@ -177,7 +177,11 @@ __device__ __forceinline__ float glibc_expf(float x, const uint64_t *T) {
     const double r2 = r * r;
     double y = __fma_rn(r, 0x1.62e42ff0c52d6p-6, 1.0);
     y = __fma_rn(z, r2, y);
-    return (float)(y * sc);
+    float res = (float)(y * sc);
+    res = x > 0x1.62e42ep6f ? __int_as_float(0x7f800000) : res;
+    res = x < -0x1.9d1d9ep6f ? 0x1p-149f : res;
+    res = x < -0x1.9fe368p6f ? 0.0f : res;
+    return res;
 }
 // inclusive max scan over the 64 lanes of a wave (lane i ends with max of lanes 0..i)
 __device__ __forceinline__ float wave_scan_max(float v) {

@@ -43,7 +43,7 @@ constexpr int FA_R = 32, FA_KCH = 32;
 // diagnostic build only (-DFA_STAMPS, scratch/fa_stamps.py): s_memtime at the phase boundaries of chunks 4..7 of workgroup 0, wave 0
 #ifdef FA_STAMPS
 __device__ unsigned long long g_fa_stamps[64];
-#define FA_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && chunk0 >= 4 * FA_KCH && chunk0 < 8 * FA_KCH) g_fa_stamps[(chunk0 / FA_KCH - 4) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FA_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && chunk0 >= 4 * FA_KCH && chunk0 < 8 * FA_KCH) g_fa_stamps[(chunk0 / FA_KCH - 4) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FA_STAMP(i)
 #endif
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
                 if (diag && e > (row & 3)) v = FA_NEG;
                 s4[e] = v;
             }
+            FA_STAMP(8);
             float tm = FA_NEG;
             if (live) {
                 tm = s4[0];
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
             const float incl = fmaxf(sc, carry);
             const float prev = MH_DPPF(incl, incl, 0x111, 0xF);
             const float excl = tile == 0 ? carry : prev;
+            FA_STAMP(9);
             float p4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, cc = 1.0f, sum = 0.0f;
             if (live) {
                 if (excl != incl) { cc = glibc_expf((excl - incl) * scale, etab); moved_any[tile] = 1; }
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
                 for (int e = 1; e < 4; ++e) p4[e] = e < nc ? p4[e] : 0.0f;
                 sum = ((p4[0] + p4[1]) + p4[2]) + p4[3];
             }
+            FA_STAMP(10);
 #pragma unroll
             for (int e = 0; e < 4; ++e) P[row * 33 + 4 * tile + e] = p4[e];
             Cc[row * 8 + tile] = cc;

@@ -16,8 +16,10 @@ for Sq in (512, 1024):
     torch.cuda.synchronize()
     buf = np.zeros(64, dtype=np.uint64)
     assert lib.load().mllm_hip_debug_read_fa_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
-    st = buf.reshape(8, 8)[:4].astype(np.int64)
+    full = buf.reshape(4, 16).astype(np.int64)
+    st = full[:, :8]
     d = np.diff(st, axis=1)
     print('Sq', Sq, 'cycles per phase (median of chunks 4..7):')
     for i, n in enumerate(names): print('   %-30s %6d' % (n, int(np.median(d[:, i]))))
     print('   chunk total                    %6d' % int(np.median(st[1:, 0] - st[:-1, 0])))
+    print('   inside the softmax: fold of the partials %d, tile / prefix maximum %d, expf x 5 %d, stores %d' % tuple(int(np.median(x)) for x in (full[:, 8] - full[:, 4], full[:, 9] - full[:, 8], full[:, 10] - full[:, 9], full[:, 5] - full[:, 10])))
