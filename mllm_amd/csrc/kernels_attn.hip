@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
     V = reinterpret_cast<const char *>(V) + (int64_t)blockIdx.z * bv * (F16 ? 2 : 4);
     static_assert(D % 16 == 0 && D <= 128, "head dim");
     constexpr int NS = D / 16;              // MFMAs per score chain
-    constexpr int KP = D + 1;               // K row pitch in LDS (odd: the per-key column reads are conflict-free)
+    constexpr int KP = D + 4;               // K row pitch in LDS: a multiple of four floats, so a staged group is ONE 16-byte store (with the odd pitch D + 1 it was four
+                                            // scalar stores); the per-key column reads of the score MFMAs then meet two lanes per bank instead of one, which costs them a cycle
     constexpr int VP = VT ? 33 : D;         // V: [key][D] as stored, or [d][33] from the transposed slab
     constexpr int NDT = (D + 31) / 32;      // 32-wide dim tiles of the output
     constexpr int KE = FA_KCH * D / 256;    // staged elements per thread and operand
@@ -160,8 +161,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void fa2_prefill_kernel(con
             if (e4 < FA_KCH * D / 4) {
                 {
                     const int key = e4 / (D / 4), d4 = e4 - key * (D / 4);
-                    float *kd = Ks + key * KP + 4 * d4;      // odd pitch: four scalar stores
-                    kd[0] = kst[i].x; kd[1] = kst[i].y; kd[2] = kst[i].z; kd[3] = kst[i].w;
+                    *reinterpret_cast<float4 *>(Ks + key * KP + 4 * d4) = kst[i];
                 }
                 if (VT) {
                     const int dd = e4 / (FA_KCH / 4), k4 = e4 - dd * (FA_KCH / 4);
