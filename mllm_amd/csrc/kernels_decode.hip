@@ -44,7 +44,7 @@ namespace mllm_hip {
 #endif
 constexpr bool g_nt = MLLM_HIP_NT != 0;
 
-#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB)
+#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB) || defined(MLLM_HIP_STAMPS_PJB)
 __device__ unsigned long long g_stamps[8192 * 16];
 #endif
 #ifdef MLLM_HIP_STAMPS
@@ -88,6 +88,12 @@ __device__ unsigned long long g_stamps[8192 * 16];
 #define STAMPB(i)
 #endif
 // stamps of the gate|up GEMV only (diagnostic build with -DMLLM_HIP_STAMPS_GUB: scratch/stamps_gub.py); the attention's stamps stay silent in that build
+// (the same for the down projection with -DMLLM_HIP_STAMPS_PJB: scratch/stamps_pjb.py)
+#if defined(MLLM_HIP_STAMPS_PJB)
+#define GSTAMP2(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && K > 4096) mllm_hip::g_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GSTAMP2(i)
+#endif
 #if defined(MLLM_HIP_STAMPS_GUB)
 #define GSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) mllm_hip::g_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -140,33 +146,91 @@ __host__ __device__ static inline size_t act_lds_bytes(int K, bool with_xf) {
     return (size_t)K + ((K / 256 * 4 + 15) & ~15) + ((K / 32 * 4 + 15) & ~15) + (with_xf ? (size_t)K * 4 : 0) + 64;
 }
 
-// one wave quantises NB 256-blocks (block wid + 4i, 4 consecutive values per lane) into LDS: quantize_row_q8_K_reference.
-// Branch-free and written block-parallel (arrays over i) so the NB reduction chains interleave instead of serialising.
+// one wave quantises NB 256-blocks (block wid + WPB*i, 4 consecutive values per lane) into LDS: quantize_row_q8_K_reference (Quantize.hpp / ggml).
+// Written block-parallel (arrays over i) so the NB reduction chains interleave, and counted per instruction: the down projection's prologue quantises 35
+// blocks on 8 waves = 2 waves per SIMD, and is bound by VALU issue, not latency (scratch/stamps_pjb.py: 1.68 us of the kernel's 5 at ~106 VALU per block).
+//   * |max| is reduced on the value BITS with integer max: DPP folds into v_max_u32 (fmaxf on a DPP move costs a move, a canonicalise and the max);
+//   * the SIGNED first maximum (ggml keeps x[j] of the first |x[j]| == amax, in index order) comes from the lanes' max / min: the first lane holding +amax or -amax
+//     decides, and only a lane holding both (with amax != 0) needs the element order -- that case takes the per-element path below behind a wave-uniform branch;
+//   * the two IEEE divisions (-128 / max, 1 / iscale) of all NB blocks are done once, block i in lane i, instead of NB times on uniform values;
+//   * iscale * x and the magic add (nearest_int) are the two-wide v_pk_mul_f32 / v_pk_add_f32; the byte of q IS the low byte of the sum's bits, so the clamp to 127
+//     is an unsigned min on the bits, the pack two v_perm + or, and q0+q1+q2+q3 one v_dot4 (identical for every finite input).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_QUAD_X1, 0xF));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_QUAD_X2, 0xF));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_HALF_MIRROR, 0xF));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_MIRROR, 0xF));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_BCAST15, 0xA));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_BCAST31, 0xC));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 template <int NB, int WPB>
 __device__ __forceinline__ void wave_quant_blocks(const float4 (&v)[NB], int lane, int wid, int nblk, const ActLds &a) {
-    float amax[NB], mx[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) amax[i] = fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
-#pragma unroll
-    for (int i = 0; i < NB; ++i) amax[i] = wave_max(amax[i]);
+    float hi[NB], lo[NB];
+    unsigned abits[NB], mbits[NB];      // wave-uniform: bits of amax (>= +0) and of the signed first maximum
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const float a0 = fabsf(v[i].x), a1 = fabsf(v[i].y), a2 = fabsf(v[i].z), a3 = fabsf(v[i].w);
-        const float mine = a0 == amax[i] ? v[i].x : (a1 == amax[i] ? v[i].y : (a2 == amax[i] ? v[i].z : v[i].w));
-        mx[i] = first_flagged(a0 == amax[i] || a1 == amax[i] || a2 == amax[i] || a3 == amax[i], mine);
+        // v_max3 / v_min3 spelled out: fmaxf() on loaded values is preceded by a canonicalising v_max x, x per operand (IEEE mode)
+        float t;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v[i].x), "v"(v[i].y), "v"(v[i].z));
+        asm("v_max_f32 %0, %1, %2" : "=v"(hi[i]) : "v"(t), "v"(v[i].w));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v[i].x), "v"(v[i].y), "v"(v[i].z));
+        asm("v_min_f32 %0, %1, %2" : "=v"(lo[i]) : "v"(t), "v"(v[i].w));
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        float am;
+        asm("v_max_f32 %0, |%1|, |%2|" : "=v"(am) : "v"(hi[i]), "v"(lo[i]));
+        abits[i] = wave_umax(__float_as_uint(am));
+    }
+    bool tangled = false;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const float amax = __uint_as_float(abits[i]);
+        const unsigned long long pos = __ballot(hi[i] == amax), neg = __ballot(lo[i] == -amax);
+        const unsigned long long both = pos | neg, first = both & (0ull - both);
+        mbits[i] = abits[i] ^ ((neg & first) ? 0x80000000u : 0u);
+        tangled |= (pos & neg & first) != 0 && abits[i] != 0;
+    }
+    if (tangled) {      // some lane holds +amax and -amax and is the first to hold either: the element order inside it decides
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float amax = __uint_as_float(abits[i]);
+            const float a0 = fabsf(v[i].x), a1 = fabsf(v[i].y), a2 = fabsf(v[i].z), a3 = fabsf(v[i].w);
+            const float mine = a0 == amax ? v[i].x : (a1 == amax ? v[i].y : (a2 == amax ? v[i].z : v[i].w));
+            mbits[i] = __float_as_uint(first_flagged(a0 == amax || a1 == amax || a2 == amax || a3 == amax, mine));
+        }
+    }
+    float isc[NB], dd[NB];
+    if constexpr (NB >= 3) {
+        int mxv = __float_as_int(1.0f);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) asm("v_writelane_b32 %0, %1, %2" : "+v"(mxv) : "s"((int)mbits[i]), "n"(i));
+        const float isv = -128.0f / __int_as_float(mxv), ddv = 1.0f / isv;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            isc[i] = abits[i] ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(isv), i)) : 0.0f;
+            dd[i] = abits[i] ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ddv), i)) : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            isc[i] = abits[i] ? -128.0f / __uint_as_float(mbits[i]) : 0.0f;
+            dd[i] = abits[i] ? 1.0f / isc[i] : 0.0f;
+        }
     }
     int qsum[NB];
     uint32_t packed[NB];
-    float dd[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const bool nz = amax[i] != 0.0f;
-        const float iscale = nz ? -128.0f / mx[i] : 0.0f;
-        const int q0 = min(127, nearest_int(iscale * v[i].x)), q1 = min(127, nearest_int(iscale * v[i].y));
-        const int q2 = min(127, nearest_int(iscale * v[i].z)), q3 = min(127, nearest_int(iscale * v[i].w));
-        dd[i] = nz ? 1.0f / iscale : 0.0f;
-        packed[i] = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
-        qsum[i] = q0 + q1 + q2 + q3;
+        const f32x2_t s = {isc[i], isc[i]}, magic = {12582912.0f, 12582912.0f};
+        const f32x2_t m01 = f32x2_t{v[i].x, v[i].y} * s + magic, m23 = f32x2_t{v[i].z, v[i].w} * s + magic;      // -ffp-contract=off: a product, then a sum
+        const uint32_t top = 0x4B40007Fu;      // bits of 12582912 + 127
+        const uint32_t b0 = min(__float_as_uint(m01.x), top), b1 = min(__float_as_uint(m01.y), top);
+        const uint32_t b2 = min(__float_as_uint(m23.x), top), b3 = min(__float_as_uint(m23.y), top);
+        packed[i] = __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);
+        qsum[i] = __builtin_amdgcn_sdot4((int)packed[i], 0x01010101, 0, false);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) qsum[i] = group8_sum(qsum[i]);   // 8 lanes = 32 values (bsums[2k] + bsums[2k+1])
@@ -175,8 +239,8 @@ __device__ __forceinline__ void wave_quant_blocks(const float4 (&v)[NB], int lan
         const int blk = wid + WPB * i;
         if (blk < nblk) {
             reinterpret_cast<uint32_t *>(a.qs + blk * a.qstride)[lane] = packed[i];
-            if ((lane & 7) == 0) a.q8s[blk * 8 + (lane >> 3)] = qsum[i];
-            if (lane == 0) a.d[blk] = dd[i];
+            a.q8s[blk * 8 + (lane >> 3)] = qsum[i];      // the 8 lanes of a group hold the same sum, every lane the same d: same-address stores, no exec masks
+            a.d[blk] = dd[i];
         }
     }
 }
@@ -643,6 +707,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__r
     char *stage = smem + ((gub_act_bytes(K) + 15) & ~(size_t)15);
     float2 *tab = reinterpret_cast<float2 *>(stage + pjb_stage_bytes(RPW, nb));
     float4 v[NQ];
+    GSTAMP2(0);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int blk = wid + WPB * i;
@@ -663,20 +728,27 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__r
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) if (wid + WPB * i >= nb) v[i] = make_float4(0, 0, 0, 0);
+    GSTAMP2(1);
     wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
+    GSTAMP2(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GSTAMP2(3);
     __syncthreads();
+    GSTAMP2(4);
     if (tid < RPW * nb) {
         const int row = tid / nb, b = tid - row * nb;
         blk_emit(stage + (size_t)tid * 144, a, b, tab + (size_t)tid * Q4K_SLOTS);
     }
+    GSTAMP2(5);
     __syncthreads();
+    GSTAMP2(6);
     if (4 * wid < RPW) {
         const int nr = RPW - 4 * wid < 4 ? RPW - 4 * wid : 4;
         const float res = q4k_chain(tab + (size_t)4 * wid * nb * Q4K_SLOTS, nb, nb, nr, lane);
         const int rw = row0 + 4 * wid + (lane >> 4);
         if ((lane & 15) == 8 && (lane >> 4) < nr) y[rw] = residual ? res + residual[rw] : res;
     }
+    GSTAMP2(7);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -999,7 +1071,7 @@ __global__ __launch_bounds__(256) void dec_next_kernel(DecodeState *__restrict__
         state->step += 1;
     }
 }
-#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB)
+#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB) || defined(MLLM_HIP_STAMPS_PJB)
 }  // namespace mllm_hip
 extern "C" int mllm_hip_debug_read_stamps(unsigned long long *host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(mllm_hip::g_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;

@@ -78,6 +78,26 @@ def test_linear_q4k_gemv_vs_oracle(M, K, N):
     assert eq(y, ref), md(y, ref)
 
 
+# the decode quantiser finds the SIGNED first maximum of a 256-block from the lanes' max / min (4 consecutive values per lane); ties of +amax and -amax decide the sign of
+# iscale by index order: in different lanes, inside one lane in both orders, the maximum at the very end, an all-zero block, and a block that clamps at 127
+@pytest.mark.parametrize("K,N", [(1536, 96), (8960, 64)])
+def test_linear_q4k_gemv_signed_maximum_ties(K, N):
+    Wq, x, _ = _q4k_case(1, K, N, K * 3 + N, bias=False)
+    nb = K // 256
+    x = np.clip(x, -2.0, 2.0)
+    cases = [((5, 3.0), (77, -3.0)), ((5, -3.0), (77, 3.0)), ((40, 3.0), (41, -3.0)), ((40, -3.0), (41, 3.0)), ((42, -3.0), (43, 3.0), (3, 3.0)),
+             ((255, -3.0),), ((252, 3.0), (253, 3.0), (254, -3.0), (255, -3.0)), ((0, -3.0), (1, 3.0), (2, -3.0), (3, 3.0))]
+    for b in range(nb):
+        for j, val in cases[b % len(cases)]:
+            x[0, b * 256 + j] = val
+    if nb > 8:
+        x[0, 8 * 256:9 * 256] = 0.0
+        x[0, 9 * 256:10 * 256] = -0.0
+    y = ops.linear_q4k(Wq, x, N)
+    ref = orc.linear(x, Wq, orc.Q4_K, N)
+    assert eq(y, ref), md(y, ref)
+
+
 # the GEMM's K loop is peeled (first blocks / block nb-2 / last block): nb = 1, 2, 3, 4 and more; ragged M and N edges, an odd number of 32-column tiles (the second
 # tile of a workgroup's 32 x 64 is then idle), weights expanded from nibbles in registers
 @pytest.mark.parametrize("M,K,N", [(16, 256, 128), (64, 1536, 256), (282, 1536, 2048), (100, 8960, 192), (1024, 1280, 384), (33, 512, 96),
