@@ -149,6 +149,53 @@ __device__ __forceinline__ float first_flagged(bool flag, float mine) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), src));
 }
 
+// ---- Q8_K of one 256-block held as 4 consecutive values per lane, counted per instruction (the decode form over several blocks at once is
+// wave_quant_blocks of kernels_decode.hip, where the reasoning is written out) ----
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {      // integer max: DPP folds into v_max_u32 (fmaxf on a DPP move costs a move, a canonicalise and the max)
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_QUAD_X1, 0xF));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_QUAD_X2, 0xF));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_HALF_MIRROR, 0xF));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_MIRROR, 0xF));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_BCAST15, 0xA));
+    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_BCAST31, 0xC));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// bits of amax = max |x| over the block (wave-uniform, >= +0) and the value ggml's strict `>` scan keeps: x[first j with |x[j]| == amax].  The first lane holding +amax
+// or -amax decides the sign; only a lane that holds both (amax != 0) needs the order of its four elements, behind a wave-uniform branch.
+__device__ __forceinline__ float q8k_first_max(const float4 &v, unsigned &abits) {
+    float t, hi, lo, am;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v.x), "v"(v.y), "v"(v.z));
+    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(t), "v"(v.w));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v.x), "v"(v.y), "v"(v.z));
+    asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(t), "v"(v.w));
+    asm("v_max_f32 %0, |%1|, |%2|" : "=v"(am) : "v"(hi), "v"(lo));
+    abits = wave_umax(__float_as_uint(am));
+    const float amax = __uint_as_float(abits);
+    const unsigned long long pos = __ballot(hi == amax), neg = __ballot(lo == -amax);
+    const unsigned long long both = pos | neg, first = both & (0ull - both);
+    unsigned mbits = abits ^ ((neg & first) ? 0x80000000u : 0u);
+    if ((pos & neg & first) != 0 && abits != 0) {
+        const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+        const float mine = a0 == amax ? v.x : (a1 == amax ? v.y : (a2 == amax ? v.z : v.w));
+        mbits = __float_as_uint(first_flagged(a0 == amax || a1 == amax || a2 == amax || a3 == amax, mine));
+    }
+    return __uint_as_float(mbits);
+}
+// min(127, nearest_int(iscale * x)) of the lane's four values, left as the BITS of 12582912 + q (the low byte is q's byte; q as a float is bits - 12582912.0f exactly).
+// Identical to the reference for every finite product.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void q8k_round4(const float4 &v, float iscale, uint32_t (&b)[4]) {
+    const f32x2_t s = {iscale, iscale}, magic = {12582912.0f, 12582912.0f};
+    const f32x2_t m01 = f32x2_t{v.x, v.y} * s + magic, m23 = f32x2_t{v.z, v.w} * s + magic;      // -ffp-contract=off: a product, then a sum (v_pk_mul_f32, v_pk_add_f32)
+    const uint32_t top = 0x4B40007Fu;      // bits of 12582912 + 127
+    b[0] = min(__float_as_uint(m01.x), top); b[1] = min(__float_as_uint(m01.y), top);
+    b[2] = min(__float_as_uint(m23.x), top); b[3] = min(__float_as_uint(m23.y), top);
+}
+__device__ __forceinline__ uint32_t q8k_bytes(const uint32_t (&b)[4]) {
+    return __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u) | __builtin_amdgcn_perm(b[3], b[2], 0x04000c0cu);
+}
+__device__ __forceinline__ int q8k_sum4(uint32_t bytes) { return __builtin_amdgcn_sdot4((int)bytes, 0x01010101, 0, false); }
+
 // expf exactly as the reference's attention gets it from glibc 2.35 libm on an AVX2+FMA x86-64 host (__expf_fma: N = 32 table,
 // cubic in double, kd = fma(InvLn2N, x, Shift), r = fma(InvLn2N, x, -(kd - Shift))); oracle/restate.c:orc_expf is the same
 // restatement and is checked against libm on ~10^9 arguments.  Finite or -inf arguments only.

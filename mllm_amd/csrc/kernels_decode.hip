@@ -155,16 +155,6 @@ __host__ __device__ static inline size_t act_lds_bytes(int K, bool with_xf) {
 //   * the two IEEE divisions (-128 / max, 1 / iscale) of all NB blocks are done once, block i in lane i, instead of NB times on uniform values;
 //   * iscale * x and the magic add (nearest_int) are the two-wide v_pk_mul_f32 / v_pk_add_f32; the byte of q IS the low byte of the sum's bits, so the clamp to 127
 //     is an unsigned min on the bits, the pack two v_perm + or, and q0+q1+q2+q3 one v_dot4 (identical for every finite input).
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned wave_umax(unsigned v) {
-    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_QUAD_X1, 0xF));
-    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_QUAD_X2, 0xF));
-    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_HALF_MIRROR, 0xF));
-    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_MIRROR, 0xF));
-    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_BCAST15, 0xA));
-    v = max(v, (unsigned)MH_DPP(0, (int)v, DPP_BCAST31, 0xC));
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
 template <int NB, int WPB>
 __device__ __forceinline__ void wave_quant_blocks(const float4 (&v)[NB], int lane, int wid, int nblk, const ActLds &a) {
     float hi[NB], lo[NB];

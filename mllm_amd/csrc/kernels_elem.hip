@@ -18,25 +18,14 @@ namespace mllm_hip {
 // q = min(127, nearest_int(iscale*x)); bsums over 16; d = 1/iscale.
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_quant_q8k(float4 v, int lane, int8_t *qs_blk, float *d_out, int16_t *bsums_blk) {
-    float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
-    float amax = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-    amax = wave_max(amax);
-    // the first element (in element order) that attains amax -- the reference's strict `>` scan keeps the first
-    const float mine = a0 == amax ? v.x : (a1 == amax ? v.y : (a2 == amax ? v.z : v.w));
-    const float mx = first_flagged(a0 == amax || a1 == amax || a2 == amax || a3 == amax, mine);
-    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    float dd = 0.0f;
-    if (amax != 0.0f) {
-        const float iscale = __fdiv_rn(-128.0f, mx);
-        q0 = min(127, nearest_int(__fmul_rn(iscale, v.x)));
-        q1 = min(127, nearest_int(__fmul_rn(iscale, v.y)));
-        q2 = min(127, nearest_int(__fmul_rn(iscale, v.z)));
-        q3 = min(127, nearest_int(__fmul_rn(iscale, v.w)));
-        dd = __fdiv_rn(1.0f, iscale);
-    }
-    const uint32_t packed = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+    unsigned abits;
+    const float mx = q8k_first_max(v, abits);      // the first element (in element order) that attains amax -- the reference's strict `>` scan keeps the first
+    const float iscale = abits ? __fdiv_rn(-128.0f, mx) : 0.0f, dd = abits ? __fdiv_rn(1.0f, iscale) : 0.0f;      // an all-zero block: every q = nearest_int(0 * x) = 0
+    uint32_t b[4];
+    q8k_round4(v, iscale, b);
+    const uint32_t packed = q8k_bytes(b);
     reinterpret_cast<uint32_t *>(qs_blk)[lane] = packed;
-    const int s = group4_sum(q0 + q1 + q2 + q3);
+    const int s = group4_sum(q8k_sum4(packed));
     if ((lane & 3) == 0) bsums_blk[lane >> 2] = (int16_t)s;
     if (lane == 0) *d_out = dd;
 }
@@ -50,28 +39,21 @@ typedef _Float16 v4h_t __attribute__((ext_vector_type(4)));
 #define QP_WAVES 8      // rows per workgroup of the quantise + pack launches (a 32-row tile is 4 workgroups)
 #endif
 __device__ __forceinline__ void wave_quant_pack(float4 v, int lane, bool live, uint8_t *pack, size_t tb, int nb, int m, int i) {
-    float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
-    float amax = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-    amax = wave_max(amax);
-    const float mine = a0 == amax ? v.x : (a1 == amax ? v.y : (a2 == amax ? v.z : v.w));
-    const float mx = first_flagged(a0 == amax || a1 == amax || a2 == amax || a3 == amax, mine);
-    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    float dd = 0.0f;
-    if (live && amax != 0.0f) {
-        const float iscale = __fdiv_rn(-128.0f, mx);
-        q0 = min(127, nearest_int(__fmul_rn(iscale, v.x)));
-        q1 = min(127, nearest_int(__fmul_rn(iscale, v.y)));
-        q2 = min(127, nearest_int(__fmul_rn(iscale, v.z)));
-        q3 = min(127, nearest_int(__fmul_rn(iscale, v.w)));
-        dd = __fdiv_rn(1.0f, iscale);
-    }
+    unsigned abits;
+    const float mx = q8k_first_max(v, abits);
+    const bool nz = live && abits != 0;
+    const float iscale = nz ? __fdiv_rn(-128.0f, mx) : 0.0f, dd = nz ? __fdiv_rn(1.0f, iscale) : 0.0f;
+    uint32_t b[4];
+    q8k_round4(v, iscale, b);
+    const f32x2_t unmagic = {-12582912.0f, -12582912.0f};
+    const f32x2_t q01 = f32x2_t{__uint_as_float(b[0]), __uint_as_float(b[1])} + unmagic, q23 = f32x2_t{__uint_as_float(b[2]), __uint_as_float(b[3])} + unmagic;      // q as floats, exactly
     const size_t tile = (size_t)(m >> 5) * nb + i;
     const int mi = m & 31, j = lane >> 4, hf = (lane >> 3) & 1, t = lane & 7;
     v4h_t o;
-    o[0] = (_Float16)(float)q0; o[1] = (_Float16)(float)q1; o[2] = (_Float16)(float)q2; o[3] = (_Float16)(float)q3;
+    o[0] = (_Float16)q01.x; o[1] = (_Float16)q01.y; o[2] = (_Float16)q23.x; o[3] = (_Float16)q23.y;
     *reinterpret_cast<v4h_t *>(pack + ((((tile * 8 + t) * 2 + (j >> 1)) * 64 + (j & 1) * 32 + mi) * 16) + hf * 8) = o;
     // q8s[k] = sum of the 32 values of 8-lane group k; lane 16u gathers (q8s[2u], q8s[2u+1]) -> (even part, low bit) pairs of Am
-    const int s8 = group8_sum(q0 + q1 + q2 + q3);
+    const int s8 = group8_sum(q8k_sum4(q8k_bytes(b)));
     const int s8n = MH_DPP(0, s8, 0x108 /* row_shl:8 */, 0xF);
     if ((lane & 15) == 0) {
         v4h_t mo;
