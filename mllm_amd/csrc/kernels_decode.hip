@@ -546,6 +546,51 @@ __device__ __forceinline__ void blk_emit(const char *blk, const ActLds &a, int b
     e[10] = make_float2(dm, (float)prod1); e[11] = make_float2(dm, (float)prod3);
 }
 
+// The same table entries by a PAIR of adjacent lanes: lane h = 0 / 1 takes nibble words j = 2h, 2h+1 (sub-blocks 4h .. 4h+3) and the mins of its four sub-blocks; the
+// integer class sums of the two halves are added across the pair by DPP (integer sums: any order), then lane 0 stores slots 0-3, 8, 10 and lane 1 slots 4-7, 9, 11.
+// For the down projection (6 rows x 35 super-blocks per workgroup of 512 lanes) this puts 420 lanes to work instead of 210 on an emit that is bound by one wave's
+// instruction stream (323 VALU per super-block; scratch/stamps_pjb.py).  Every lane of a quad must be active (the caller rounds the active range up).
+__device__ __forceinline__ void blk_emit_pair(const char *blk, const ActLds &a, int b, int h, float2 *e) {
+    const uint4 hdr = *reinterpret_cast<const uint4 *>(blk);
+    const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
+    uint32_t sc8[2], mn8[2];
+    unpack_q4k_scales(hdr.y, hdr.z, hdr.w, sc8, mn8);
+    const uint32_t sc = h ? sc8[1] : sc8[0], mn = h ? mn8[1] : mn8[0];
+    const int8_t *xb = a.qs + b * a.qstride + h * 128;
+    const char *qb = blk + 16 + h * 64;
+    int cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sl = (int)((sc >> (16 * j)) & 0xff), sh = (int)((sc >> (16 * j + 8)) & 0xff);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q0 = *reinterpret_cast<const u32x4 *>(qb + 32 * j), q1 = *reinterpret_cast<const u32x4 *>(qb + 16 + 32 * j);
+        const i32x4 xl0 = *reinterpret_cast<const i32x4 *>(xb + 64 * j), xl1 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 16);
+        const i32x4 xh0 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 32), xh1 = *reinterpret_cast<const i32x4 *>(xb + 64 * j + 48);
+        int lo[8], hi[8], xl[8], xh[8], dl[8], dh[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const unsigned q = t < 4 ? q0[t & 3] : q1[t & 3];
+            lo[t] = (int)(q & 0x0f0f0f0fu); hi[t] = (int)((q >> 4) & 0x0f0f0f0fu);
+            xl[t] = t < 4 ? xl0[t & 3] : xl1[t & 3]; xh[t] = t < 4 ? xh0[t & 3] : xh1[t & 3];
+        }
+        dot4z_x8(dl, lo, xl);
+        dot4z_x8(dh, hi, xh);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cls[t] = __mul24(sh, dh[t]) + (__mul24(sl, dl[t]) + cls[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) cls[t] += MH_DPP(0, cls[t], DPP_QUAD_X1, 0xF);
+    const int4 s4 = *reinterpret_cast<const int4 *>(a.q8s + b * 8 + 4 * h);
+    const int pa = __mul24((int)(mn & 0xff), s4.x) + __mul24((int)((mn >> 8) & 0xff), s4.y), pb = __mul24((int)((mn >> 16) & 0xff), s4.z) + __mul24((int)(mn >> 24), s4.w);
+    const float xd = a.d[b];
+    const float dy = xd * d, dm = (-xd) * dmin;      // VecDotQ4.cpp:228-229
+    float2 *eh = e + 4 * h;
+    eh[0] = make_float2(dy, (float)(h ? cls[1] : cls[0])); eh[1] = make_float2(dy, (float)(h ? cls[5] : cls[4]));
+    eh[2] = make_float2(dy, (float)(h ? cls[3] : cls[2])); eh[3] = make_float2(dy, (float)(h ? cls[7] : cls[6]));
+    e[8 + h] = make_float2(dm, (float)pa); e[10 + h] = make_float2(dm, (float)pb);
+}
+
 template <int PAIRS, int NV, int WPB>
 __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *__restrict__ x, const float *__restrict__ norm_w, float eps,
                                                                   const uint8_t *__restrict__ W, float *__restrict__ act, int I, int K) {
@@ -725,9 +770,11 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__r
     GSTAMP2(3);
     __syncthreads();
     GSTAMP2(4);
-    if (tid < RPW * nb) {
-        const int row = tid / nb, b = tid - row * nb;
-        blk_emit(stage + (size_t)tid * 144, a, b, tab + (size_t)tid * Q4K_SLOTS);
+    if (2 * RPW * nb <= 64 * WPB) {      // a lane pair per super-block (see blk_emit_pair)
+        const int sb = tid >> 1;
+        if (sb < RPW * nb) blk_emit_pair(stage + (size_t)sb * 144, a, sb % nb, tid & 1, tab + (size_t)sb * Q4K_SLOTS);
+    } else if (tid < RPW * nb) {
+        blk_emit(stage + (size_t)tid * 144, a, tid % nb, tab + (size_t)tid * Q4K_SLOTS);
     }
     GSTAMP2(5);
     __syncthreads();

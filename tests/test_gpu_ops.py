@@ -41,6 +41,11 @@ def test_quantize_q8k_bit_exact(M, K):
     if M > 1:
         x[1, :256] = 0                                        # all-zero block
         x[2, 5] = 7.25; x[2, 9] = -7.25                       # equal |x| with opposite sign: first one wins
+        if K >= 512:                                          # ... also inside one lane's four values (both orders), at the block's last value, and a value that clamps at 127
+            x[2, 256 + 40] = -30.0; x[2, 256 + 41] = 30.0
+            x[0, 256 + 42] = 30.0; x[0, 256 + 43] = -30.0; x[0, 256 + 3] = -30.0
+        if K >= 768:
+            x[2, 767] = -50.0; x[2, 600] = 49.9999
     q = ops.quantize_q8k(x)
     blocks = orc.quantize_q8_K(x).reshape(M, K // 256, 292)
     d = blocks[:, :, :4].copy().view(np.float32).reshape(M, K // 256)
@@ -93,6 +98,21 @@ def test_linear_q4k_gemv_signed_maximum_ties(K, N):
     if nb > 8:
         x[0, 8 * 256:9 * 256] = 0.0
         x[0, 9 * 256:10 * 256] = -0.0
+    y = ops.linear_q4k(Wq, x, N)
+    ref = orc.linear(x, Wq, orc.Q4_K, N)
+    assert eq(y, ref), md(y, ref)
+
+
+def test_linear_q4k_gemm_signed_maximum_ties():      # the same ties through the prefill quantiser that writes the GEMM's packed operand
+    M, K, N = 40, 768, 96
+    Wq, x, _ = _q4k_case(M, K, N, 99, bias=False)
+    x = np.clip(x, -2.0, 2.0)
+    for m in range(M):
+        for b in range(K // 256):
+            j = (m * 7 + b * 13) % 252
+            x[m, b * 256 + j] = 3.0 if (m + b) % 2 else -3.0
+            x[m, b * 256 + j + (1 if m % 3 else 9)] = -3.0 if (m + b) % 2 else 3.0
+    x[5, 256:512] = 0.0
     y = ops.linear_q4k(Wq, x, N)
     ref = orc.linear(x, Wq, orc.Q4_K, N)
     assert eq(y, ref), md(y, ref)
