@@ -9,7 +9,8 @@
 //     vec_dot_q4_K_q8_K's AVX2 lanes the integer sum of (nibble * 6-bit scale) x q8 -- all operands and partial sums exact in fp16 / fp32 --
 //     comes out of two MFMAs on pre-packed fp16 operands; the mins term sum_j mn_j * bsum_j is one more MFMA per pair of sub-blocks;
 //     the reference's per-super-block fp32 chain step acc = fma(d_x d_w, sum, acc) then runs on the VALU, so the result is bit-identical.
-//   fp32 weights (patch-embed conv, fp32 models): gemm_f32_kernel, vec_dot_fp32's 32 chains + ordered leftovers on the VALU.
+//   fp32 weights (patch-embed conv, fp32 models): gemm_f32_mfma_kernel -- vec_dot_fp32's 32 chains as 32 accumulator tiles of v_mfma_f32_16x16x4_f32 -- and, for
+//   shapes it does not take (M < 16, K < 128, K % 4), gemm_f32_kernel: the 32 chains + ordered leftovers on the VALU.
 #include <type_traits>
 #include <atomic>
 
@@ -679,6 +680,153 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             if (c == i * F32_TN + j && m0 + i < M && n0 + j < N) y[(int64_t)(m0 + i) * ldy + n0 + j] = bias ? acc[i][j] + bias[n0 + j] : acc[i][j];
 }
 
+// The same GEMM on the matrix cores.  vec_dot_fp32 keeps 32 chains per output (chain c takes k = c, c + 32, ...), and v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain
+// over its four k slots in slot order (scratch/mfma/test16.hip) -- so ONE accumulator tile per chain, fed k = 32 (4j + slot) + c at step j, advances chain c of 16 x 16
+// outputs by four links per instruction, in the reference's order.  A lane (row l & 15, slot l >> 4) needs the 32 consecutive floats x[row][128 j + 32 slot ..] and
+// w[row][...] of a step: they are the operands of the step's 32 MFMAs (one per chain).  Read straight from global memory each of a lane's eight 16-byte loads touches 64
+// different lines (94 us for the patch embedding, the L1's tag rate), so a step's 128 columns of the workgroup's 32 + 32 rows are staged through LDS (coalesced 512-byte
+// row pieces in, eight ds_read_b128 per lane and operand out, row pitch 132 floats: conflict-free), double-buffered, one barrier per step.  Wave = one 16 x 16 tile with
+// 32 x 4 accumulator registers; workgroup = 2 x 2 tiles.  Behind the MFMA steps: the K / 32 % 4 whole links that are left (VALU, in the C layout), the chain fold in the
+// order of the swizzle tree above (16, 8, 4, 1, 2), the K % 32 ordered leftovers, the bias.  Needs K % 4 == 0 and 16-byte aligned rows.
+typedef float f32mm_v4 __attribute__((ext_vector_type(4)));
+constexpr int F32MM_BLK = 1024 + 16;      // bytes of one staged pair of rows: 2 x 128 floats, their 128-byte lines interleaved (piece f of row 2p + b at slot 16 (f >> 3) + 8 b + (f & 7)), + 16
+__device__ __forceinline__ void f32mm_glds16(const void *gsrc, unsigned lds_dst_in) {
+    unsigned keep;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const float *__restrict__ W, const float *__restrict__ bias, const float *__restrict__ x,
+                                                               float *__restrict__ y, int64_t ldy, int M, int N, int K) {
+    // staged rows 0..31: x rows m0b .. m0b+31, rows 32..63: w rows n0b .. n0b+31.  LDS-DMA lands a wave instruction's 64 x 16 bytes contiguously, so an instruction
+    // takes the two rows of a pair with their 128-byte lines interleaved (eight adjacent lanes = one whole line) and the pairs are 16 bytes apart on top: the 16 rows a
+    // ds_read_b128 of one column piece meets then lie in 16 different groups of four banks (pair p at 4p, the odd row 32 further: conflict-free).  No staging registers
+    // (they would spill under 128 accumulators).  With 16-byte interleaving (adjacent lanes on alternating rows) the launch took 62 us: the loads did not coalesce.
+    __shared__ __attribute__((aligned(16))) char stage[2][32 * F32MM_BLK];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
+    const int m0b = blockIdx.y * 32, n0b = blockIdx.x * 32;
+    const int m0 = m0b + (wid >> 1) * 16, n0 = n0b + (wid & 1) * 16;
+    f32mm_v4 acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = f32mm_v4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int ni = K >> 5, nj = ni >> 2;
+    const float *src[8];      // wave w lands pairs 8w .. 8w+7: lane l takes piece 8 (l >> 4) + (l & 7) of row 2 pair + ((l >> 3) & 1)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int row = 2 * (8 * wid + g) + ((lane >> 3) & 1);
+        src[g] = (row < 32 ? x + (int64_t)min(m0b + row, M - 1) * K : W + (int64_t)min(n0b + row - 32, N - 1) * K) + 4 * (8 * (lane >> 4) + (lane & 7));
+    }
+    const unsigned st0 = (unsigned)(size_t)&stage[0][0];
+    auto land = [&](int j) {
+        const unsigned dst = st0 + (unsigned)((j & 1) * 32 * F32MM_BLK + 8 * wid * F32MM_BLK);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) f32mm_glds16(src[g] + 128 * j, dst + (unsigned)(g * F32MM_BLK));
+    };
+    if (nj > 0) land(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int rx = (wid >> 1) * 16 + l15, rw = 32 + (wid & 1) * 16 + l15;
+    const int xoff = (rx >> 1) * F32MM_BLK + (rx & 1) * 128 + 256 * q, woff = (rw >> 1) * F32MM_BLK + (rw & 1) * 128 + 256 * q;      // piece 8q + e at + 16 e bytes
+    for (int j = 0; j < nj; ++j) {
+        const char *cur = stage[j & 1];
+        if (j + 1 < nj) land(j + 1);
+        // operands in two halves of 16 chains (64 operand registers on top of 128 accumulators do not fit two waves per SIMD)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            float4 xc[4], wc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                xc[g] = *reinterpret_cast<const float4 *>(cur + xoff + 16 * (4 * hf + g));
+                wc[g] = *reinterpret_cast<const float4 *>(cur + woff + 16 * (4 * hf + g));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 16 * hf + 4 * g;
+                acc[c0 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[g].x, wc[g].x, acc[c0 + 0], 0, 0, 0);
+                acc[c0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[g].y, wc[g].y, acc[c0 + 1], 0, 0, 0);
+                acc[c0 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[g].z, wc[g].z, acc[c0 + 2], 0, 0, 0);
+                acc[c0 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[g].w, wc[g].w, acc[c0 + 3], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();      // step j + 1 has landed; nobody still reads step j's buffer when step j + 2 is requested into it
+    }
+    if (m0 >= M || n0 >= N) return;      // (after the last barrier: a tile wholly outside still helped staging)
+    // from here on in the C layout: this lane owns outputs (m0 + 4 q + r, n0 + l15), r = 0..3
+    const float *wn = W + (int64_t)min(n0 + l15, N - 1) * K;
+    const float *xm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xm[r] = x + (int64_t)min(m0 + 4 * q + r, M - 1) * K;
+    // (both tails request all their values first and then walk the links from registers: a loop of load -> fma pays a memory round trip per link -- with the
+    // patch embedding's 24 leftover columns that was 50 of the launch's 62 us)
+    for (int i = 4 * nj; i < ni; ++i) {      // whole links past the last full MFMA step
+        float4 wt[8], xt[4][8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            wt[g] = *reinterpret_cast<const float4 *>(wn + 32 * i + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xt[r][g] = *reinterpret_cast<const float4 *>(xm[r] + 32 * i + 4 * g);
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[4 * g + 0][r] = __fmaf_rn(wt[g].x, xt[r][g].x, acc[4 * g + 0][r]);
+                acc[4 * g + 1][r] = __fmaf_rn(wt[g].y, xt[r][g].y, acc[4 * g + 1][r]);
+                acc[4 * g + 2][r] = __fmaf_rn(wt[g].z, xt[r][g].z, acc[4 * g + 2][r]);
+                acc[4 * g + 3][r] = __fmaf_rn(wt[g].w, xt[r][g].w, acc[4 * g + 3][r]);
+            }
+        }
+    }
+    // the fold's first level, then the requests for the K % 32 leftover columns (a multiple of four; with all 32 accumulator tiles still live they would not fit), then the rest
+    f32mm_v4 s16[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s16[c] = acc[c] + acc[c + 16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(s16[c]));
+    const int nl4 = (K - 32 * ni) >> 2;
+    float4 wl[7], xl[4][7];
+    if (nl4 > 0) {
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+            const int gg = min(g, nl4 - 1);
+            wl[g] = *reinterpret_cast<const float4 *>(wn + 32 * ni + 4 * gg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xl[r][g] = *reinterpret_cast<const float4 *>(xm[r] + 32 * ni + 4 * gg);
+        }
+    }
+    f32mm_v4 v;
+    {
+        f32mm_v4 s8[8], s4[4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s8[c] = s16[c] + s16[c + 8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s4[c] = s8[c] + s8[c + 4];
+        v = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+    if (nl4 > 0) {
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+            if (g < nl4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = __fmaf_rn(wl[g].x, xl[r][g].x, v[r]);
+                    v[r] = __fmaf_rn(wl[g].y, xl[r][g].y, v[r]);
+                    v[r] = __fmaf_rn(wl[g].z, xl[r][g].z, v[r]);
+                    v[r] = __fmaf_rn(wl[g].w, xl[r][g].w, v[r]);
+                }
+            }
+        }
+    }
+    if (n0 + l15 < N) {
+        const float bv = bias ? bias[n0 + l15] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * q + r;
+            if (m < M) y[(int64_t)m * ldy + n0 + l15] = bias ? v[r] + bv : v[r];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // A7, eager-attention form: gemm_fp32 / gemm_fp32_fp16 (compute/GemmFp.hpp:104-150, :233-283) per head on BHSD operands.  One thread per output element (the
 // reference's order leaves every element its own chain over K); 64 consecutive columns per wave, so the row of B is one coalesced read and A's value a broadcast.
@@ -873,6 +1021,10 @@ extern "C" int mllm_hip_gemm_f32_bhsd(const float *a, const void *b, int b_dtype
 extern "C" int mllm_hip_linear_f32(const float *W, const float *bias, const float *x, float *y, int64_t ldy, int M, int N, int K, void *stream) {
     if (K <= 0 || N <= 0) return MLLM_HIP_ERR_SHAPE;
     if (M <= 0) return MLLM_HIP_OK;
+    if (M >= 16 && K >= 128 && K % 4 == 0 && (((uintptr_t)W | (uintptr_t)x) & 15) == 0 && (M + 31) / 32 <= 65535) {
+        hipLaunchKernelGGL(gemm_f32_mfma_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, as_stream(stream), W, bias, x, y, ldy, M, N, K);
+        return MH_LAUNCH_OK("gemm_f32_mfma");
+    }
     dim3 grid((N + 4 * F32_TN - 1) / (4 * F32_TN), (M + 2 * F32_TM - 1) / (2 * F32_TM));
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), W, bias, x, y, ldy, M, N, K);
     return MH_LAUNCH_OK("gemm_f32");

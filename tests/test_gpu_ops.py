@@ -231,6 +231,20 @@ def test_linear_f32_and_patch_convs(ops_gold):
     assert eq(y, orc.patch_gemm(px, W))
 
 
+# the fp32 Linear on the matrix cores (gemm_f32_mfma_kernel): ragged M / N tiles, K / 32 not a multiple of four (whole links left for the VALU), K % 32 leftovers, K % 4 != 0
+# and M < 16 (the VALU kernel), with and without bias
+@pytest.mark.parametrize("M,K,N,bias", [(64, 2048, 96, False), (50, 1176, 70, True), (17, 160, 33, True), (33, 224, 16, False), (40, 1000, 48, True), (16, 128, 16, False),
+                                        (20, 130, 24, True), (5, 2048, 64, True), (100, 96, 40, False)])
+def test_linear_f32_shapes_vs_oracle(M, K, N, bias):
+    r = rng(M * 31 + K + N)
+    W = (r.standard_normal((N, K)) * 0.05).astype(np.float32)
+    x = r.standard_normal((M, K)).astype(np.float32)
+    b = (r.standard_normal(N) * 0.1).astype(np.float32) if bias else None
+    y = ops.linear_f32(W, x, bias=b)
+    ref = orc.linear(x, W, orc.F32, N, b)
+    assert eq(y, ref), md(y, ref)
+
+
 # ---- A9 / A18 --------------------------------------------------------------------------------------------------------------
 def test_rmsnorm(ops_gold):
     g = ops_gold
