@@ -73,6 +73,10 @@ int mllm_hip_pool_free(void *dptr, void *stream);
  * still be in flight on `stream`.  mllm_hip_upload_release frees the staging buffers (they are created on first use). */
 int mllm_hip_upload(void *dst, const void *src_host, size_t nbytes, void *stream);
 int mllm_hip_upload_release(void);
+/* Page-lock a host buffer the caller keeps (hipHostRegister), so that the per-call copies into it -- the 608 KB logits row that Qwen2VLModel::Forward hands to the
+ * host sampler every token (modeling_qwen2_vl.hpp:399-403, Generate.hpp:156-224) -- are one DMA instead of a staged pageable copy.  Unregister before freeing it. */
+int mllm_hip_host_register(void *host, size_t nbytes);
+int mllm_hip_host_unregister(void *host);
 
 /* ---- A4: activation quantisation. quantize_row_q8_K_reference (ggml QuantizeQ8.cpp:216-251), quantize_row_q8_0_reference
  *      (:32-55), as called by mat_mul (compute/Matmul.cpp:77-120) ----------------------------------------------------- */

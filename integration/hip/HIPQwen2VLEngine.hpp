@@ -35,7 +35,10 @@ public:
         if (mllm_hip_model_create(&c, mllm_path.c_str(), &m_) != MLLM_HIP_OK) throw std::runtime_error(std::string("mllm_hip_model_create: ") + mllm_hip_last_error());
         Module::llm_model_ptr = this;
     }
-    ~HIPQwen2VLEngine() override { if (m_) mllm_hip_model_destroy(m_); }
+    ~HIPQwen2VLEngine() override {
+        if (pinned_) mllm_hip_host_unregister(pinned_);
+        if (m_) mllm_hip_model_destroy(m_);
+    }
     HIPQwen2VLEngine(const HIPQwen2VLEngine &) = delete;
     HIPQwen2VLEngine &operator=(const HIPQwen2VLEngine &) = delete;
 
@@ -48,7 +51,14 @@ public:
     std::vector<Tensor> Forward(std::vector<Tensor> inputs, std::vector<std::any>) override {
         Tensor &ids = inputs[0];
         const int S = ids.sequence();
-        logits_host_.resize(vocab_);
+        // the logits row lives in ONE host Tensor for the life of the Module (Tensor copies share their TensorImpl), page-locked once: a fresh 608 KB Tensor per
+        // token is an mmap, 150 page faults and a staged pageable copy -- together more than a tenth of the 0.9 ms step
+        if (!pinned_) {
+            out_ = Tensor(1, 1, 1, vocab_, Backend::global_backends[MLLM_CPU].get(), true);
+            out_.setName("lm_logits");
+            if (mllm_hip_host_register(out_.hostPtr<float>(), (size_t)vocab_ * sizeof(float)) == MLLM_HIP_OK) pinned_ = out_.hostPtr<float>();
+        }
+        float *logits = out_.hostPtr<float>();
         int32_t next = 0;
         int rc;
         if (S > 1) {
@@ -60,21 +70,19 @@ public:
                 pix = inputs[1].hostPtr<float>();      // [n_patch][3 * 2 * 14 * 14], contiguous (processing_qwen2_vl.hpp:249-252)
                 for (int d = 0; d < 3; ++d) meta[d] = (int32_t)inputs[2].dataAt<float>(0, 0, 0, d);
             }
-            rc = mllm_hip_model_prefill(m_, id.data(), S, pix, pix ? meta : nullptr, nullptr, 0, logits_host_.data(), &next, nullptr);
+            rc = mllm_hip_model_prefill(m_, id.data(), S, pix, pix ? meta : nullptr, nullptr, 0, logits, &next, nullptr);
         } else {
-            rc = mllm_hip_model_decode(m_, (int32_t)ids.dataAt<float>(0, 0, 0, 0), logits_host_.data(), &next, nullptr);
+            rc = mllm_hip_model_decode(m_, (int32_t)ids.dataAt<float>(0, 0, 0, 0), logits, &next, nullptr);
         }
         if (rc != MLLM_HIP_OK) throw std::runtime_error(std::string("HIPQwen2VLEngine::Forward: ") + mllm_hip_last_error());
-        Tensor out(1, 1, 1, vocab_, Backend::global_backends[MLLM_CPU].get(), true);
-        out.setName("lm_logits");
-        memcpy(out.hostPtr<float>(), logits_host_.data(), (size_t)vocab_ * sizeof(float));
-        return {out};
+        return {out_};
     }
 
 private:
     mllm_hip_model *m_ = nullptr;
     int vocab_;
-    std::vector<float> logits_host_;
+    Tensor out_;
+    float *pinned_ = nullptr;
 };
 
 }  // namespace mllm

@@ -158,6 +158,16 @@ extern "C" int mllm_hip_upload(void *dst, const void *src_host, size_t nbytes, v
     }
     return MLLM_HIP_OK;
 }
+extern "C" int mllm_hip_host_register(void *host, size_t nbytes) {
+    if (!host || !nbytes) return MLLM_HIP_ERR_ARG;
+    MH_CHECK(hipHostRegister(host, nbytes, hipHostRegisterDefault));
+    return MLLM_HIP_OK;
+}
+extern "C" int mllm_hip_host_unregister(void *host) {
+    if (!host) return MLLM_HIP_ERR_ARG;
+    MH_CHECK(hipHostUnregister(host));
+    return MLLM_HIP_OK;
+}
 extern "C" int mllm_hip_upload_release(void) {
     std::lock_guard<std::mutex> lock(g_stage.mu);
     for (int i = 0; i < 2; ++i) {

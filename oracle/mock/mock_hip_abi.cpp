@@ -44,6 +44,8 @@ int mllm_hip_stream_create(void **s) { *s = (void *)0x1; return 0; }
 int mllm_hip_stream_destroy(void *) { return 0; }
 int mllm_hip_h2d(void *d, const void *s, size_t n, void *) { memcpy(d, s, n); return 0; }
 int mllm_hip_upload(void *d, const void *s, size_t n, void *) { memcpy(d, s, n); return 0; }
+int mllm_hip_host_register(void *, size_t) { return 0; }
+int mllm_hip_host_unregister(void *) { return 0; }
 int mllm_hip_d2h(void *d, const void *s, size_t n, void *) { memcpy(d, s, n); return 0; }
 int mllm_hip_sync(void *) { return 0; }
 
