@@ -245,6 +245,21 @@ def test_linear_f32_shapes_vs_oracle(M, K, N, bias):
     assert eq(y, ref), md(y, ref)
 
 
+def test_host_register_round_trip():      # a page-locked host row is an ordinary copy target (the engine-backed Module keeps its logits Tensor registered)
+    import ctypes as C
+    L = lib.load()
+    host = np.zeros(151936, dtype=np.float32)
+    src = torch.arange(151936, dtype=torch.float32, device="cuda")
+    assert L.mllm_hip_host_register(C.c_void_p(host.ctypes.data), C.c_size_t(host.nbytes)) == 0
+    try:
+        assert L.mllm_hip_d2h(C.c_void_p(host.ctypes.data), C.c_void_p(src.data_ptr()), C.c_size_t(host.nbytes), None) == 0
+        assert L.mllm_hip_sync(None) == 0
+        assert np.array_equal(host, np.arange(151936, dtype=np.float32))
+    finally:
+        assert L.mllm_hip_host_unregister(C.c_void_p(host.ctypes.data)) == 0
+    assert L.mllm_hip_host_register(None, C.c_size_t(16)) != 0
+
+
 # ---- A9 / A18 --------------------------------------------------------------------------------------------------------------
 def test_rmsnorm(ops_gold):
     g = ops_gold
