@@ -4,11 +4,23 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float v16f __attribute__((ext_vector_type(16)));
-template <int MODE>      // bit 0: MFMA role runs, bit 1: fp64 role runs, bit 2: fp32 role runs
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+template <int MODE>      // bit 0: fp32 MFMA role runs, bit 1: fp64 role runs, bit 2: fp32 role runs, bit 3: the MFMA role issues f16 MFMAs (v_mfma_f32_32x32x16_f16) instead
 __global__ __launch_bounds__(512) void k(float *out, unsigned long long *t, int iters) {
     const int role = threadIdx.x >> 8;
     unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     if (role == 0) {
+        if (MODE & 8) {
+            v16f a0 = {0}, a1 = {0};
+            v8h x, y;
+            for (int e = 0; e < 8; ++e) { x[e] = (_Float16)(threadIdx.x * 1e-3f + e); y[e] = (_Float16)(1.0f + e * 0.25f); }
+            for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                for (int s = 0; s < 5; ++s) { a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a1, 0, 0, 0); }
+            }
+            out[threadIdx.x] = a0[0] + a1[3];
+        }
         if (MODE & 1) {
             v16f a0 = {0}, a1 = {0};
             float x = threadIdx.x * 1e-3f, y = 1.0f + threadIdx.x * 1e-4f;
@@ -56,5 +68,8 @@ int main() {
     run<4>("fp32 fma alone", out, t);
     run<3>("MFMA + fp64 fma", out, t);
     run<5>("MFMA + fp32 fma", out, t);
+    run<8>("f16 MFMA alone", out, t);
+    run<10>("f16 MFMA + fp64 fma", out, t);
+    run<12>("f16 MFMA + fp32 fma", out, t);
     return 0;
 }
