@@ -49,6 +49,17 @@ __global__ __launch_bounds__(512) void k(float *out, unsigned long long *t, int 
             }
             out[threadIdx.x] = d0 + d1 + d2 + d3;
         }
+        if (MODE & 16) {      // the same four fp32 chains as single v_fma_f32 (the compiler packs the plain form into v_pk_fma_f32)
+            float d0 = threadIdx.x * 1e-3f, d1 = 1.0f, d2 = 2.0f, d3 = 3.0f;
+            const float m = 1.0000001f, c = 1e-9f;
+            for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                for (int s = 0; s < 40; ++s) {
+                    asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(m), "v"(c));
+                }
+            }
+            out[threadIdx.x] = d0 + d1 + d2 + d3;
+        }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     if ((threadIdx.x & 63) == 0) t[threadIdx.x >> 6] = t1 - t0;
@@ -71,5 +82,8 @@ int main() {
     run<8>("f16 MFMA alone", out, t);
     run<10>("f16 MFMA + fp64 fma", out, t);
     run<12>("f16 MFMA + fp32 fma", out, t);
+    run<16>("single v_fma_f32 alone", out, t);
+    run<17>("MFMA + single v_fma_f32", out, t);
+    run<24>("f16 MFMA + single v_fma_f32", out, t);
     return 0;
 }
