@@ -155,8 +155,51 @@ __host__ __device__ static inline size_t act_lds_bytes(int K, bool with_xf) {
 //   * the two IEEE divisions (-128 / max, 1 / iscale) of all NB blocks are done once, block i in lane i, instead of NB times on uniform values;
 //   * iscale * x and the magic add (nearest_int) are the two-wide v_pk_mul_f32 / v_pk_add_f32; the byte of q IS the low byte of the sum's bits, so the clamp to 127
 //     is an unsigned min on the bits, the pack two v_perm + or, and q0+q1+q2+q3 one v_dot4 (identical for every finite input).
+// The form for one or two blocks per wave (q|k|v, o, gate|up: K / 256 <= 16 over 8 waves), where the quantiser is a single dependent chain and not an instruction count:
+// the per-instruction form below, with its ballots, 64-bit scalar mask arithmetic and uniform branch, is SLOWER there (same-box A/B: Qwen1.5-0.5B 1,688 -> 1,646 tok/s,
+// TinyLlama-1.1B 1,562 -> 1,478 with it in every kernel) -- it pays only where a wave quantises three or more blocks (the 8,960-wide down projection).
+template <int NB, int WPB>
+__device__ __forceinline__ void wave_quant_blocks_chain(const float4 (&v)[NB], int lane, int wid, int nblk, const ActLds &a) {
+    float amax[NB], mx[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) amax[i] = fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) amax[i] = wave_max(amax[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const float a0 = fabsf(v[i].x), a1 = fabsf(v[i].y), a2 = fabsf(v[i].z), a3 = fabsf(v[i].w);
+        const float mine = a0 == amax[i] ? v[i].x : (a1 == amax[i] ? v[i].y : (a2 == amax[i] ? v[i].z : v[i].w));
+        mx[i] = first_flagged(a0 == amax[i] || a1 == amax[i] || a2 == amax[i] || a3 == amax[i], mine);
+    }
+    int qsum[NB];
+    uint32_t packed[NB];
+    float dd[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const bool nz = amax[i] != 0.0f;
+        const float iscale = nz ? -128.0f / mx[i] : 0.0f;
+        const int q0 = min(127, nearest_int(iscale * v[i].x)), q1 = min(127, nearest_int(iscale * v[i].y));
+        const int q2 = min(127, nearest_int(iscale * v[i].z)), q3 = min(127, nearest_int(iscale * v[i].w));
+        dd[i] = nz ? 1.0f / iscale : 0.0f;
+        packed[i] = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+        qsum[i] = q0 + q1 + q2 + q3;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) qsum[i] = group8_sum(qsum[i]);   // 8 lanes = 32 values (bsums[2k] + bsums[2k+1])
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int blk = wid + WPB * i;
+        if (blk < nblk) {
+            reinterpret_cast<uint32_t *>(a.qs + blk * a.qstride)[lane] = packed[i];
+            if ((lane & 7) == 0) a.q8s[blk * 8 + (lane >> 3)] = qsum[i];
+            if (lane == 0) a.d[blk] = dd[i];
+        }
+    }
+}
+
 template <int NB, int WPB>
 __device__ __forceinline__ void wave_quant_blocks(const float4 (&v)[NB], int lane, int wid, int nblk, const ActLds &a) {
+    if constexpr (NB < 3) { wave_quant_blocks_chain<NB, WPB>(v, lane, wid, nblk, a); return; }
     float hi[NB], lo[NB];
     unsigned abits[NB], mbits[NB];      // wave-uniform: bits of amax (>= +0) and of the signed first maximum
 #pragma unroll
@@ -770,7 +813,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__r
     GSTAMP2(3);
     __syncthreads();
     GSTAMP2(4);
-    if (2 * RPW * nb <= 64 * WPB) {      // a lane pair per super-block (see blk_emit_pair)
+    if (RPW * nb > 64 && 2 * RPW * nb <= 64 * WPB) {      // a lane pair per super-block (see blk_emit_pair) once one wave no longer holds them all
         const int sb = tid >> 1;
         if (sb < RPW * nb) blk_emit_pair(stage + (size_t)sb * 144, a, sb % nb, tid & 1, tab + (size_t)sb * Q4K_SLOTS);
     } else if (tid < RPW * nb) {
