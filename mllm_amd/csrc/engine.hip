@@ -164,6 +164,7 @@ struct mllm_hip_model {
     mllm_hip_model_config c;
     hipStream_t st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int32_t *pin_tok = nullptr;      // two page-locked words: the token handed to a decode step, the token it produced (no pageable staging, no extra synchronisation)
     std::vector<void *> allocs, temps, vis_allocs;
     Loader ld;
     int D = 0, HD = 0, KVD = 0, QKV = 0;
@@ -521,7 +522,8 @@ extern "C" int mllm_hip_model_create(const mllm_hip_model_config *cfg, const cha
         m->KVD = c0.kv_heads * m->D;
         m->QKV = m->HD + 2 * m->KVD;
     }
-    if (hipStreamCreate(&m->st) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess || m->ld.init() != 0) {
+    if (hipStreamCreate(&m->st) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&m->pin_tok), 2 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess || m->ld.init() != 0) {
         mllm_hip_model_destroy(m); return MLLM_HIP_ERR_HIP;
     }
     int rc = create_impl(m, f);
@@ -569,6 +571,7 @@ extern "C" void mllm_hip_model_destroy(mllm_hip_model *m) {
     if (m->pin_img) (void)hipHostFree(m->pin_img);
     m->ld.destroy();
     for (int b = 0; b < 2; ++b) { if (m->vup[b]) (void)hipEventDestroy(m->vup[b]); if (m->vfree[b]) (void)hipEventDestroy(m->vfree[b]); }
+    if (m->pin_tok) (void)hipHostFree(m->pin_tok);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->st) (void)hipStreamDestroy(m->st);
@@ -889,10 +892,12 @@ static int arm_decode(M *m);
 
 static int finish(M *m, float *logits_host, int32_t *next_token, float *elapsed_ms) {
     HH(hipEventRecord(m->ev1, m->st));
-    HH(hipEventSynchronize(m->ev1));
+    // the copies ride the stream behind the step and ONE synchronisation covers the step and both of them
+    if (logits_host) HH(hipMemcpyAsync(logits_host, m->logits, (size_t)m->c.vocab * 4, hipMemcpyDeviceToHost, m->st));
+    if (next_token) HH(hipMemcpyAsync(m->pin_tok + 1, m->tok_dev, 4, hipMemcpyDeviceToHost, m->st));
+    HH(hipStreamSynchronize(m->st));
+    if (next_token) *next_token = m->pin_tok[1];
     if (elapsed_ms) HH(hipEventElapsedTime(elapsed_ms, m->ev0, m->ev1));
-    if (logits_host) HH(hipMemcpy(logits_host, m->logits, (size_t)m->c.vocab * 4, hipMemcpyDeviceToHost));
-    if (next_token) HH(hipMemcpy(next_token, m->tok_dev, 4, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1006,8 +1011,8 @@ static int resync_after_error(mllm_hip_model *m, int rc) {
 extern "C" int mllm_hip_model_decode(mllm_hip_model *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms) {
     if (!m || !m->has_llm || m->cache_len <= 0) return MLLM_HIP_ERR_ARG;
     if (m->cache_len + 1 > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + 1 > %d)\n", m->cache_len, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
-    HH(hipMemcpyAsync(&m->d_state->token, &token, 4, hipMemcpyHostToDevice, m->st));
-    HH(hipStreamSynchronize(m->st));
+    m->pin_tok[0] = token;      // (page-locked: the copy is stream-ordered and the word is not written again before finish() has synchronised)
+    HH(hipMemcpyAsync(&m->d_state->token, m->pin_tok, 4, hipMemcpyHostToDevice, m->st));
     HH(hipEventRecord(m->ev0, m->st));
     EH(launch_step(m));
     m->cache_len += 1;
