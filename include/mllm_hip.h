@@ -303,6 +303,8 @@ int mllm_hip_model_load_stats(const mllm_hip_model *m, float *total_ms, int64_t 
 int mllm_hip_model_memory_stats(const mllm_hip_model *m, int64_t *resident_bytes, int64_t *released_bytes);
 /* Module::clear_kvcache: KVCache sequence counters and RoPE position counters back to 0 (CPUKVCache.hpp:26-29, CPURoPE.hpp:63-65) */
 int mllm_hip_model_clear_kvcache(mllm_hip_model *m);
+/* tokens the KV cache holds (KVCache::getCacheSeqLen, CPUKVCache.hpp:22-25; mllm/Op.hpp:121-124): 0 on a fresh or cleared model; -1 for a NULL model */
+int mllm_hip_model_cache_len(const mllm_hip_model *m);
 /* One prefill forward.  ids: n_ids host ints.  image (optional, fp32, host or device memory): QWEN2VL pixel_values `[n_patch][3*2*14*14]` with
  * image_meta = grid_thw (3 ints); LLAVA one image `[H][C][W]` (CLIP img2Tensor layout, models/clip/processing_clip.hpp:28-44),
  * image_meta NULL.  visual_dev (optional, device fp32): the tower's output rows already computed (e.g. all-gathered from the ranks

@@ -106,6 +106,7 @@ void HIPBackend::copy_from_host(const DeviceMemory &dest, const void *src) {
     if (!dest.handle || !src || dest.size_in_bytes == 0) return;
     upload(dest.handle, src, dest.size_in_bytes);
     if (dest.size_in_bytes <= (64u << 10) && dest.size_in_bytes % 4 == 0) remember_host(dest.handle, (const float *)src, dest.size_in_bytes / 4);      // fact 3
+    else shadows_.erase(dest.handle);      // a larger upload into a handle that had a shadow: the shadow is stale now
 }
 void HIPBackend::copy_to_host(void *dest, const DeviceMemory &src) {
     if (!dest || !src.handle || src.size_in_bytes == 0) return;
@@ -294,6 +295,10 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
     op->setUp(input_tensors, out_tensors);
     op->execute(input_tensors, out_tensors);
     ++ops_run_;
+    // a shadow describes what the host uploaded; an Op that wrote the block on the device (in place, or into a recycled pool block) has made it stale
+    if (!shadows_.empty())
+        if (auto *hop = dynamic_cast<HIPOp *>(op); !hop || !hop->keeps_shadow())
+            for (const auto &out_tensor : out_tensors) shadows_.erase(out_tensor->device_memory().handle);
     vector<Tensor> results;
     for (const auto &out_tensor : out_tensors) results.push_back(*out_tensor);
     return results;

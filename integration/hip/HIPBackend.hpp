@@ -53,6 +53,9 @@ class HIPOp : public Op {
 public:
     HIPOp(Backend *bn, const std::string &name) : Op(bn, name) {}
     virtual bool host_inputs() const { return false; }
+    // the Op does not write its output on the device: a view of its input (F_VIEW, F_CLIP, F_TRANPOSE, F_FLATTEN, PARAMETER, KVCACHE) or a host upload whose shadow
+    // execute() registers itself (F_WHERE).  runOp drops the host shadow of every other Op's output block, which the device has just overwritten.
+    virtual bool keeps_shadow() const { return false; }
 
 protected:
     HIPBackend *hb() const;

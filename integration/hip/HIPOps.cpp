@@ -124,19 +124,25 @@ public:
     }
     ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode load(AbstructLoader &loader) override {
-        if (loader.getDataType(name() + ".weight") != MLLM_TYPE_Q4_0) throw std::runtime_error("HIPEmbeddingOp: only the Q4_0 table of *-q4_k.mllm files: " + name());
-        table_ = hb()->q40_table(loader, name() + ".weight", vocab_, hidden_);      // shared with the tied lm_head's PARAMETER
+        const DataType dt = loader.getDataType(name() + ".weight");
+        if (dt == MLLM_TYPE_Q4_0) table_ = hb()->q40_table(loader, name() + ".weight", vocab_, hidden_);      // shared with the tied lm_head's PARAMETER
+        else if (dt == MLLM_TYPE_F32) load_tensor(f32_, backend_, loader, name() + ".weight", vocab_, hidden_);      // CLIP's position_embedding (an "embeddings" name: fp32 in the file)
+        else throw std::runtime_error("HIPEmbeddingOp: Q4_0 or fp32 tables (what *-q4_k.mllm files hold): " + name());
         return MLLM_NO_ERROR;
     }
     ErrorCode execute(TensorList inputs, TensorList outputs) override {
         const int S = inputs[0]->batch() * inputs[0]->sequence();
-        if (S) HIPCHK(mllm_hip_embedding_q40((const float *)dptr(inputs[0]), (const uint8_t *)table_->qs, (const uint16_t *)table_->d, (float *)dptr(outputs[0]), S, hidden_, vocab_, hb()->stream()));
+        if (S == 0) return MLLM_NO_ERROR;
+        if (table_) HIPCHK(mllm_hip_embedding_q40((const float *)dptr(inputs[0]), (const uint8_t *)table_->qs, (const uint16_t *)table_->d, (float *)dptr(outputs[0]), S, hidden_, vocab_, hb()->stream()));
+        else HIPCHK(mllm_hip_gather_rows((const float *)f32_.device_memory().handle, hidden_, vocab_, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), hidden_, S, hidden_, 0, hb()->stream()));      // CPUEmbedding.cpp:46-60: a row copy
         return MLLM_NO_ERROR;
     }
+    ErrorCode free(TensorList, TensorList) override { if (!table_) f32_.free(); return MLLM_NO_ERROR; }
 
 private:
     int hidden_, vocab_;
     std::shared_ptr<HIPQ40Table> table_;
+    Tensor f32_;
 };
 
 // ---- PARAMETER: CPUParameter (op/CPUParameter.cpp; batch, seq, head, dim, Layer.hpp:904-918): hands out its weight.  The one on the hot path is the tied lm_head,
@@ -144,6 +150,7 @@ private:
 class HIPParameterOp final : public HIPOp {
 public:
     HIPParameterOp(Backend *bn, const string &name, int b, int h, int s, int d) : HIPOp(bn, name), b_(b), h_(h), s_(s), d_(d) {}
+    bool keeps_shadow() const override { return true; }
     ErrorCode reshape(TensorList, TensorList outputs) override {
         outputs[0]->reshape(b_, h_, s_, d_);
         return MLLM_NO_ERROR;
@@ -334,6 +341,7 @@ public:
 class HIPKVCacheOp final : public HIPOp {
 public:
     HIPKVCacheOp(Backend *bn, const string &name, int cache_max) : HIPOp(bn, name), cache_max_(cache_max) {}
+    bool keeps_shadow() const override { return true; }
     ErrorCode reshape(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->batch() == 1 && inputs[0]->dtype() == MLLM_TYPE_F32, "KVCACHE: batch 1, fp32 producer");
         if (cache_seq_len_ + inputs[0]->sequence() > cache_max_) {      // CPUKVCache.cpp:121-126
@@ -583,6 +591,7 @@ private:
 class HIPViewOp final : public HIPOp {
 public:
     HIPViewOp(Backend *bn, const string &name, int b, int h, int s, int d) : HIPOp(bn, name), b_(b), h_(h), s_(s), d_(d) {}
+    bool keeps_shadow() const override { return true; }
     ErrorCode reshape(TensorList inputs, TensorList outputs) override {
         auto &in = inputs[0];
         const bool five = in->ctype() == BCTHW;
@@ -632,6 +641,7 @@ private:
 class HIPClipSeqOp final : public HIPOp {
 public:
     HIPClipSeqOp(Backend *bn, const string &name, int a, int b, bool single) : HIPOp(bn, name), a_(a), b_(b), single_(single) {}
+    bool keeps_shadow() const override { return true; }
     ErrorCode reshape(TensorList inputs, TensorList outputs) override {
         const int S = inputs[0]->sequence();
         lo_ = a_ < 0 ? S + a_ : a_;
@@ -657,6 +667,7 @@ private:
 class HIPTransposeOp final : public HIPOp {
 public:
     HIPTransposeOp(Backend *bn, const string &name, Chl a, Chl b) : HIPOp(bn, name), a_(a), b_(b) {}
+    bool keeps_shadow() const override { return true; }
     ErrorCode reshape(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->ctype() == BSHD, "F_TRANPOSE: BSHD input");
         outputs[0]->transCopyShape(inputs[0]->shape());
@@ -674,6 +685,83 @@ public:
 
 private:
     Chl a_, b_;
+};
+
+// F_TRANPOSE with the pair list {(SEQUENCE, DIMENSION), (HEAD, SEQUENCE)}: how ViTEmbedding / LLaVAVisionEmbedding turn the patch convolution's output [1, oh, OC, ow]
+// (BSHD memory [OC][oh][ow]) into patch rows (models/vit/modeling_vit.hpp:78, models/llava/modeling_llava.hpp:54).  On the CPU it is a flip of the axis map the
+// producer then writes through (op/CPUTransposeFunc.hpp:53-86,106-119: ctype BDSH); the device keeps every activation contiguous BSHD, so here the data moves:
+// out (head = ow, sequence = oh, dimension = OC), memory [oh][ow][OC] = the transpose of [OC][oh * ow].
+class HIPPatchRowsTransposeOp final : public HIPOp {
+public:
+    HIPPatchRowsTransposeOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs[0]->ctype() == BSHD && inputs[0]->batch() == 1 && inputs[0]->dtype() == MLLM_TYPE_F32, "F_TRANPOSE {(S,D),(H,S)}: one fp32 BSHD image's patch grid");
+        outputs[0]->reshape(1, inputs[0]->dimension(), inputs[0]->head(), inputs[0]->sequence());
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        const int OC = inputs[0]->sequence(), N = inputs[0]->head() * inputs[0]->dimension();
+        if (OC && N) HIPCHK(mllm_hip_transpose_f32((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), OC, N, hb()->stream()));
+        return MLLM_NO_ERROR;
+    }
+};
+
+// F_FLATTEN (Tensor::flatten, op/CPUFlattenFunc.hpp:249-332; always called in place, Tensor.cpp:506-512): two neighbouring axes of a contiguous BSHD tensor become
+// one -- (HEAD, SEQUENCE): [b, h, s, d] -> [b, 1, s*h, d] (position s*H + h: the memory order); (HEAD, DIMENSION): -> [b, 1, s, h*d]; (BATCH, SEQUENCE) with one head:
+// -> [1, 1, b*s, d].  No data moves, as on the CPU (:297-300).
+class HIPFlattenOp final : public HIPOp {
+public:
+    HIPFlattenOp(Backend *bn, const string &name, Chl a, Chl b) : HIPOp(bn, name), a_(a), b_(b) {}
+    bool keeps_shadow() const override { return true; }
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        auto &in = inputs[0];
+        need(in->ctype() == BSHD, "F_FLATTEN: contiguous BSHD input (the 5-D forms are not on the five configs' path)");
+        int B = in->batch(), H = in->head(), S = in->sequence(), D = in->dimension();
+        if (a_ == HEAD && b_ == SEQUENCE) { S *= H; H = 1; }
+        else if (a_ == HEAD && b_ == DIMENSION) { D *= H; H = 1; }
+        else if (a_ == BATCH && b_ == SEQUENCE && H == 1) { S *= B; B = 1; }
+        else throw std::runtime_error("F_FLATTEN: axis pair not on this backend");
+        outputs[0]->reshape(B, H, S, D);
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
+        if (outputs[0].get() != inputs[0].get()) {
+            outputs[0]->setDtype(inputs[0]->dtype());
+            hb()->view_of(outputs[0], dptr(inputs[0]), inputs[0]->device_memory().size_in_bytes);
+        }
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    Chl a_, b_;
+};
+
+// F_CAT on SEQUENCE (Tensor::cat, op/CPUCatFunc.hpp:611-624: the one-head branch is a memcpy per input): the class row in front of the patch rows
+// (`Tensor::cat({cls_token(), embd}, SEQUENCE)`, modeling_vit.hpp:80, modeling_llava.hpp:56).  fp32 [1, 1, s_i, D] inputs; one pitched copy each.
+class HIPCatSeqOp final : public HIPOp {
+public:
+    HIPCatSeqOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        int S = 0;
+        for (auto &in : inputs) {
+            need(in->batch() == 1 && in->head() == 1 && in->dimension() == inputs[0]->dimension() && in->dtype() == MLLM_TYPE_F32 && in->dimension() % 4 == 0,
+                 "F_CAT(SEQUENCE): fp32 [1, 1, s, D] inputs of one width (a multiple of 4)");
+            S += in->sequence();
+        }
+        outputs[0]->reshape(1, 1, S, inputs[0]->dimension());
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        const int D = inputs[0]->dimension();
+        float *dst = (float *)dptr(outputs[0]);
+        for (auto &in : inputs) {
+            if (in->sequence()) HIPCHK(mllm_hip_copy_2d_f32((const float *)dptr(in), D, dst, D, in->sequence(), D, hb()->stream()));
+            dst += (size_t)in->sequence() * D;
+        }
+        return MLLM_NO_ERROR;
+    }
 };
 
 // F_SPLIT on DIMENSION (Tensor::split, op/CPUSplitFunc.hpp:32-172): the reference scatters the producer straight into the parts ("aggregated" children) or runs
@@ -748,6 +836,7 @@ public:
 class HIPWhereOp final : public HIPOp {
 public:
     HIPWhereOp(Backend *bn, const string &name, float value, int axis) : HIPOp(bn, name), value_(value), axis_(axis) {}
+    bool keeps_shadow() const override { return true; }
     ErrorCode reshape(TensorList inputs, TensorList outputs) override {
         auto &in = inputs[0];
         const std::vector<float> &v = hb()->host_floats(in);
@@ -797,6 +886,38 @@ public:
                                             inputs[0]->dimension(), hb()->stream()));
         return MLLM_NO_ERROR;
     }
+};
+// F_INDEX_PUT with accumulate = true (op/CPUIndexPutFunc.hpp:61-69,93-121): the LLaVA splice -- the ONE row of `dest` that holds the <image> id is replaced by all
+// rows of `value` [1, 1, R, D], so the sequence grows by R - 1 (`embd.index_put(vision, where_idx, true)`, modeling_llava.hpp:131).  A fresh output, three pitched
+// copies: the rows before the marker, the visual rows, the rows behind it.  The index is read from the host shadow of F_WHERE's upload (it shapes nothing here, but
+// the copies need it as a host integer).  One image per call: with more the reference's loop re-reads the first image's rows under a racing `omp parallel for`.
+class HIPIndexPutGrowOp final : public HIPOp {
+public:
+    HIPIndexPutGrowOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
+    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+        need(inputs.size() == 3 && inputs[1]->batch() == 1 && inputs[2]->dimension() == 1, "F_INDEX_PUT(accumulate): (dest, one image's rows, one index)");
+        auto &dst = inputs[0], &src = inputs[1];
+        need(dst->batch() == 1 && dst->head() == 1 && src->head() == 1 && dst->dimension() == src->dimension() && dst->dimension() % 4 == 0 && dst->dtype() == MLLM_TYPE_F32 &&
+                 src->dtype() == MLLM_TYPE_F32, "F_INDEX_PUT(accumulate): fp32 rows of one width (a multiple of 4), batch 1, one head");
+        at_ = (int)hb()->host_floats(inputs[2])[0];
+        need(at_ >= 0 && at_ < dst->sequence(), "F_INDEX_PUT(accumulate): index outside the destination");
+        outputs[0]->reshape(1, 1, dst->sequence() - 1 + src->sequence(), dst->dimension());
+        return MLLM_NO_ERROR;
+    }
+    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+        const int D = inputs[0]->dimension(), S = inputs[0]->sequence(), R = inputs[1]->sequence();
+        const float *dst = (const float *)dptr(inputs[0]), *src = (const float *)dptr(inputs[1]);
+        float *out = (float *)dptr(outputs[0]);
+        void *st = hb()->stream();
+        if (at_) HIPCHK(mllm_hip_copy_2d_f32(dst, D, out, D, at_, D, st));
+        if (R) HIPCHK(mllm_hip_copy_2d_f32(src, D, out + (size_t)at_ * D, D, R, D, st));
+        if (S - at_ - 1 > 0) HIPCHK(mllm_hip_copy_2d_f32(dst + (size_t)(at_ + 1) * D, D, out + (size_t)(at_ + R) * D, D, S - at_ - 1, D, st));
+        return MLLM_NO_ERROR;
+    }
+
+private:
+    int at_ = 0;
 };
 
 }  // namespace
@@ -877,11 +998,19 @@ void HIPBackend::registerOps() {
     };
     creators_[F_VIEW] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return new HIPViewOp(b, n, geti(p, "b"), geti(p, "h"), geti(p, "s"), geti(p, "d")); };
     creators_[F_TRANPOSE] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        if (geti(p, "num_pairs") == 2 && (Chl)geti(p, "axis1_0") == SEQUENCE && (Chl)geti(p, "axis2_0") == DIMENSION && (Chl)geti(p, "axis1_1") == HEAD && (Chl)geti(p, "axis2_1") == SEQUENCE)
+            return new HIPPatchRowsTransposeOp(b, n);      // the patch-grid -> patch-rows form of the ViT / CLIP embeddings
         if (geti(p, "num_pairs") != 1) return nullptr;
         const Chl a = (Chl)geti(p, "axis1_0"), c = (Chl)geti(p, "axis2_0");
         const bool sd = (a == SEQUENCE && c == DIMENSION) || (a == DIMENSION && c == SEQUENCE);
         return sd ? new HIPTransposeOp(b, n, a, c) : nullptr;      // the (HEAD, SEQUENCE) transposes of the eager-attention branch move data: not on this backend
     };
+    creators_[F_FLATTEN] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        const Chl a = (Chl)geti(p, "axis_start"), c = (Chl)geti(p, "axis_end");
+        const bool ok = (a == HEAD && (c == SEQUENCE || c == DIMENSION)) || (a == BATCH && c == SEQUENCE);
+        return ok ? new HIPFlattenOp(b, n, a, c) : nullptr;
+    };
+    creators_[F_CAT] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return (Chl)geti(p, "axis") == SEQUENCE ? new HIPCatSeqOp(b, n) : nullptr; };
     creators_[F_SPLIT] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
         if ((Chl)geti(p, "split_dim") != DIMENSION) return nullptr;      // HD / D_HD splits of fused in_proj layouts (Chl::HD, Types.hpp:139-140): not on the five configs' path
         std::vector<int> each;
@@ -890,7 +1019,10 @@ void HIPBackend::registerOps() {
     };
     creators_[F_MM] = [](HIPBackend *b, const OpParam &, const std::string &n) -> Op * { return new HIPMatmulOp(b, n); };
     creators_[F_WHERE] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return new HIPWhereOp(b, n, getf(p, "value"), geti(p, "axis", -1)); };
-    creators_[F_INDEX_PUT] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * { return geti(p, "accumulate") ? nullptr : new HIPIndexPutOp(b, n); };
+    creators_[F_INDEX_PUT] = [](HIPBackend *b, const OpParam &p, const std::string &n) -> Op * {
+        if (geti(p, "accumulate")) return new HIPIndexPutGrowOp(b, n);
+        return new HIPIndexPutOp(b, n);
+    };
 }
 
 }  // namespace mllm

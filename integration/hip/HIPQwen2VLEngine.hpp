@@ -28,7 +28,7 @@ public:
         c.rms_eps = (float)config.rms_norm_eps; c.final_eps = 1e-6f;      // model.norm: RMSNorm(hidden_dim, 1e-6, ...) (modeling_qwen2_vl.hpp:374)
         c.rope_theta = (float)config.rope_theta;
         for (int i = 0; i < 3; ++i) c.mrope_section[i] = config.mrope_section[i];
-        c.cache_limit = config.cache_limit; c.tie_embedding = 1; c.qkv_bias = 1;
+        c.cache_limit = config.cache_limit; c.tie_embedding = config.tie_embedding_words ? 1 : 0; c.qkv_bias = 1;      // tied embed_tokens head or a separate lm_head Linear (modeling_qwen2_vl.hpp:375-401)
         c.v_dim = config.vision_embed_dim; c.v_heads = 16; c.v_blocks = 32; c.v_patch = 14; c.v_merge = config.spatial_merge_size;      // Qwen2VisionModel(..., 16, ..., 14, 336, 32, ...) (:371)
         c.image_token_id = config.image_token_id; c.vision_start_token_id = config.vision_start_token_id;
         c.vision_end_token_id = config.vision_end_token_id; c.video_token_id = config.video_token_id;
@@ -47,7 +47,9 @@ public:
     void clear_kvcache() { mllm_hip_model_clear_kvcache(m_); }
 
     // inputs: input_ids [1, 1, S, 1] (floats holding the ids), pixel_values [n_patch, 3, 2, 14, 14] or empty, image_grid_thw [1, 1, 1, 3] or empty.
-    // S > 1: a prefill of these ids (with the image, if one is handed over); S == 1: one decode step for this token.  Returns {logits [1, 1, 1, vocab]} on the CPU backend.
+    // An empty cache or S > 1: a prefill of these ids (with the image, if one is handed over); S == 1 on a filled cache: one decode step for this token.
+    // Returns {logits [1, 1, 1, vocab]} on the CPU backend -- the SAME page-locked Tensor every call (a caller that keeps the logits of an earlier step copies them:
+    // the reference hands out a fresh Tensor per Forward).
     std::vector<Tensor> Forward(std::vector<Tensor> inputs, std::vector<std::any>) override {
         Tensor &ids = inputs[0];
         const int S = ids.sequence();
@@ -61,7 +63,7 @@ public:
         float *logits = out_.hostPtr<float>();
         int32_t next = 0;
         int rc;
-        if (S > 1) {
+        if (S > 1 || mllm_hip_model_cache_len(m_) == 0) {
             std::vector<int32_t> id(S);
             for (int i = 0; i < S; ++i) id[i] = (int32_t)ids.dataAt<float>(0, 0, i, 0);
             const float *pix = nullptr;

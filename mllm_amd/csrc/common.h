@@ -9,6 +9,7 @@
 namespace mllm_hip {
 
 void set_error(const char *what, hipError_t e, const char *file, int line);
+void set_error_msg(const char *fmt, ...);      // a formatted message for mllm_hip_last_error() that is not a HIP error (shape / argument refusals)
 int check_launch(const char *what, const char *file, int line);
 
 #define MH_CHECK(expr)                                                        \

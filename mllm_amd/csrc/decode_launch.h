@@ -45,6 +45,8 @@ struct DecodeCtx {
     int vt_ld;
     int n_layers;                       // entries of the DecodeLayer array handed to the launchers
     const WeightWarm *warm_tab;         // device, [n_layers] (decode_warm_table), or nullptr: no warming workgroups in the attention launch
+    int attn_flags;                     // decode_attn_flags() as it stood when the model was created: the warming table was built for these, and every launch of this
+                                        // model uses them (option "attn_flags" must be set before mllm_hip_model_create; a later change does not reach a live model)
 };
 
 // raw Q4_K rows -> decode order: the nibble dwords of every super-block transposed so that a lane's 16 bytes are one column class (q4k_dot.h)

@@ -209,7 +209,7 @@ struct mllm_hip_model {
     float *dec_sin = nullptr, *dec_cos = nullptr, *part_val = nullptr, *cur_sin = nullptr, *cur_cos = nullptr;
     int *part_idx = nullptr, *history = nullptr;
     int nsplit = 0, max_parts = 4096, dec_rows = 0;
-    DecodeCtx dctx;
+    DecodeCtx dctx{};
     std::vector<DecodeLayer> dlayers;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -466,6 +466,7 @@ static int create_impl(M *m, const MllmFile &f) {
         {      // the attention launch's weight-warming regions, one entry per layer (read when the model is created: the captured graph holds the pointer)
             std::vector<WeightWarm> tab(m->dlayers.size());
             const int fl = decode_attn_flags();
+            d.attn_flags = fl;
             d.warm_tab = nullptr;
             if ((fl & 1) && !(fl & 4) && decode_warm_table(d, m->dlayers.data(), (int)m->dlayers.size(), fl, tab.data()) > 0) {
                 WeightWarm *dev = nullptr;
@@ -578,6 +579,7 @@ extern "C" void mllm_hip_model_destroy(mllm_hip_model *m) {
     delete m;
 }
 extern "C" int mllm_hip_model_clear_kvcache(mllm_hip_model *m) { if (!m) return MLLM_HIP_ERR_ARG; m->cache_len = 0; m->last_pos = -1.0f; return MLLM_HIP_OK; }
+extern "C" int mllm_hip_model_cache_len(const mllm_hip_model *m) { return m ? m->cache_len : -1; }
 extern "C" int64_t mllm_hip_model_decode_weight_bytes(const mllm_hip_model *m) { return m ? m->decode_weight_bytes : 0; }
 extern "C" void *mllm_hip_model_stream(mllm_hip_model *m) { return m ? (void *)m->st : nullptr; }
 // bring-up aid (not part of include/mllm_hip.h): device pointers of the prefill activations, 0 h0, 1 h1, 2 qkv, 3 attn, 4 gate|up, 5 act
@@ -739,6 +741,13 @@ static int forward_vision(M *m, const float *pix, const int32_t *meta, float *ou
     if (m->vkind == V_QWEN2VL) {
         const int N = meta[0] * meta[1] * meta[2], PE = 3 * 2 * c.v_patch * c.v_patch;
         const int VD = V / c.v_heads, MM = V * c.v_merge * c.v_merge, NT = NB * (N / (c.v_merge * c.v_merge)), R = NB * N;
+        // the tower's Linears are resident in the packed (M >= 16) form only: a pass needs 16 patch rows.  The reference's default min_pixels (56 x 56 = a 4 x 4 grid,
+        // processing_qwen2_vl.hpp:84-109) never makes fewer; the C ABI takes any grid, so say it here instead of failing inside the first block
+        if (meta[0] <= 0 || meta[1] <= 0 || meta[2] <= 0 || meta[1] % c.v_merge || meta[2] % c.v_merge || R < 16) {
+            set_error_msg("mllm_hip vision tower: grid_thw = (%d, %d, %d) x %d image(s): needs positive multiples of the merge size %d and at least 16 patches per pass", meta[0], meta[1],
+                          meta[2], NB, c.v_merge);
+            return MLLM_HIP_ERR_SHAPE;
+        }
         {   // rotary tables (CPUVisionRoPE): rot_dim = head_dim/2
             std::vector<float> s((size_t)N * (VD / 2)), co((size_t)N * (VD / 2));
             EH(mllm_hip_vision_rope_table(meta[0], meta[1], meta[2], c.v_merge, VD / 2, s.data(), co.data()));

@@ -766,6 +766,9 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const float *__restr
 // contiguous run of RPW * K/256 super-blocks, disk layout) go to LDS by LDS-DMA, issued once the activation row has arrived and
 // running underneath its quantisation; lane g of the workgroup owns super-block g of the run; RPW / 4 waves walk the chains.
 __host__ __device__ static inline size_t pjb_stage_bytes(int rpw, int nb) { return ((size_t)rpw * nb * 144 + 1023) & ~(size_t)1023; }
+// rows per workgroup of the lane-per-super-block projection (dec_proj_blk): ONE definition for the launchers and for the warming table of the attention launch, whose
+// regions must be the consumer workgroups' row groups (eight waves walk four rows' chains each: at most 32 rows per workgroup)
+static inline int pjb_rows_per_wg(int N, int K) { return std::max(1, std::min(std::min(512 / (K / 256), 32), (N + 255) / 256)); }
 static inline size_t pjb_lds_bytes(int K, int rpw) {
     return ((gub_act_bytes(K) + 15) & ~(size_t)15) + pjb_stage_bytes(rpw, K / 256) + (size_t)rpw * (K / 256) * Q4K_SLOTS * 8;
 }
@@ -1249,7 +1252,7 @@ static int launch_proj(const uint8_t *W, const uint8_t *Wraw, const float *xin, 
     const int pjb_min_ns = option(OPT_PJB_MIN_NS) >= 0 ? option(OPT_PJB_MIN_NS) : 3;   // short rows: the 8-lane kernel is faster
     {
         const int nb = K >> 8;
-        const int rpw = std::max(1, std::min(std::min(512 / nb, 32), (N + 255) / 256));
+        const int rpw = pjb_rows_per_wg(N, K);
         if (NS >= pjb_min_ns && NS <= 5 && Wraw && !pjb_off && N >= rpw) {
             constexpr int BW = 8, NQ = NS;
             const size_t blds = pjb_lds_bytes(K, rpw);
@@ -1275,7 +1278,7 @@ static int launch_proj(const uint8_t *W, const uint8_t *Wraw, const float *xin, 
 int dec_linear_row_q4k(const void *Wraw, const float *x, const float *addend, float *y, int N, int K, hipStream_t st) {
     if (K <= 0 || K % 256 || N <= 0) return 1;
     const int nb = K >> 8, nsr = (nb + 7) / 8;
-    const int rpw = std::max(1, std::min(std::min(512 / nb, 32), (N + 255) / 256));      // eight waves walk four rows' chains each: at most 32 rows per workgroup
+    const int rpw = pjb_rows_per_wg(N, K);
     if (nsr > 5 || N < rpw) return 1;
     const size_t lds = pjb_lds_bytes(K, rpw);
 #define ROW_CASE(NSV)                                                                                                                                     \
@@ -1346,7 +1349,7 @@ int decode_warm_table(const DecodeCtx &c, const DecodeLayer *layers, int n_layer
                 if (cnt <= 8 * WeightWarm::GROUPS && ww.n < WeightWarm::MAXR) { ww.base[ww.n] = layers[li + 1].Wqkv; ww.bytes[ww.n] = per; ww.count[ww.n] = cnt; ++ww.n; }
             }
             if ((flags & 32) && ww.n < WeightWarm::MAXR) {      // dec_proj_blk (down): workgroup g = rows [g * rpw, + rpw)
-                const int rpw = std::max(1, std::min(512 / nbI, (c.H + 255) / 256)), cnt = (c.H + rpw - 1) / rpw;
+                const int rpw = pjb_rows_per_wg(c.H, nbI * 256), cnt = (c.H + rpw - 1) / rpw;
                 if (cnt <= 8 * WeightWarm::GROUPS && c.H % rpw == 0) { ww.base[ww.n] = L.Wdown_raw; ww.bytes[ww.n] = rpw * nbI * 144; ww.count[ww.n] = cnt; ++ww.n; }
             }
         }
@@ -1365,7 +1368,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
     case 0:
     {
         // bit 3 of the attention flags (set by default): dec_qkv warms the L2 with the layer's cache rows for the attention launch that follows
-        const int aflags = decode_attn_flags();
+        const int aflags = c.attn_flags;
         KvWarm kw{nullptr, nullptr, nullptr, c.kv_heads, c.D, c.kv_heads * c.D, c.vt_ld, c.cache_limit};
         if ((aflags & 8) && (aflags & 1) && c.kv_heads <= 8) {
             kw.kslab = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D;
@@ -1380,7 +1383,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
         // bit 0: XCD placement of a K/V group's heads, bit 1: two-stage key fetch (both neutral in time at T = 290..430, profiles/r02_attn_experiments.md;
         // the second keeps the fetched bytes near the algorithmic ones at short contexts)
-        const int flags = decode_attn_flags();
+        const int flags = c.attn_flags;
         const int ds_env = option(OPT_ATTN_DS) > 0 ? option(OPT_ATTN_DS) : 0;     // workgroups per head (1, 2 or 4); 0 = default
         const int ds = ds_env == 1 || ds_env == 2 || ds_env == 4 ? ds_env : 2;
         const dim3 grid((flags & 1) ? dec_attn_grid(c.heads, c.kv_heads, ds) : c.heads * ds);

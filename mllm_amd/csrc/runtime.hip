@@ -5,6 +5,8 @@
 #include <cstring>
 #include <mutex>
 
+#include <cstdarg>
+
 #include "common.h"
 
 namespace mllm_hip {
@@ -12,6 +14,12 @@ static thread_local char g_err[512] = "";
 
 void set_error(const char *what, hipError_t e, const char *file, int line) {
     snprintf(g_err, sizeof(g_err), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+}
+void set_error_msg(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
 }
 int check_launch(const char *what, const char *file, int line) {
     hipError_t e = hipGetLastError();

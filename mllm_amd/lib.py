@@ -224,6 +224,10 @@ class Model:
     def clear_kvcache(self):
         check(load().mllm_hip_model_clear_kvcache(self._h))
 
+    def cache_len(self) -> int:
+        """Tokens the KV cache holds (0 on a fresh or cleared model)."""
+        return int(load().mllm_hip_model_cache_len(self._h))
+
     def load_stats(self):
         tot, h2d, tail, nb = C.c_float(), C.c_float(), C.c_float(), C.c_int64()
         check(load().mllm_hip_model_load_stats(self._h, C.byref(tot), C.byref(nb), C.byref(h2d), C.byref(tail)), "load_stats")

@@ -1,10 +1,16 @@
 """Seeded synthetic weights / inputs for the hot-path configs (SURVEY §8d "Synthetic inputs").
 
 No model weights ship with the reference and there is no network, so every measurement and parity case runs on
-synthetic tensors: ``W ~ N(0, 0.02^2)`` fp32, norm weights = 1, biases = ``0.01*N(0,1)``, each tensor drawn from
-``numpy.random.default_rng(20251031 + crc32(name))``.  Tensor names follow the reference's name configs
+synthetic tensors, each drawn from ``numpy.random.default_rng(20251031 + crc32(name))``: norm weights = 1, biases =
+``0.01*N(0,1)`` fp32, fp32-stored weights ``N(0, 0.02^2)``.  Weights the file stores as Q4_K / Q4_0 are drawn
+DIRECTLY IN THE QUANTISED DOMAIN (``q4k_blocks`` / ``q40_blocks``: seeded block scales, 6-bit sub-block scales / mins
+and nibbles chosen so that the dequantised weights have zero mean and a standard deviation of about 0.02) -- there is
+no fp32 original and no quantiser anywhere in this repository; what both the reference (for the goldens) and the HIP
+path consume is the same file, byte for byte.  Tensor names follow the reference's name configs
 (mllm/models/qwen/configuration_qwen.hpp:28-47, mllm/models/qwen2_vl/configuration_qwen2_vl.hpp:20-32).
-The per-name storage dtype policy restates tools/quantizer/QuantWriter.cpp:10-35,123-157 for a Q4_K target.
+The per-name storage dtype policy restates tools/quantizer/QuantWriter.cpp:10-35,123-157 for a Q4_K target; the block
+layouts are mllm/DataType.hpp:75-78 (block_q4_0) and :93-98 (block_q4_K; 6-bit packing as read by
+dequantize_row_q4_K, third_party/ggml/QuantizeQ4.cpp:295-333).
 """
 from __future__ import annotations
 
@@ -99,6 +105,81 @@ def tensor_f32(name: str, shape: Tuple[int, ...], kind: str) -> np.ndarray:
     x = rng.standard_normal(n, dtype=np.float32)
     x *= np.float32(0.01 if kind == "bias" else 0.02)
     return x
+
+
+def _bell_nibbles(rng: np.random.Generator, shape) -> np.ndarray:
+    """Nibbles 0..15 with a triangular (bell-like) distribution, mean 7.75, standard deviation 3.3: the rounded mean of the two halves of a random byte."""
+    b = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    return ((b & 15) + (b >> 4) + 1) >> 1
+
+
+Q_MEAN = 7.75      # mean of _bell_nibbles
+Q_STD = 3.3
+
+
+def q4k_blocks(rng: np.random.Generator, nblk: int, std: float = 0.02, full_range: bool = False) -> np.ndarray:
+    """`nblk` block_q4_K super-blocks (144 B / 256 weights) drawn in the quantised domain, uint8 [nblk][144].
+    w = d * sc_j * q - dmin * m_j per 32-weight sub-block j: sc_j in 20..63, m_j ~ 7.75 * sc_j / 8 (+-2) with dmin ~ 8 d, so a sub-block's weights centre on
+    zero; d is set for a standard deviation of `std` at the mean scale and jitters by +-25 % per super-block.
+    full_range (op tests): every field over its whole range instead -- scales and mins 0..63, uniform nibbles, d and dmin from 0 (every 16th block) to 4x the nominal."""
+    out = np.empty((nblk, 144), dtype=np.uint8)
+    if full_range:
+        sc = rng.integers(0, 64, size=(nblk, 8), dtype=np.uint8)
+        m = rng.integers(0, 64, size=(nblk, 8), dtype=np.uint8)
+        d = (np.float32(std / (Q_STD * 41.5)) * rng.uniform(0.0, 4.0, size=nblk).astype(np.float32)).astype(np.float16)
+        dmin = (np.float32(8 * std / (Q_STD * 41.5)) * rng.uniform(0.0, 4.0, size=nblk).astype(np.float32)).astype(np.float16)
+        d[::16] = 0
+        dmin[8::16] = 0
+    else:
+        sc = rng.integers(20, 64, size=(nblk, 8), dtype=np.uint8)
+        m = np.clip(np.rint(sc.astype(np.float32) * np.float32(Q_MEAN / 8)).astype(np.int32) + rng.integers(-2, 3, size=(nblk, 8)), 0, 63).astype(np.uint8)
+        d = (np.float32(std / (Q_STD * 41.5)) * rng.uniform(0.8, 1.25, size=nblk).astype(np.float32)).astype(np.float16)
+        dmin = (d.astype(np.float32) * np.float32(8) * rng.uniform(0.95, 1.05, size=nblk).astype(np.float32)).astype(np.float16)
+    out[:, 0:2] = d.view(np.uint8).reshape(nblk, 2)
+    out[:, 2:4] = dmin.view(np.uint8).reshape(nblk, 2)
+    # 12 bytes of 6-bit fields: bytes 0..3 = sc[0..3] | (sc[4..7] >> 4) << 6, bytes 4..7 = m[0..3] | (m[4..7] >> 4) << 6, bytes 8..11 = sc[4..7] & 15 | (m[4..7] & 15) << 4
+    out[:, 4:8] = sc[:, :4] | ((sc[:, 4:] >> 4) << 6)
+    out[:, 8:12] = m[:, :4] | ((m[:, 4:] >> 4) << 6)
+    out[:, 12:16] = (sc[:, 4:] & 15) | ((m[:, 4:] & 15) << 4)
+    out[:, 16:] = rng.integers(0, 256, size=(nblk, 128), dtype=np.uint8) if full_range else _bell_nibbles(rng, (nblk, 128)) | (_bell_nibbles(rng, (nblk, 128)) << 4)
+    return out
+
+
+def q40_blocks(rng: np.random.Generator, nblk: int, std: float = 0.02, full_range: bool = False) -> np.ndarray:
+    """`nblk` block_q4_0 blocks (fp16 d + 16 nibble bytes; w = (q - 8) d), uint8 [nblk][18], standard deviation about `std`.
+    full_range (op tests): uniform nibbles, d of either sign (a real quantiser stores max / -8) from 0 (every 16th block) to 4x the nominal."""
+    out = np.empty((nblk, 18), dtype=np.uint8)
+    if full_range:
+        d = (np.float32(std / Q_STD) * rng.uniform(-4.0, 4.0, size=nblk).astype(np.float32)).astype(np.float16)
+        d[::16] = 0
+        nib = rng.integers(0, 256, size=(nblk, 16), dtype=np.uint8)
+    else:
+        d = (np.float32(std / Q_STD) * rng.uniform(0.8, 1.25, size=nblk).astype(np.float32)).astype(np.float16)
+        nib = _bell_nibbles(rng, (nblk, 16)) | (_bell_nibbles(rng, (nblk, 16)) << 4)
+    out[:, 0:2] = d.view(np.uint8).reshape(nblk, 2)
+    out[:, 2:] = nib
+    return out
+
+
+def quantized_blocks(dtype: int, rng: np.random.Generator, n_elem: int, std: float = 0.02, full_range: bool = False) -> np.ndarray:
+    """Flat uint8 bytes of `n_elem` weights stored as `dtype` (Q4_K or Q4_0), drawn in the quantised domain."""
+    be, _ = mf.BLOCK[dtype]
+    if n_elem % be:
+        raise ValueError(f"{n_elem} elements do not fill {mf.DTYPE_NAME[dtype]} blocks of {be}")
+    if dtype == mf.Q4_K:
+        return q4k_blocks(rng, n_elem // be, std, full_range).ravel()
+    if dtype == mf.Q4_0:
+        return q40_blocks(rng, n_elem // be, std, full_range).ravel()
+    raise ValueError(f"no quantised-domain synthesiser for dtype {dtype}")
+
+
+def tensor_stored(name: str, shape: Tuple[int, ...], kind: str, target: int = mf.Q4_K) -> Tuple[int, np.ndarray]:
+    """(storage dtype, bytes / fp32 values) of one synthetic tensor as a `*-q4_k.mllm` (or fp32) file holds it."""
+    dt = storage_dtype(name, target)
+    if dt == mf.F32:
+        return dt, tensor_f32(name, shape, kind)
+    rng = np.random.default_rng(SEED0 + zlib.crc32(name.encode()))
+    return dt, quantized_blocks(dt, rng, int(np.prod(shape)))
 
 
 def qwen2vl_tensors(c: Qwen2VLConfig, vision: bool = True) -> Iterator[Tuple[str, Tuple[int, ...], str]]:

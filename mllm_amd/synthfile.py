@@ -1,8 +1,8 @@
-"""TEST FIXTURE TOOLING, not product: builds synthetic `*-q4_k.mllm` files with the fixture quantiser (tests/fixtures/quantlib.py; no dependency on the reference tool at run time).
+"""Writes the synthetic `*-q4_k.mllm` (or fp32) weight files every test, the bench and the golden generator run on.
 
-Same per-name dtype policy and block formats as `quantize <in> <out> Q4_K` of the reference
-(tools/quantizer/QuantWriter.cpp:123-157,288-300); byte-for-byte agreement with it is pinned by tests/test_host.py
-(digests of files the reference tool wrote, tests/golden/*_digests.json).
+The tensors come from mllm_amd/synth.py -- Q4_K / Q4_0 tensors drawn directly in the quantised domain, fp32 ones as seeded normals -- under the per-name dtype policy
+of the reference's `quantize <in> <out> Q4_K` (tools/quantizer/QuantWriter.cpp:123-157), in the container format of mllm_amd/mllmfile.py (mllm/ParamLoader.cpp:14-31).
+No quantiser is involved: the reference (oracle/make_golden.py, in the development container) and the HIP path read the same bytes.
 """
 from __future__ import annotations
 
@@ -11,21 +11,21 @@ import os
 
 import numpy as np
 
-from mllm_amd import mllmfile as mf, synth
+from . import mllmfile as mf, synth
 
-from . import quantlib
+
+TAG = "q4k-qd1"      # file-name tag of the synthesis scheme (quantised-domain draw, version 1): a cached file of another scheme is never picked up
 
 
 def _make_tensor(args):
     name, shape, kind, target = args
-    x = synth.tensor_f32(name, shape, kind)
-    dt = synth.storage_dtype(name, target)
-    return name, dt, (x if dt == mf.F32 else quantlib.quantize(dt, x))
+    dt, data = synth.tensor_stored(name, shape, kind, target)
+    return name, dt, data
 
 
 def build_q4k_file(path: str, specs, target: int = mf.Q4_K, workers: int | None = None) -> str:
-    """Synthesise + quantise every tensor and write the .mllm.  Tensors are made by a thread pool (numpy's Generator and the
-    ctypes call into the C quantiser both release the GIL); the output bytes do not depend on `workers`."""
+    """Synthesise every tensor and write the .mllm.  Tensors are made by a thread pool (numpy's Generator and array arithmetic release the GIL);
+    the output bytes do not depend on `workers`."""
     jobs = [(n, s, k, target) for n, s, k in specs]
     total = sum(int(np.prod(s)) for _, s, _, _ in jobs)
     if workers is None:
@@ -44,7 +44,7 @@ def build_q4k_file(path: str, specs, target: int = mf.Q4_K, workers: int | None 
 
 def qwen2vl_file(cfg: synth.Qwen2VLConfig, cache_dir: str = "/tmp/mllm_amd_cache", tag: str = "", vision: bool = True) -> str:
     os.makedirs(cache_dir, exist_ok=True)
-    key = f"q2vl-h{cfg.hidden}-i{cfg.inter}-l{cfg.layers}-v{cfg.vocab}-vd{cfg.v_dim}-vb{cfg.v_blocks}{'' if vision else '-novis'}{tag}-q4k.mllm"
+    key = f"q2vl-h{cfg.hidden}-i{cfg.inter}-l{cfg.layers}-v{cfg.vocab}-vd{cfg.v_dim}-vb{cfg.v_blocks}{'' if vision else '-novis'}{'' if cfg.tie_embedding else '-untied'}{tag}-{TAG}.mllm"
     path = os.path.join(cache_dir, key)
     if not os.path.exists(path):
         build_q4k_file(path, synth.qwen2vl_tensors(cfg, vision=vision))
@@ -61,7 +61,7 @@ def tensor_digests(path: str) -> dict:
 def causal_lm_file(cfg: synth.CausalLMConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> str:
     os.makedirs(cache_dir, exist_ok=True)
     key = (f"{cfg.family}-h{cfg.hidden}-i{cfg.inter}-l{cfg.layers}-a{cfg.heads}k{cfg.kv_heads}-v{cfg.vocab}-t{int(cfg.tie_embedding)}"
-           f"-{'f32' if cfg.target == mf.F32 else 'q4k'}.mllm")
+           f"-{'f32' if cfg.target == mf.F32 else TAG}.mllm")
     path = os.path.join(cache_dir, key)
     if not os.path.exists(path):
         build_q4k_file(path, synth.causal_lm_tensors(cfg), target=cfg.target)
@@ -70,7 +70,7 @@ def causal_lm_file(cfg: synth.CausalLMConfig, cache_dir: str = "/tmp/mllm_amd_ca
 
 def vit_file(cfg: synth.ViTConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> str:
     os.makedirs(cache_dir, exist_ok=True)
-    path = os.path.join(cache_dir, f"vit-h{cfg.hidden}-f{cfg.ffn}-b{cfg.blocks}-p{cfg.patch}-i{cfg.img}-c{cfg.classes}-q4k.mllm")
+    path = os.path.join(cache_dir, f"vit-h{cfg.hidden}-f{cfg.ffn}-b{cfg.blocks}-p{cfg.patch}-i{cfg.img}-c{cfg.classes}-{TAG}.mllm")
     if not os.path.exists(path):
         build_q4k_file(path, synth.vit_tensors(cfg))
     return path
@@ -78,7 +78,7 @@ def vit_file(cfg: synth.ViTConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> st
 
 def llava_file(cfg: synth.LLaVAConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> str:
     os.makedirs(cache_dir, exist_ok=True)
-    path = os.path.join(cache_dir, f"llava-h{cfg.hidden}-i{cfg.inter}-l{cfg.layers}-v{cfg.vocab}-vh{cfg.v_hidden}-vb{cfg.v_blocks}-img{cfg.img}-q4k.mllm")
+    path = os.path.join(cache_dir, f"llava-h{cfg.hidden}-i{cfg.inter}-l{cfg.layers}-v{cfg.vocab}-vh{cfg.v_hidden}-vb{cfg.v_blocks}-img{cfg.img}-{TAG}.mllm")
     if not os.path.exists(path):
         build_q4k_file(path, synth.llava_tensors(cfg))
     return path
@@ -86,12 +86,7 @@ def llava_file(cfg: synth.LLaVAConfig, cache_dir: str = "/tmp/mllm_amd_cache") -
 
 def moe_file(cfg: synth.MoEConfig, cache_dir: str = "/tmp/mllm_amd_cache") -> str:
     os.makedirs(cache_dir, exist_ok=True)
-    path = os.path.join(cache_dir, f"moe-h{cfg.hidden}-i{cfg.inter}-e{cfg.experts}-k{cfg.per_tok}-q4k.mllm")
+    path = os.path.join(cache_dir, f"moe-h{cfg.hidden}-i{cfg.inter}-e{cfg.experts}-k{cfg.per_tok}-{TAG}.mllm")
     if not os.path.exists(path):
         build_q4k_file(path, synth.moe_tensors(cfg))
     return path
-
-
-def write_fp32_mllm(path: str, specs) -> None:
-    """The fp32 `.mllm` of the synthetic tensors -- the input of the reference's own `quantize` tool (oracle/make_golden.py)."""
-    mf.write_mllm(path, ((n, mf.F32, synth.tensor_f32(n, s, k)) for n, s, k in specs))

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """oracle/make_golden.py -- TEST INFRASTRUCTURE.  Generates the committed golden vectors under tests/golden/ by running
-the compiled REFERENCE itself (oracle/_ref/ref_ops, ref_qwen2vl, quantize -- built by oracle/Makefile.ref from
-/root/reference).  Runs only in the development container; the GPU box sees only the resulting small .npz files.
+the compiled REFERENCE itself (oracle/_ref/ref_ops, ref_qwen2vl, ref_llm, ref_vit, ref_llava_parts, quantize -- built by
+oracle/Makefile.ref from /root/reference).  Runs only in the development container; the GPU box sees only the resulting small .npz files.
 
-    make -f oracle/Makefile.ref -j8 && python oracle/make_golden.py [--full]
+    make -f oracle/Makefile.ref -j8 && python oracle/make_golden.py [--full]          # op goldens + tiny Qwen2-VL (+ the 2 B runs)
+    python oracle/make_golden.py --all [--full]                                          # every golden that depends on a synthetic model file
 
-Every case stores its inputs (fp32), the raw weight bytes the reference consumed and the reference's outputs, so the
-tests need neither the reference nor a quantiser to replay it.
+Op-level cases store their inputs (fp32), the raw weight bytes the reference consumed (written by the reference's own `quantize` tool from seeded fp32 arrays)
+and the reference's outputs, so the tests replay them without the reference.  Model-level cases run the reference on the synthetic `.mllm` files of
+mllm_amd/synthfile.py (Q4_K / Q4_0 tensors drawn directly in the quantised domain: the reference and the HIP path read the same bytes; no quantiser in between).
 """
 from __future__ import annotations
 
@@ -21,7 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mllm_amd import mllmfile as mf, synth  # noqa: E402
-from tests.fixtures import weights  # noqa: E402
+from mllm_amd import synthfile as weights  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -176,9 +178,7 @@ def ops_golden():
 def e2e_tiny():
     c = synth.qwen2vl_tiny()
     td = tempfile.mkdtemp()
-    src, dst = os.path.join(td, "f32.mllm"), os.path.join(td, "q4k.mllm")
-    weights.write_fp32_mllm(src, synth.qwen2vl_tensors(c))
-    subprocess.run([os.path.join(REF, "quantize"), src, dst, "Q4_K"], check=True, capture_output=True)
+    dst = weights.qwen2vl_file(c, cache_dir=td)
     pix, grid, ids = synth.qwen2vl_inputs(c, (8, 8), 6)
     pix.tofile(os.path.join(td, "pix.f32"))
     ids.tofile(os.path.join(td, "ids.i32"))
@@ -198,46 +198,63 @@ def e2e_tiny():
                     "--out", td2, "--cfg", cfg, "--dump-every", "1"], check=True, capture_output=True)
     toks_t = np.fromfile(os.path.join(td2, "tokens.i32"), dtype=np.int32)
     logits_t = np.stack([np.fromfile(os.path.join(td2, f"logits_{s}.f32"), dtype=np.float32) for s in range(6)])
-    f = mf.MllmFile(dst)
-    import hashlib
-    dig = {n: hashlib.sha256(f.raw(n).tobytes()).hexdigest()[:16] for n in f.names() if n != "lm_head.weight"}
-    f.close()
+    # the untied form (tie_embedding_words = false: a separate Q4_K lm_head Linear, modeling_qwen2_vl.hpp:375-401; what demo_qwen2_vl's larger presets use): image + text, 8 steps
+    cu = synth.qwen2vl_tiny()
+    cu.tie_embedding = False
+    dst_u = weights.qwen2vl_file(cu, cache_dir=td)
+    td3 = tempfile.mkdtemp()
+    subprocess.run([os.path.join(REF, "ref_qwen2vl"), "--model", dst_u, "--ids", os.path.join(td, "ids.i32"), "--pix", os.path.join(td, "pix.f32"), "--grid", "1,8,8", "--steps", "8",
+                    "--threads", "4", "--out", td3, "--cfg", cfg + ",0", "--dump-every", "1"], check=True, capture_output=True)
+    toks_u = np.fromfile(os.path.join(td3, "tokens.i32"), dtype=np.int32)
+    logits_u = np.stack([np.fromfile(os.path.join(td3, f"logits_{s}.f32"), dtype=np.float32) for s in range(8)])
     np.savez_compressed(os.path.join(GOLD, "qwen2vl_tiny.npz"), ids=ids, grid=grid, tokens=toks, logits=logits, image_embeds=emb.reshape(-1, c.hidden),
-                        ids_text=ids_t, tokens_text=toks_t, logits_text=logits_t)
-    json.dump(dig, open(os.path.join(GOLD, "qwen2vl_tiny_q4k_digests.json"), "w"), indent=0, sort_keys=True)
+                        ids_text=ids_t, tokens_text=toks_t, logits_text=logits_t, tokens_untied=toks_u, logits_untied=logits_u)
     print("qwen2vl_tiny.npz tokens", toks.tolist())
 
 
-def e2e_full(out_dir="/tmp/full/out", run_log="/tmp/full/run.log"):
-    """Packs the full-size (Qwen2-VL-2B shaped) reference run made with ref_qwen2vl on /tmp/full/q2vl_q4k.mllm
-    (reference-quantised synthetic weights): greedy ids, top-64 logits and a strided sample of the dumped logits rows."""
-    toks = np.fromfile(os.path.join(out_dir, "tokens.i32"), dtype=np.int32)
-    steps = sorted(int(f[7:-4]) for f in os.listdir(out_dir) if f.startswith("logits_"))
-    top_i, top_v, samp = [], [], []
-    for s in steps:
-        l = np.fromfile(os.path.join(out_dir, f"logits_{s}.f32"), dtype=np.float32)
-        idx = np.argsort(-l, kind="stable")[:64]
-        top_i.append(idx.astype(np.int32)); top_v.append(l[idx]); samp.append(l[::97].copy())
-    timing = open(run_log).read().splitlines()[0]
-    np.savez_compressed(os.path.join(GOLD, "qwen2vl_2b_ref.npz"), tokens=toks, steps=np.array(steps, dtype=np.int32), top_idx=np.stack(top_i),
-                        top_val=np.stack(top_v), strided=np.stack(samp), timing=np.frombuffer(timing.encode(), dtype=np.uint8))
-    print("qwen2vl_2b_ref.npz", toks[:8], timing)
+CACHE = os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache")
 
 
-def _ref_weights(specs, target):
-    """fp32 .mllm of the synthetic tensors -> the reference's own `quantize` (or the fp32 file itself for an F32 target)."""
-    td = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP"))
-    src, dst = os.path.join(td, "f32.mllm"), os.path.join(td, "q.mllm")
-    weights.write_fp32_mllm(src, specs)
-    if target == mf.F32:
-        return td, src
-    subprocess.run([os.path.join(REF, "quantize"), src, dst, "Q4_K"], check=True, capture_output=True)
-    os.remove(src)
-    return td, dst
+def _cfg_q2vl(c):
+    return (f"{c.hidden},{c.inter},{c.layers},{c.heads},{c.kv_heads},{c.vocab},{c.v_dim},{c.cache_limit},{c.image_token_id},{c.vision_start_token_id},"
+            f"{c.vision_end_token_id},{c.video_token_id}")
+
+
+def e2e_full():
+    """The full-size (Qwen2-VL-2B shaped) reference runs on the synthetic file: (1) 448 x 448 image + 24 tokens, 65 greedy steps: ids, and of steps 0 / 16 / 32 / 48 / 64
+    the top-64 logits and every 97th; (2) a 40-token text prompt, 33 steps, steps 0 / 8 / .. / 32 likewise; (3) the vision tower's image_embeds, all 256 x 1536."""
+    c = synth.qwen2vl_2b()
+    path = weights.qwen2vl_file(c, cache_dir=CACHE)
+    pix, grid, ids = synth.qwen2vl_inputs(c, (32, 32), 24)
+
+    def run(ids_, steps, every, with_img):
+        td = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP"))
+        ids_.astype(np.int32).tofile(os.path.join(td, "ids.i32"))
+        cmd = [os.path.join(REF, "ref_qwen2vl"), "--model", path, "--ids", os.path.join(td, "ids.i32"), "--steps", str(steps), "--threads", "8", "--out", td, "--cfg", _cfg_q2vl(c),
+               "--dump-every", str(every)]
+        if with_img:
+            pix.tofile(os.path.join(td, "pix.f32"))
+            cmd += ["--pix", os.path.join(td, "pix.f32"), "--grid", "1,32,32"]
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True)
+        toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
+        dumped = sorted(int(f[7:-4]) for f in os.listdir(td) if f.startswith("logits_") and int(f[7:-4]) % every == 0)
+        ti, tv, st = _sampled(np.stack([np.fromfile(os.path.join(td, f"logits_{s_}.f32"), dtype=np.float32) for s_ in dumped]))
+        return toks, np.array(dumped, dtype=np.int32), ti, tv, st, out.stdout.strip().splitlines()[0]
+
+    toks, steps, ti, tv, st, timing = run(ids, 65, 16, True)
+    np.savez_compressed(os.path.join(GOLD, "qwen2vl_2b_ref.npz"), tokens=toks, steps=steps, top_idx=ti, top_val=tv, strided=st, timing=np.frombuffer(timing.encode(), dtype=np.uint8))
+    print("qwen2vl_2b_ref.npz", toks[:8], steps, timing)
+    ids_t = np.random.default_rng(5).integers(0, 150000, size=40).astype(np.int32)
+    toks, steps, ti, tv, st, timing = run(ids_t, 33, 8, False)
+    np.savez_compressed(os.path.join(GOLD, "qwen2vl_2b_ref_text.npz"), ids=ids_t, tokens=toks, steps=steps, top_idx=ti, top_val=tv, strided=st)
+    print("qwen2vl_2b_ref_text.npz", toks[:8], steps, timing)
+    (emb,), _ = run_ops("vision", path, [[(pix, (1024, 3, 2, 14, 14)), (grid.astype(np.float32), (1, 1, 1, 3))]], p=(c.hidden, c.v_dim), threads=8)
+    np.savez_compressed(os.path.join(GOLD, "qwen2vl_2b_ref_vision.npz"), image_embeds=emb.reshape(-1, c.hidden))
+    print("qwen2vl_2b_ref_vision.npz", emb.reshape(-1, c.hidden).shape)
 
 
 def run_ref_llm(c, n_prompt, steps, threads=4):
-    td, path = _ref_weights(synth.causal_lm_tensors(c), c.target)
+    td, path = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP")), weights.causal_lm_file(c, CACHE)
     ids = synth.causal_lm_ids(c, n_prompt)
     ids.tofile(os.path.join(td, "ids.i32"))
     cfg = f"{c.hidden},{c.inter},{c.layers},{c.heads},{c.kv_heads},{c.vocab},{c.cache_limit},{int(c.tie_embedding)}"
@@ -245,22 +262,20 @@ def run_ref_llm(c, n_prompt, steps, threads=4):
                           "--threads", str(threads), "--out", td, "--cfg", cfg], check=True, capture_output=True, text=True)
     toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
     logits = np.stack([np.fromfile(os.path.join(td, f"logits_{s}.f32"), dtype=np.float32) for s in range(steps)])
-    os.remove(path)
     return ids, toks, logits, out.stdout.strip().splitlines()[0]
 
 
 def run_ref_vit(c, n_img, threads=4):
-    td, path = _ref_weights(synth.vit_tensors(c), mf.Q4_K)
+    td, path = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP")), weights.vit_file(c, CACHE)
     synth.vit_images(c, n_img).tofile(os.path.join(td, "img.f32"))
     cfg = f"{c.hidden},{c.heads},{c.ffn},{c.blocks},{c.patch},{c.img},{c.classes}"
     out = subprocess.run([os.path.join(REF, "ref_vit"), "--model", path, "--img", os.path.join(td, "img.f32"), "--n", str(n_img), "--threads", str(threads),
                           "--out", td, "--cfg", cfg], check=True, capture_output=True, text=True)
-    os.remove(path)
     return np.fromfile(os.path.join(td, "vit_logits.f32"), dtype=np.float32).reshape(n_img, c.classes), out.stdout.strip().splitlines()[0]
 
 
 def run_ref_llava(c, steps, threads=4):
-    td, path = _ref_weights(synth.llava_tensors(c), mf.Q4_K)
+    td, path = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP")), weights.llava_file(c, CACHE)
     ids, img = synth.llava_inputs(c)
     ids.tofile(os.path.join(td, "ids.i32"))
     img.tofile(os.path.join(td, "img.f32"))
@@ -269,14 +284,13 @@ def run_ref_llava(c, steps, threads=4):
                     str(steps), "--threads", str(threads), "--out", td, "--cfg", cfg], check=True, capture_output=True, text=True)
     toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
     logits = np.stack([np.fromfile(os.path.join(td, f"logits_{s}.f32"), dtype=np.float32) for s in range(steps)])
-    os.remove(path)
     return ids, toks, logits
 
 
-def run_ref_llava_parts(c, steps, threads=4, n_text=10, keep=None):
+def run_ref_llava_parts(c, steps, threads=4, n_text=10):
     """The reference's LLaVA graph composed from its own modules with the position ids as an input (oracle/ref_drivers/ref_llava_parts.cpp): the
     whole-graph run LLaVAModel itself cannot give at this snapshot.  Returns ids, greedy tokens, last-row logits per step, projected visual rows."""
-    td, path = keep if keep else _ref_weights(synth.llava_tensors(c), mf.Q4_K)
+    td, path = tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP")), weights.llava_file(c, CACHE)
     ids, img = synth.llava_inputs(c, n_text)
     ids.tofile(os.path.join(td, "ids.i32"))
     img.tofile(os.path.join(td, "img.f32"))
@@ -288,8 +302,6 @@ def run_ref_llava_parts(c, steps, threads=4, n_text=10, keep=None):
     out = subprocess.run(base + ["--steps", str(steps)], check=True, capture_output=True, text=True)
     toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
     logits = np.stack([np.fromfile(os.path.join(td, f"logits_{s}.f32"), dtype=np.float32) for s in range(steps)])
-    if not keep:
-        os.remove(path)
     return ids, toks, logits, vis, out.stdout.strip().splitlines()[-1]
 
 
@@ -301,15 +313,12 @@ def llava_tiny():
     print("llava_tiny.npz", tok.tolist(), timing)
 
 
-def llava_full(path=None):
+def llava_full():
     """LLaVA-1.5-7B geometry (4096 / 11008 / 32 heads x 128, 32 layers, vocab 32064) + CLIP-ViT-L/14-336 (1024 / 4096 / 16 heads x 64, 23 blocks,
     577 tokens) on synthetic Q4_K weights: 14-token prompt with one image (S = 589 after the splice) + 5 decode steps.  Stored: greedy ids, top-64
     and every 97th logit of each step, and every 61st projected visual row (all 4096 columns)."""
     c = synth.llava_7b()
-    keep = None
-    if path:      # a file weights.llava_file() wrote with the fixture quantiser (byte-identical to the reference tool's, tests/test_host.py)
-        keep = (tempfile.mkdtemp(dir=os.environ.get("MLLM_GOLD_TMP")), path)
-    ids, tok, log, vis, timing = run_ref_llava_parts(c, 6, threads=8, keep=keep)
+    ids, tok, log, vis, timing = run_ref_llava_parts(c, 6, threads=8)
     ti, tv, st = _sampled(log)
     np.savez_compressed(os.path.join(GOLD, "llava_7b.npz"), ids=ids, tokens=tok, top_idx=ti, top_val=tv, strided=st, vision_rows=vis[::61],
                         timing=np.frombuffer(timing.encode(), dtype=np.uint8))
@@ -490,10 +499,10 @@ def n4_golden():
 
 
 def moe_golden():
-    """the reference's own MiniCPMMoE block (ref_ops case moe) on reference-quantised synthetic weights: 4 experts, 2 per token, 37 tokens (every expert
+    """the reference's own MiniCPMMoE block (ref_ops case moe) on the synthetic Q4_K file of mllm_amd/synthfile.py: 4 experts, 2 per token, 37 tokens (every expert
     receives tokens, some fewer than 16 rows, one more) and a single token (decode: two experts get one row, the others none)."""
     c = synth.moe_tiny()
-    td, path = _ref_weights(synth.moe_tensors(c), mf.Q4_K)
+    path = weights.moe_file(c, CACHE)
     G = {}
     for tag, n in (("p", 37), ("d", 1)):
         x = synth.moe_input(c, n, seed=17 + n)
@@ -551,8 +560,18 @@ if __name__ == "__main__":
         sampling()
         sys.exit(0)
     if "--llava-full" in sys.argv:
-        i = sys.argv.index("--llava-full")
-        llava_full(sys.argv[i + 1] if i + 1 < len(sys.argv) else None)
+        llava_full()
+        sys.exit(0)
+    if "--all" in sys.argv:      # every golden that depends on a synthetic model file
+        e2e_tiny()
+        configs_tiny()
+        llava_tiny()
+        moe_golden()
+        if "--full" in sys.argv:
+            e2e_full()
+            configs_full()
+            tinyllama_full()
+            llava_full()
         sys.exit(0)
     if "--configs" in sys.argv:
         configs_tiny()

@@ -84,6 +84,7 @@ int main(int argc, char **argv) {
         config.vision_start_token_id = cv[9];
         config.vision_end_token_id = cv[10];
         config.video_token_id = cv[11];
+        if (cv.size() > 12) config.tie_embedding_words = cv[12] != 0;      // optional 13th field: 0 = a separate lm_head Linear (modeling_qwen2_vl.hpp:375-401)
     }
     auto model = Qwen2VLModel(config);
     model.load(model_path);

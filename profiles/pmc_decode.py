@@ -9,7 +9,7 @@ import numpy as np
 os.environ.setdefault("MLLM_HIP_NO_GRAPH", "1")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mllm_amd import lib, synth  # noqa: E402
-from tests.fixtures import weights  # noqa: E402
+from mllm_amd import synthfile as weights  # noqa: E402
 
 cfg = synth.qwen2vl_2b()
 m = lib.Qwen2VL(cfg, weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache")))

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from mllm_amd import mllmfile as mf, synth
-from tests.fixtures import weights
+from mllm_amd import synthfile as weights
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CACHE = os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache")

@@ -18,7 +18,7 @@ DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_hip_qwen2vl")
 
 def _cfg_string(c):
     return (f"{c.hidden},{c.inter},{c.layers},{c.heads},{c.kv_heads},{c.vocab},{c.v_dim},{c.cache_limit},{c.image_token_id},{c.vision_start_token_id},"
-            f"{c.vision_end_token_id},{c.video_token_id}")
+            f"{c.vision_end_token_id},{c.video_token_id},{int(c.tie_embedding)}")
 
 
 def _run(td, cfg, path, ids, steps, pix=None, grid=None, engine=0):
@@ -41,7 +41,7 @@ def tiny(tmp_path_factory):
     if not os.path.exists(DRIVER):
         pytest.skip("oracle/_ref/ref_hip_qwen2vl was not built (make -f oracle/Makefile.ref, container only)")
     from mllm_amd import synth
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     cfg = synth.qwen2vl_tiny()
     return cfg, weights.qwen2vl_file(cfg, cache_dir=str(tmp_path_factory.mktemp("w")))
 
@@ -71,6 +71,23 @@ def test_reference_module_text_only_prompt(tiny, tiny_gold, tmp_path):
     assert np.array_equal(logits, g["logits_text"]), float(np.max(np.abs(logits - g["logits_text"])))
 
 
+@pytest.mark.parametrize("engine", [0, 1], ids=["op-by-op", "engine-module"])
+def test_untied_lm_head_through_the_boundary(tiny, tiny_gold, tmp_path, engine):
+    """config.tie_embedding_words = false (demo_qwen2_vl's larger presets): the reference's Qwen2VLModel takes its `lm_head` Linear instead of the tied embedding table
+    (modeling_qwen2_vl.hpp:375-401); both the Op-by-Op adapter and the engine-backed Module (which once hard-wired the tied head) must follow the flag: every logit of
+    8 steps equals the reference's CPU run on the untied file."""
+    from mllm_amd import synth
+    from mllm_amd import synthfile as weights
+    g = tiny_gold
+    cfg = synth.qwen2vl_tiny()
+    cfg.tie_embedding = False
+    path = weights.qwen2vl_file(cfg, cache_dir=str(tmp_path))
+    pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
+    report, toks, logits = _run(str(tmp_path), cfg, path, ids, len(g["tokens_untied"]), pix, grid, engine=engine)
+    assert report["cpu_fallback_ops"] == 0 and report["refused"] == [], report
+    assert toks.tolist() == g["tokens_untied"].tolist() and np.array_equal(logits, g["logits_untied"])
+
+
 def test_reference_module_at_the_2b_geometry(tmp_path):
     """The same, at BASELINE's geometry: the reference's Qwen2VLModel (28 layers, hidden 1536, 32 vision blocks) on the Q4_K file through the adapter, 448 x 448 image + 24 tokens
     prefilled, 64 decode steps: ids equal the reference's CPU run (tests/golden/qwen2vl_2b_ref.npz) and so do its sampled logits (top 64 + every 97th) at steps 0, 16, 32, 48, 64;
@@ -79,7 +96,7 @@ def test_reference_module_at_the_2b_geometry(tmp_path):
     if not os.path.exists(DRIVER):
         pytest.skip("oracle/_ref/ref_hip_qwen2vl was not built (make -f oracle/Makefile.ref, container only)")
     from mllm_amd import synth
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     cfg = synth.qwen2vl_2b()
     path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
     g = np.load(os.path.join(ROOT, "tests", "golden", "qwen2vl_2b_ref.npz"))
@@ -107,7 +124,7 @@ def test_engine_module_behind_the_reference_frontend(tiny, tiny_gold, tmp_path):
     demo loop (model(input) -> host argmax -> chatPostProcessing): ids and every logit of every step equal the reference's CPU run, image + text and text only; then the 2B
     geometry: ids and sampled logits, and the reference's own profiling() of that run."""
     from mllm_amd import synth
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     cfg, path = tiny
     g = tiny_gold
     pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)

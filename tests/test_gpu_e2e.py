@@ -11,7 +11,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from mllm_amd import lib, synth  # noqa: E402
-from tests.fixtures import weights  # noqa: E402
+from mllm_amd import synthfile as weights  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -51,6 +51,34 @@ def test_tiny_text_only_prompt(tiny_model, tiny_gold):
         maxerr = max(maxerr, float(np.max(np.abs(logits - g["logits_text"][s]))))
     assert toks == g["tokens_text"].tolist()
     assert maxerr == 0.0, maxerr
+
+
+def test_untied_lm_head_and_cache_len(tiny_gold, tmp_path):
+    """tie_embedding_words = false (a separate Q4_K lm_head Linear, modeling_qwen2_vl.hpp:375-401): every logit of 8 steps equals the reference's run on the untied file;
+    mllm_hip_model_cache_len follows the prefill, the decode steps and clear_kvcache; and a tiny 2 x 2 grid (4 patches: below the tower's 16-row minimum) is refused with a
+    message instead of failing inside the first block."""
+    g = tiny_gold
+    cfg = synth.qwen2vl_tiny()
+    cfg.tie_embedding = False
+    m = lib.Qwen2VL(cfg, weights.qwen2vl_file(cfg, cache_dir=str(tmp_path)))
+    pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
+    assert m.cache_len() == 0
+    tok, logits, _ = m.prefill(ids, pix, grid)
+    assert m.cache_len() == len(ids)
+    toks, rows = [tok], [logits]
+    for s in range(1, len(g["tokens_untied"])):
+        tok, logits, _ = m.decode(tok)
+        toks.append(tok)
+        rows.append(logits)
+    assert m.cache_len() == len(ids) + len(toks) - 1
+    assert toks == g["tokens_untied"].tolist() and np.array_equal(np.stack(rows), g["logits_untied"])
+    m.clear_kvcache()
+    assert m.cache_len() == 0
+    small = np.zeros((4, cfg.patch_elems), dtype=np.float32)
+    out = torch.empty((1, cfg.hidden), dtype=torch.float32, device="cuda")
+    with pytest.raises(lib.MllmHipError, match="16 patches"):
+        m.vision(small, np.array([1, 2, 2], dtype=np.int32), out.data_ptr())
+    m.close()
 
 
 def test_vision_tower_matches_reference(tiny_model, tiny_gold):

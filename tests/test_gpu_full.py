@@ -11,7 +11,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from mllm_amd import lib, synth  # noqa: E402
-from tests.fixtures import weights  # noqa: E402
+from mllm_amd import synthfile as weights  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -81,7 +81,7 @@ def test_pipelined_decode_attention_equals_the_unpipelined_kernel_over_a_long_co
     the same greedy ids and bit-identical logits along a decode that takes the cache from 30 to 760 keys -- every block count from 1 to 24, blocks that wrap the
     producers' LDS regions (more than 14 blocks), partial last blocks, the appended key alone in its block."""
     from mllm_amd import lib, synth
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     cfg = synth.qwen2vl_tiny()
     cfg.cache_limit = 800
     path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
@@ -109,7 +109,7 @@ def test_weight_warming_workgroups_change_nothing_but_time():
     """The attention launch's warming workgroups (attn_flags bits 4 / 6: the CUs that hold no head read the layer's gate|up and o-projection rows through LDS-DMA into a
     landing pad, so that the XCD L2s hold them when those launches arrive) at the 2B shape -- where every region of decode_warm_table exists -- against the same model
     without them: identical ids over 200 steps and bit-identical logits of the step behind them."""
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     cfg = synth.qwen2vl_2b()
     path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
     pix, grid, ids = synth.qwen2vl_inputs(cfg, (32, 32), 24)

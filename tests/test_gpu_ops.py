@@ -10,7 +10,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from mllm_amd import lib, mllmfile as mf, ops  # noqa: E402
-from tests.fixtures import quantlib  # noqa: E402
+from mllm_amd import synth  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
@@ -67,10 +67,10 @@ def test_quantize_q80_bit_exact(M, K):
 # ---- A1/A2/A5: Q4_K Linear -----------------------------------------------------------------------------------------------
 def _q4k_case(M, K, N, seed, bias=True):
     r = rng(seed)
-    W = (r.standard_normal((N, K)) * 0.05).astype(np.float32)
+    Wq = synth.quantized_blocks(lib.Q4_K, r, N * K, std=0.05, full_range=True)      # Q4_K rows drawn in the quantised domain, every field over its whole range (mllm_amd/synth.py)
     x = r.standard_normal((M, K)).astype(np.float32)
     b = (r.standard_normal(N) * 0.1).astype(np.float32) if bias else None
-    return quantlib.quantize(lib.Q4_K, W), x, b
+    return Wq, x, b
 
 
 # M = 1 goes through the one-launch form (dec_linear_row_q4k: up to 32 rows per workgroup, the last workgroup re-doing rows of its neighbour); K beyond 10240 and M = 3 the two-launch one
@@ -188,7 +188,7 @@ def test_linear_is_linear_in_weights_rows_and_zero_input():
     give bit-identical outputs whichever wave computes them."""
     K, N = 1536, 17920
     r = rng(11)
-    blk = quantlib.quantize(lib.Q4_K, (r.standard_normal((64, K)) * 0.02).astype(np.float32)).reshape(64, -1)
+    blk = synth.quantized_blocks(lib.Q4_K, r, 64 * K).reshape(64, -1)
     Wq = np.tile(blk, (N // 64, 1)).ravel()
     x = r.standard_normal((1, K)).astype(np.float32)
     y = ops.linear_q4k(Wq, x, N).cpu().numpy().reshape(N // 64, 64)
@@ -202,7 +202,7 @@ def test_linear_is_linear_in_weights_rows_and_zero_input():
 @pytest.mark.parametrize("K,N", [(1536, 4096), (512, 160), (1024, 999), (4096, 64)])
 def test_linear_q40_vs_oracle(K, N):
     r = rng(K + N)
-    Wq = quantlib.quantize(lib.Q4_0, (r.standard_normal((N, K)) * 0.05).astype(np.float32))
+    Wq = synth.quantized_blocks(lib.Q4_0, r, N * K, std=0.05, full_range=True)
     x = r.standard_normal((1, K)).astype(np.float32)
     y = ops.linear_q40(Wq, x, N)
     ref = orc.linear(x, Wq, orc.Q4_0, N)

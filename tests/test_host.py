@@ -1,17 +1,14 @@
 """CPU-side tests of the product's host logic: the C-ABI library loads and exports every symbol include/mllm_hip.h
-declares, the .mllm container round-trips, the host quantisers are byte-identical to the reference `quantize` tool (pinned by
-digests captured from the reference, tests/golden/qwen2vl_tiny_q4k_digests.json), and the host-side table builders agree
+declares, the .mllm container round-trips, the synthetic weight files are what mllm_amd/synth.py says they are (valid Q4_K / Q4_0
+blocks drawn in the quantised domain, deterministic, the reference's per-name dtype policy), and the host-side table builders agree
 with the oracle.  No GPU, no compute launch."""
-import ctypes
-import hashlib
-import json
 import os
 
 import numpy as np
 import pytest
 
 from mllm_amd import lib, mllmfile as mf, synth
-from tests.fixtures import quantlib, weights
+from mllm_amd import synthfile as weights
 from oracle import oracle as orc
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -25,23 +22,38 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
-def test_quantized_nbytes_and_errors():
-    assert quantlib.nbytes(quantlib.Q4_K, 512) == 288
-    assert quantlib.nbytes(quantlib.Q4_0, 64) == 36
-    assert quantlib.nbytes(quantlib.Q4_K, 100) == -1
+def test_quantised_domain_blocks_are_valid_and_centred():
+    """q4k_blocks / q40_blocks: the right sizes, every 6-bit field within range by construction of the packing, dequantised weights (oracle restatement of
+    dequantize_row_q4_K / _q4_0, QuantizeQ4.cpp:295-333, 74-93) with zero mean and the requested standard deviation, and the draw is a pure function of the seed."""
+    r = np.random.default_rng(5)
+    b = synth.q4k_blocks(r, 2048)
+    assert b.shape == (2048, 144) and b.dtype == np.uint8
+    w = orc.dequantize(b.ravel(), orc.Q4_K, 2048 * 256)
+    assert abs(float(w.mean())) < 1e-3 and 0.017 < float(w.std()) < 0.025 and np.isfinite(w).all()
+    q = synth.q40_blocks(r, 4096)
+    assert q.shape == (4096, 18)
+    w0 = orc.dequantize(q.ravel(), orc.Q4_0, 4096 * 32)
+    assert abs(float(w0.mean())) < 3e-3 and 0.017 < float(w0.std()) < 0.025
+    assert np.array_equal(synth.q4k_blocks(np.random.default_rng(5), 2048), b)
+    # the 6-bit fields as the reference's reader unpacks them (get_scale_min_k4): scales 20..63, mins follow the scales
+    sc_lo, m_lo = b[:, 4:8] & 63, b[:, 8:12] & 63
+    assert sc_lo.min() >= 20 and np.all(np.abs(m_lo.astype(int) - np.rint(sc_lo * (7.75 / 8)).astype(int)) <= 2)
+    assert synth.quantized_blocks(mf.Q4_K, r, 512).size == 288 and synth.quantized_blocks(mf.Q4_0, r, 64).size == 36
     with pytest.raises(ValueError):
-        quantlib.quantize(lib.Q4_K, np.zeros(100, dtype=np.float32))
+        synth.quantized_blocks(mf.Q4_K, r, 100)
 
 
-def test_product_library_does_not_contain_the_fixture_quantiser():
+def test_no_quantiser_in_the_tree():
+    """The synthetic files are drawn in the quantised domain: no fp32 -> Q4_K / Q4_0 fitter exists in the product library, the package or the tests."""
     so = lib.load()
     assert not hasattr(so, "mllm_hip_quantize_host") and not hasattr(so, "mllm_quant_rows")
-    # ... and nothing under mllm_amd/ imports the fixture tooling (it lives under tests/fixtures/)
-    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mllm_amd")
-    for f in os.listdir(pkg):
-        if f.endswith(".py"):
-            src = open(os.path.join(pkg, f)).read()
-            assert "quantlib" not in src and "quantize_host" not in src and "tests.fixtures" not in src, f
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert not os.path.exists(os.path.join(root, "tests", "fixtures"))
+    for d in ("mllm_amd", "tests"):
+        for f in os.listdir(os.path.join(root, d)):
+            if f.endswith(".py") and f != "test_host.py":
+                src = open(os.path.join(root, d, f)).read()
+                assert "quantlib" not in src and "tests.fixtures" not in src, f
 
 
 def test_mllm_file_roundtrip(tmp_path):
@@ -69,32 +81,20 @@ def test_storage_dtype_policy():
     assert synth.storage_dtype("visual.merger.mlp.0.weight") == mf.Q4_K
 
 
-def test_host_quantizer_matches_reference_tool_digests(tmp_path):
-    """Builds the tiny Qwen2-VL file with the product's quantiser and compares per-tensor sha256 with the digests of the file
-    the reference's own `quantize ... Q4_K` produced from the same fp32 tensors."""
-    want = json.load(open(os.path.join(GOLD, "qwen2vl_tiny_q4k_digests.json")))
-    path = weights.qwen2vl_file(synth.qwen2vl_tiny(), cache_dir=str(tmp_path))
-    got = weights.tensor_digests(path)
-    assert set(got) == set(want)
-    bad = [n for n in want if got[n] != want[n]]
-    assert not bad, bad[:5]
-
-
-def test_host_quantizer_full_size_digests():
-    """The same at the benchmark's size: the 729 tensors of the Qwen2-VL-2B shaped synthetic model (2.2 B parameters) written by the fixture quantiser
-    against the digests of the file the reference's `quantize ... Q4_K` wrote from the same fp32 tensors (that file also holds an untied lm_head the
-    tied config never reads).  Uses the cached file when bench.py / the GPU tests have built it already; about a minute on 8 cores otherwise."""
-    want = json.load(open(os.path.join(GOLD, "qwen2vl_2b_q4k_digests.json")))
-    path = weights.qwen2vl_file(synth.qwen2vl_2b(), cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
-    got = weights.tensor_digests(path)
-    assert len(got) == 729 and set(got) <= set(want)
-    bad = [n for n in got if got[n] != want[n]]
-    assert not bad, bad[:5]
-
-
-def test_q80_host_quantizer_vs_oracle():
-    x = np.random.default_rng(3).standard_normal(32 * 40).astype(np.float32)
-    assert np.array_equal(quantlib.quantize(lib.Q8_0, x), orc.quantize_q8_0(x).ravel())
+def test_synthetic_file_is_deterministic_and_follows_the_dtype_policy(tmp_path):
+    """The tiny Qwen2-VL file twice (1 and 4 worker threads): identical bytes; every tensor has the dtype QuantWriter's policy gives its name and the size its shape
+    needs; the reference reads exactly this file for the goldens (oracle/make_golden.py)."""
+    cfg = synth.qwen2vl_tiny()
+    p1 = weights.build_q4k_file(str(tmp_path / "a.mllm"), synth.qwen2vl_tensors(cfg), workers=1)
+    p2 = weights.build_q4k_file(str(tmp_path / "b.mllm"), synth.qwen2vl_tensors(cfg), workers=4)
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    f = mf.MllmFile(p1)
+    specs = {n: s for n, s, _ in synth.qwen2vl_tensors(cfg)}
+    assert f.names() == list(specs)
+    for n, shp in specs.items():
+        dt = synth.storage_dtype(n)
+        assert f.dtype(n) == dt and f.raw(n).size == mf.nbytes(dt, int(np.prod(shp))), n
+    f.close()
 
 
 def test_rotary_tables_match_oracle():

@@ -42,7 +42,7 @@ def test_reference_module_runs_through_the_adapter_on_the_null_device(tmp_path):
     import numpy as np
 
     from mllm_amd import build as b, synth
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     b.build()
     subprocess.run(["make", "-f", "oracle/Makefile.ref", "-j8", "mock"], cwd=ROOT, check=True, capture_output=True, timeout=1500)
     exe = os.path.join(ROOT, "oracle", "_ref", "mock_hip_qwen2vl")
@@ -63,6 +63,49 @@ def test_reference_module_runs_through_the_adapter_on_the_null_device(tmp_path):
     assert reports[0]["live_device_blocks"] == reports[1]["live_device_blocks"], reports      # nothing accumulates over decode steps
     assert reports[1]["hip_ops_run"] > reports[0]["hip_ops_run"] > 600
     assert len(np.fromfile(str(tmp_path / "tokens.i32"), dtype=np.int32)) == 9
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not present (GPU box)")
+def test_other_configs_modules_run_through_the_adapter_on_the_null_device(tmp_path):
+    """The same for the other four BASELINE configs' Modules (QWenForCausalLM, TinyLLaMAModel, ViTModel, the LLaVA graph; oracle/ref_drivers/ref_hip_{llm,vit,llava}.cpp):
+    trace pass, load pass, prefill and decode steps on the null device under AddressSanitizer -- no Op refused (F_CAT, F_FLATTEN, the two-pair F_TRANPOSE, the fp32
+    EMBEDDING and F_INDEX_PUT(accumulate) all have creators), no ASan report."""
+    import json
+
+    from mllm_amd import build as b, mllmfile as mf, synth
+    from mllm_amd import synthfile as weights
+    b.build()
+    subprocess.run(["make", "-f", "oracle/Makefile.ref", "-j8", "mock"], cwd=ROOT, check=True, capture_output=True, timeout=1500)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    td = str(tmp_path)
+
+    def run(cmd):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0 and "AddressSanitizer" not in out.stderr, (cmd[0], out.returncode, out.stderr[-3000:])
+        r = json.loads(next(l for l in out.stdout.splitlines() if l.startswith('{"backend"')))
+        assert r["cpu_fallback_ops"] == 0 and r["refused"] == [], r
+        return r
+
+    for fam, c in (("qwen", synth.qwen15_tiny()), ("tinyllama", synth.tinyllama_tiny(mf.Q4_K))):
+        synth.causal_lm_ids(c, 20).tofile(os.path.join(td, "ids.i32"))
+        cfg = f"{c.hidden},{c.inter},{c.layers},{c.heads},{c.kv_heads},{c.vocab},{c.cache_limit},{int(c.tie_embedding)}"
+        r = run([os.path.join(ROOT, "oracle", "_ref", "mock_hip_llm"), "--family", fam, "--model", weights.causal_lm_file(c), "--ids", os.path.join(td, "ids.i32"), "--steps", "4",
+                 "--threads", "2", "--out", td, "--cfg", cfg])
+        assert r["hip_ops_run"] > 150
+    c = synth.vit_tiny()
+    synth.vit_images(c, 2).tofile(os.path.join(td, "img.f32"))
+    r = run([os.path.join(ROOT, "oracle", "_ref", "mock_hip_vit"), "--model", weights.vit_file(c), "--img", os.path.join(td, "img.f32"), "--n", "2", "--threads", "2", "--out", td,
+             "--cfg", f"{c.hidden},{c.heads},{c.ffn},{c.blocks},{c.patch},{c.img},{c.classes}"])
+    assert r["hip_ops_run"] > 60
+    c = synth.llava_tiny()
+    ids, img = synth.llava_inputs(c)
+    ids.tofile(os.path.join(td, "ids.i32"))
+    img.tofile(os.path.join(td, "img.f32"))
+    cfg = f"{c.hidden},{c.heads},{c.inter},{c.layers},{c.vocab},{c.cache_limit},{c.v_hidden},{c.v_heads},{c.v_ffn},{c.v_blocks},{c.patch},{c.img}"
+    base = [os.path.join(ROOT, "oracle", "_ref", "mock_hip_llava"), "--model", weights.llava_file(c), "--ids", os.path.join(td, "ids.i32"), "--img", os.path.join(td, "img.f32"),
+            "--threads", "2", "--out", td, "--cfg", cfg]
+    assert run(base + ["--steps", "4"])["hip_ops_run"] > 200
+    run(base + ["--dump-vision", "1"])
 
 
 def test_integration_doc_lists_every_registered_creator():

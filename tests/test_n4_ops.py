@@ -145,7 +145,7 @@ def _moe_setup():
 
     from mllm_amd import mllmfile as mf, synth
     from oracle import models as om
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     cfg = synth.moe_tiny()
     path = weights.moe_file(cfg)
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "moe.npz"))
@@ -184,7 +184,7 @@ def test_hip_moe_block_matches_the_reference_module():
     more than 16 rows, i.e. both the GEMV and the GEMM form of the expert Linears) and the decode case (one token); then, at a size the golden does not cover (8 experts,
     3 per token, 300 tokens), against the restatement."""
     from mllm_amd import mllmfile as mf, ops, synth
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     ops.require_gpu()
     cfg, path, g, om = _moe_setup()
 

@@ -127,7 +127,7 @@ def test_mlp_block(ops_gold):
 # ---- model-level pin: the oracle's ops composed into the reference's graphs reproduce the reference run bit for bit ----------
 def _tiny():
     from mllm_amd import synth
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     from oracle import models
     cfg = synth.qwen2vl_tiny()
     return cfg, models, models.Weights(weights.qwen2vl_file(cfg)), np.load(os.path.join(GOLD, "qwen2vl_tiny.npz"))

@@ -85,7 +85,7 @@ def test_device_pixels_feed_the_tower():
     """The preprocessed patches stay on the device and go straight into the engine's prefill (tiny Qwen2-VL): same logits as the same patches handed over from the host."""
     import torch
     from mllm_amd import lib, synth
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     cfg = synth.qwen2vl_tiny()
     path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
     rgb = np.ascontiguousarray(G["rgb2"])       # 112 x 112 -> grid 8 x 8 -> 16 visual tokens

@@ -110,7 +110,7 @@ def test_generate_sampled_on_the_engine():
     """Module::generate's method switch on the resident engine (tiny Qwen2-VL): with u = 0 every draw takes the first candidate = the largest score, so top-k and
     top-p must reproduce the greedy ids; with other draws the ids stay inside the candidate set of each step; eos stops the loop."""
     from mllm_amd import synth
-    from tests.fixtures import weights
+    from mllm_amd import synthfile as weights
     cfg = synth.qwen2vl_tiny()
     path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
     pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
