@@ -43,7 +43,8 @@ def cpu_baseline(path, rank, ids, pix):
     if rank != 0 or not os.path.exists(exe):
         return None
     import tempfile
-    cores = min(16, os.cpu_count() or 1)
+    host_cpus = os.cpu_count() or 1
+    cores = min(16, host_cpus)
     td = tempfile.mkdtemp()
     ids.astype(np.int32).tofile(os.path.join(td, "ids.i32"))
     pix.astype(np.float32).tofile(os.path.join(td, "pix.f32"))
@@ -54,18 +55,88 @@ def cpu_baseline(path, rank, ids, pix):
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][0]
         r = json.loads(line)
         # the host's clocks and neighbours move this number by +-15 % from run to run (15.7 .. 21.4 tok/s across round 2's records): the per-step times say so
-        return {"value": round(r["decode_tok_s"], 3), "unit": "tok/s", "cores": cores, "kind": "reference", "run_to_run_spread": "about +-15 % (24 steps on shared host cores)",
+        return {"value": round(r["decode_tok_s"], 3), "unit": "tok/s", "cores": cores, "host_cpus": host_cpus, "kind": "reference", "run_to_run_spread": "about +-15 % (24 steps on shared host cores)",
                 "sample": "reference x86 AVX2 CPU backend (oracle/_ref/ref_qwen2vl, -t %d) on the same Q4_K .mllm: the same 448x448 image + 24-token prompt (S=%d) prefill, "
                           "then 24 greedy decode steps" % (cores, r["prefill_tokens"]),
                 "prefill_ms": round(r["prefill_ms"], 1), "prefill_tok_s": round(1000.0 * r["prefill_tokens"] / r["prefill_ms"], 3)}
     except Exception as e:  # the baseline is reported, never required
-        return {"value": None, "unit": "tok/s", "cores": cores, "kind": "reference", "sample": f"failed: {e}"}
+        return {"value": None, "unit": "tok/s", "cores": cores, "host_cpus": host_cpus, "kind": "reference", "sample": f"failed: {e}"}
+
+
+def pmc_mfma():
+    """Matrix-pipe busy fraction per prefill kernel from this round's rocprofv3 PMC pass (`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -- python3
+    profiles/pmc_prefill.py`, summarised by profiles/pmc_mfma_summarize.py into profiles/r04_pmc_mfma.json)."""
+    for name in ("r04_pmc_mfma.json",):
+        try:
+            return name, json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+    return None, {}
+
+
+PEAK_F16_MFMA_TF = 2500.0      # dense bf16 / fp16 MFMA peak of MI355X (MI355X_MICROARCH.md); the 5 PF headline figures are 2:1 sparse
+PEAK_F32_MFMA_TF = 157.3       # v_mfma_f32_32x32x2_f32 / 16x16x4: the exact fp32 fma-chain forms the attention is confined to
+
+
+def prefill_kernels(cfgname):
+    """Live HIP-event timings (torch events on torch's current stream, which is the stream mllm_amd.ops launches on) of the two kernels that are the prefill: the Q4_K GEMM
+    on the shapes of the config's prefill, and the exact-order FlashAttention2 on its attention shapes.  Algorithmic FLOPs: GEMM 2 M N K; attention 4 H S^2 D (causal: half)."""
+    import ctypes as C
+    import torch
+    from mllm_amd import lib, ops, synth
+    L = lib.load()
+    r = np.random.default_rng(0)
+    shapes = {"qwen2vl": [("vit fc1", 1024, 5120, 1280, 32), ("vit fc2", 1024, 1280, 5120, 32), ("vit qkv", 1024, 3840, 1280, 32), ("vit proj", 1024, 1280, 1280, 32),
+                          ("llm gate|up", 282, 17920, 1536, 28), ("llm down", 282, 1536, 8960, 28), ("llm q|k|v", 282, 2048, 1536, 28), ("llm o", 282, 1536, 1536, 28)],
+              "llava": [("clip fc1", 577, 4096, 1024, 23), ("clip fc2", 577, 1024, 4096, 23), ("llm gate|up", 589, 22016, 4096, 32), ("llm down", 589, 4096, 11008, 32)]}.get(cfgname, [])
+    attn = {"qwen2vl": [("vit block (S=1024, 16 x 80, fp32 K/V)", 1024, 16, 16, 80, False, False, 32), ("llm layer (S=282, 12/2 x 128, causal, fp16 K/V)", 282, 12, 2, 128, True, True, 28)],
+            "llava": [("clip block (S=577, 16 x 64)", 577, 16, 16, 64, False, False, 23), ("llm layer (S=589, 32 x 128, causal)", 589, 32, 32, 128, True, True, 32)]}.get(cfgname, [])
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n      # us
+
+    out = []
+    for label, M, N, K, calls in shapes:
+        Wd = torch.from_numpy(synth.quantized_blocks(lib.Q4_K, r, N * K)).cuda()
+        wp = torch.empty(int(L.mllm_hip_q4k_wpack_bytes(C.c_int(N), C.c_int(K))), dtype=torch.uint8, device="cuda")
+        xp = torch.empty(int(L.mllm_hip_q4k_prepack_bytes(C.c_int(M), C.c_int(K))), dtype=torch.uint8, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lib.check(L.mllm_hip_q4k_prepack(C.c_void_p(Wd.data_ptr()), C.c_int(N), C.c_int(K), C.c_void_p(wp.data_ptr()), st))
+        x = torch.from_numpy(r.standard_normal((M, K)).astype(np.float32)).cuda()
+        lib.check(L.mllm_hip_quantize_q8k_packed(C.c_void_p(x.data_ptr()), C.c_void_p(xp.data_ptr()), C.c_int(M), C.c_int(K), st))
+        y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+        us = timed(lambda: lib.check(L.mllm_hip_linear_q4kp_packed(C.c_void_p(wp.data_ptr()), None, C.c_void_p(xp.data_ptr()), C.c_void_p(y.data_ptr()), C.c_int(lib.F32), C.c_int64(N),
+                                                                   None, C.c_int(M), C.c_int(N), C.c_int(K), st)), 20)
+        fl = 2.0 * M * N * K
+        out.append({"kernel": "gemm_q4k " + label, "shape_MNK": [M, N, K], "calls_per_prefill": calls, "us_per_launch": round(us, 2), "flops_per_launch": fl,
+                    "achieved_TFps": round(fl / us / 1e6, 1), "peak_TFps": PEAK_F16_MFMA_TF, "frac": round(fl / us / 1e6 / PEAK_F16_MFMA_TF, 4)})
+        del Wd, wp, xp, x, y
+    for label, S, H, Hkv, D, causal, f16, calls in attn:
+        q = torch.from_numpy(r.standard_normal((S, H * D)).astype(np.float32)).cuda()
+        k = torch.from_numpy(r.standard_normal((S, Hkv * D)).astype(np.float32)).cuda()
+        v = torch.from_numpy(r.standard_normal((S, Hkv * D)).astype(np.float32)).cuda()
+        if f16:
+            k, v = k.half(), v.half()
+        us = timed(lambda: ops.flash_attention2(q, k, v, S, S, H, Hkv, D, causal), 10)
+        fl = 4.0 * H * S * S * D * (0.5 if causal else 1.0)
+        out.append({"kernel": "fa2_prefill " + label, "calls_per_prefill": calls, "us_per_launch": round(us, 2), "flops_per_launch": fl, "achieved_TFps": round(fl / us / 1e6, 1),
+                    "peak_TFps": PEAK_F32_MFMA_TF, "frac": round(fl / us / 1e6 / PEAK_F32_MFMA_TF, 4)})
+    return out
 
 
 def pmc_traffic():
     """HBM-side bytes per launch of the decode kernels from this round's rocprofv3 PMC pass (own run, FETCH_SIZE x2 gfx950 correction):
-    profiles/r03_pmc_traffic.json, regenerated by `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 profiles/pmc_decode.py` + pmc_summarize.py."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    profiles/r04_pmc_traffic.json, regenerated by `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 profiles/pmc_decode.py` + pmc_summarize.py."""
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             return name, json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -312,6 +383,22 @@ def main():
                                 "GEMV launches then find in the Infinity Cache (profiles/r03_pmc_fetch_size.md, r03_warm_workgroups.md)",
                 "kernels": kernels}
 
+    # ---- the prefill half of the metric: MFMA-bound.  Algorithmic FLOPs of the forward (2 M N K of every Linear, 4 H S^2 D of every attention; the vision
+    # tower's 1.48 TF per 448 x 448 image + the S = 282 LLM prefill's 0.74 TF) over the median device time, against the dense bf16 MFMA peak; then the two kernels that
+    # are the prefill, each timed alone on its real shapes and priced against the peak of the MFMA form it runs on, with the matrix-pipe busy fraction of the PMC pass
+    pre_flops = {"qwen2vl": 1.48e12 + 0.74e12, "llava": 0.39e12 + 2.0 * 589 * 6.6e9, "qwen15": 2.0 * 64 * 0.31e9, "tinyllama": 2.0 * 64 * 1.03e9}[cfgname]
+    pk = prefill_kernels(cfgname) if rank == 0 else []
+    mname, mfma = pmc_mfma()
+    for kdesc in pk:
+        key = "gemm_q4k" if kdesc["kernel"].startswith("gemm_q4k") else "fa2_prefill"
+        kdesc["mfma_busy_frac"] = (mfma.get(key) or {}).get("mfma_busy_frac") if cfgname == "qwen2vl" else None
+    pre_tf = pre_flops / (prefill_ms * 1e-3) / 1e12
+    prefill_roofline = {"bound": "mfma", "achieved": round(pre_tf, 1), "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": round(pre_tf / PEAK_F16_MFMA_TF, 4),
+                        "algorithmic_flops": pre_flops, "ms": round(prefill_ms, 3), "mfma_busy_source": mname,
+                        "scope": "whole prefill forward (vision tower + splice + LLM prefill): algorithmic FLOPs / median device time, against the dense bf16 / fp16 MFMA peak; the "
+                                 "attention runs on fp32 MFMAs (exact fma chains), whose peak is 157 TF: its rows are priced against that",
+                        "kernels": pk}
+
     base = None
     if cfgname == "qwen2vl" and not args.no_cpu_baseline and world == 1:
         base = cpu_baseline(path, rank, ids, image)
@@ -322,7 +409,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int8xint4->int32, fp32 accumulate (Q8_K x Q4_K)", "data": "synthetic",
             "config": {"workload": WORKLOADS[cfgname], "prefill_tokens": S, "parallelism": "replicas" if world > 1 else "single", "rccl_world": world},
             "prefill_ms": round(prefill_ms, 3), "prefill_ms_runs": [round(v, 3) for v in pre], "prefill_tok_s": round(1000.0 * S / prefill_ms, 1),
-            "decode_weight_bytes_per_token": int(wbytes), "roofline": roofline, "cpu_baseline": base, "vit_prefill": vit,
+            "decode_weight_bytes_per_token": int(wbytes), "roofline": roofline, "prefill_roofline": prefill_roofline, "cpu_baseline": base, "vit_prefill": vit,
             "setup_s": {"weights": round(t_weights, 1), "load": round(t_load, 2)}, "load": load,
         }
         print(json.dumps(out))

@@ -242,6 +242,9 @@ int mllm_hip_fa2_vt(const float *Q, int64_t ldq, const void *K, int64_t ldk, con
 int mllm_hip_patch_gemm_f32(const float *patches, const float *W, const float *bias, float *out, int N, int KK, int OC, void *stream);
 /* gather of conv2d receptive fields from the (h, c, w)-ordered image into `[oh*ow][c][kh][kw]` rows (Convolution.cpp:8-33,45-60) */
 int mllm_hip_im2patch_hcw(const float *img, float *patches, int H, int C, int W, int p, void *stream);
+/* the same gather from an image in the MEMORY order of the reference's image Tensor: `[B, head = H, sequence = C, dimension = W]` is BSHD, i.e. `[C][H][W]` in memory
+ * (mllm/Tensor.hpp:264-311 offset(); what Backend::copy_from_host uploads for CPUConvolution2D's input, op/CPUConvolution2D.cpp:112-149) -- the form the Backend / Op adapter binds */
+int mllm_hip_im2patch_chw(const float *img, float *patches, int H, int C, int W, int p, void *stream);
 
 /* ---- Qwen2-VL image preprocessing on the device.  Qwen2VLImageProcessor::preprocess_images (models/qwen2_vl/processing_qwen2_vl.hpp:190-235) after the
  *      decode: x/255 (processor/PreProcess.cpp:37-43), smart_resize (:84-109), the cubic B-spline resample of stb_image_resize2 with edge clamp (PreProcess.cpp:84-154), per-channel

@@ -7,6 +7,7 @@
 #include <unistd.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "Module.hpp"
@@ -27,6 +28,7 @@ HIPBackend::HIPBackend(int device) {
     check(mllm_hip_stream_create(&stream_), "mllm_hip_stream_create");
     registerOps();
     registerFuncs();
+    dump_dir_ = getenv("MLLM_HIP_DUMP_DIR");
 }
 
 // ---- reference-counted blocks ---------------------------------------------------------------------------------------------------------------------------------
@@ -295,6 +297,7 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
     op->setUp(input_tensors, out_tensors);
     op->execute(input_tensors, out_tensors);
     ++ops_run_;
+    if (dump_dir_) dump_outputs(op, out_tensors);
     // a shadow describes what the host uploaded; an Op that wrote the block on the device (in place, or into a recycled pool block) has made it stale
     if (!shadows_.empty())
         if (auto *hop = dynamic_cast<HIPOp *>(op); !hop || !hop->keeps_shadow())
@@ -302,6 +305,27 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
     vector<Tensor> results;
     for (const auto &out_tensor : out_tensors) results.push_back(*out_tensor);
     return results;
+}
+
+// bring-up aid (MLLM_HIP_DUMP_DIR set when the backend is created): every Op's fp32 outputs land in <dir>/<serial>_<op name>_<k>.f32, in device memory order (contiguous
+// BSHD), with the shape in <dir>/index.txt -- what a stage-by-stage comparison against the oracle's composition needs.  Synchronises after every Op; never on by default.
+void HIPBackend::dump_outputs(Op *op, const std::vector<std::shared_ptr<Tensor>> &outs) {
+    for (size_t k = 0; k < outs.size(); ++k) {
+        auto &t = outs[k];
+        if (!t->device_memory().handle || t->count() == 0 || (t->dtype() != MLLM_TYPE_F32 && t->dtype() != MLLM_TYPE_F16)) continue;
+        const size_t bytes = (size_t)t->count() * (t->dtype() == MLLM_TYPE_F16 ? 2 : 4);
+        std::vector<char> host(bytes);
+        check(mllm_hip_d2h(host.data(), t->device_memory().handle, bytes, stream_), "mllm_hip_d2h");
+        std::string nm = t->name();
+        for (auto &ch : nm) if (ch == '/' || ch == ' ') ch = '_';
+        char pre[32];
+        snprintf(pre, sizeof pre, "%05ld_", ops_run_);
+        const std::string file = std::string(pre) + nm + "_" + std::to_string(k) + (t->dtype() == MLLM_TYPE_F16 ? ".f16" : ".f32");
+        FILE *f = fopen((std::string(dump_dir_) + "/" + file).c_str(), "wb");
+        if (f) { fwrite(host.data(), 1, bytes, f); fclose(f); }
+        FILE *ix = fopen((std::string(dump_dir_) + "/index.txt").c_str(), "a");
+        if (ix) { fprintf(ix, "%s %d %d %d %d optype=%d\n", file.c_str(), t->batch(), t->head(), t->sequence(), t->dimension(), (int)op->type()); fclose(ix); }
+    }
 }
 
 std::vector<Tensor> HIPBackend::runForward(Module *module, std::vector<Tensor> inputs, std::vector<std::any> args) {

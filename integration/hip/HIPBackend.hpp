@@ -159,6 +159,8 @@ private:
     std::unordered_map<const void *, RopeTables> vision_;
     std::unordered_map<std::string, std::pair<void *, size_t>> maps_;      // .mllm path -> read-only mmap (load_from_file)
     long forward_serial_ = 0, ops_run_ = 0;
+    const char *dump_dir_ = nullptr;      // MLLM_HIP_DUMP_DIR: bring-up dumps of every Op's outputs (HIPBackend.cpp: dump_outputs)
+    void dump_outputs(Op *op, const std::vector<std::shared_ptr<Tensor>> &outs);
     std::vector<std::pair<int, std::string>> refused_;
 };
 

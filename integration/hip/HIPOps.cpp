@@ -570,7 +570,7 @@ public:
         } else {
             const int H = inputs[0]->head(), W = inputs[0]->dimension(), N = (H / kh_) * (W / kw_);
             float *patches = (float *)b->scratch(3, (size_t)N * KK * 4), *rows = (float *)b->scratch(2, (size_t)N * out_ch_ * 4);
-            HIPCHK(mllm_hip_im2patch_hcw((const float *)dptr(inputs[0]), patches, H, in_ch_, W, kh_, b->stream()));
+            HIPCHK(mllm_hip_im2patch_chw((const float *)dptr(inputs[0]), patches, H, in_ch_, W, kh_, b->stream()));      // the image Tensor [1, H, C, W] is BSHD: [C][H][W] in memory
             // rows [oh*ow][OC] -> the reference's output [B, H/p, OC, W/p], which in BSHD memory order is [OC][oh][ow]
             HIPCHK(mllm_hip_patch_gemm_f32(patches, w, bias, rows, N, KK, out_ch_, b->stream()));
             HIPCHK(mllm_hip_transpose_f32(rows, (float *)dptr(outputs[0]), N, out_ch_, b->stream()));

@@ -762,7 +762,10 @@ __global__ __launch_bounds__(256) void store_f16_kernel(const float *__restrict_
 }
 // conv2d receptive-field gather: image given in logical (h, c, w) order -> rows [oh*ow][c][kh][kw], the flattening the
 // reference uses for both kernel and receptive field (Convolution.cpp:8-33, :45-60), so weights stay [OC][C][kh][kw]
-__global__ __launch_bounds__(256) void im2patch_hcw_kernel(const float *__restrict__ img, float *__restrict__ patches, int H, int C, int W, int p) {
+// CHW: the image in the MEMORY order of the reference's image Tensor [B, head = H, sequence = C, dimension = W] (BSHD memory = [C][H][W]: what a Tensor uploaded by
+// Backend::copy_from_host holds); same rows out
+template <bool CHW>
+__global__ __launch_bounds__(256) void im2patch_kernel(const float *__restrict__ img, float *__restrict__ patches, int H, int C, int W, int p) {
     const int ow = W / p, KK = p * C * p;
     const int64_t total = (int64_t)(H / p) * ow * KK;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(256) void im2patch_hcw_kernel(const float *__restri
         const int pix = (int)(t / KK);
         const int kw = k % p, kh = (k / p) % p, c = k / (p * p);
         const int oy = pix / ow, ox = pix % ow;
-        patches[t] = img[((int64_t)(oy * p + kh) * C + c) * W + ox * p + kw];
+        patches[t] = CHW ? img[((int64_t)c * H + (oy * p + kh)) * W + ox * p + kw] : img[((int64_t)(oy * p + kh) * C + c) * W + ox * p + kw];
     }
 }
 
@@ -1141,8 +1144,13 @@ extern "C" int mllm_hip_store_f16_t(const float *x, int64_t ldx, uint16_t *out, 
 }
 extern "C" int mllm_hip_im2patch_hcw(const float *img, float *patches, int H, int C, int W, int p, void *stream) {
     if (H % p || W % p) return MLLM_HIP_ERR_SHAPE;
-    hipLaunchKernelGGL(im2patch_hcw_kernel, dim3(grid_for((int64_t)H * C * W, 256)), dim3(256), 0, as_stream(stream), img, patches, H, C, W, p);
+    hipLaunchKernelGGL(im2patch_kernel<false>, dim3(grid_for((int64_t)H * C * W, 256)), dim3(256), 0, as_stream(stream), img, patches, H, C, W, p);
     return MH_LAUNCH_OK("im2patch_hcw");
+}
+extern "C" int mllm_hip_im2patch_chw(const float *img, float *patches, int H, int C, int W, int p, void *stream) {
+    if (H % p || W % p) return MLLM_HIP_ERR_SHAPE;
+    hipLaunchKernelGGL(im2patch_kernel<true>, dim3(grid_for((int64_t)H * C * W, 256)), dim3(256), 0, as_stream(stream), img, patches, H, C, W, p);
+    return MH_LAUNCH_OK("im2patch_chw");
 }
 
 // ---- host-side rotary tables: the reference's own libm formulas ------------------------------------------------------

@@ -111,6 +111,7 @@ int mllm_hip_patch_gemm_f32(const float *p, const float *W, const float *bias, f
     return 0;
 }
 int mllm_hip_im2patch_hcw(const float *img, float *patches, int H, int C, int W, int p, void *) { rd(img, (size_t)H * C * W * 4); wr(patches, (size_t)(H / p) * (W / p) * C * p * p * 4); return 0; }
+int mllm_hip_im2patch_chw(const float *img, float *patches, int H, int C, int W, int p, void *) { rd(img, (size_t)H * C * W * 4); wr(patches, (size_t)(H / p) * (W / p) * C * p * p * 4); return 0; }
 int mllm_hip_sliding_window_mask(const float *x, float *y, int S, int H, int keys, int, void *) { rd(x, (size_t)S * H * keys * 4); wr(y, (size_t)S * H * keys * 4); return 0; }
 int mllm_hip_topk_rows(const float *x, int64_t ldx, float *v, float *i, int rows, int n, int k, void *) { rd2(x, ldx, rows, n, 4); wr(v, (size_t)rows * k * 4); wr(i, (size_t)rows * k * 4); return 0; }
 int mllm_hip_gather_rows(const float *src, int64_t lds, int n_src_rows, const float *idx, float *out, int64_t ldo, int R, int D, int, void *) {

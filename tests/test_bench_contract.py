@@ -8,10 +8,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _line_path():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))[-1]
+
+
 def _line():
     """The newest committed bench line (profiles/rNN_bench_line.json)."""
-    import glob
-    return json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))[-1]))
+    return json.load(open(_line_path()))
 
 
 def test_committed_bench_line_has_the_contract_fields():
@@ -54,6 +58,32 @@ def test_roofline_and_cpu_baseline_objects():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["unit"] == "tok/s" and c["cores"] >= 1
+
+
+def test_prefill_roofline_and_host_cpus():
+    """Round 4 on: the prefill half of the metric carries its own roofline object (MFMA-bound: algorithmic FLOPs of the forward over the median device time against the dense
+    bf16 peak, and the GEMM / attention kernels each against the peak of the MFMA form they run on, with the PMC pass's matrix-pipe busy fraction), every fraction is
+    recomputable from the numbers beside it, and cpu_baseline states the box's core count next to the threads used."""
+    if os.path.basename(_line_path()) < "r04":
+        return
+    d = _line()
+    p = d["prefill_roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_flops", "ms", "kernels"):
+        assert k in p, k
+    assert p["bound"] == "mfma" and p["unit"] == "TFLOP/s" and p["peak"] == 2500.0
+    assert abs(p["ms"] - d["prefill_ms"]) < 1e-6
+    assert abs(p["achieved"] - p["algorithmic_flops"] / (p["ms"] * 1e-3) / 1e12) / p["achieved"] < 1e-2 and abs(p["frac"] - p["achieved"] / p["peak"]) < 1e-3
+    names = [k["kernel"] for k in p["kernels"]]
+    assert any(n.startswith("gemm_q4k") for n in names) and any(n.startswith("fa2_prefill") for n in names)
+    for k in p["kernels"]:
+        assert abs(k["achieved_TFps"] - k["flops_per_launch"] / (k["us_per_launch"] * 1e-6) / 1e12) / k["achieved_TFps"] < 2e-2
+        assert abs(k["frac"] - k["achieved_TFps"] / k["peak_TFps"]) < 1e-3
+        assert k["peak_TFps"] == (2500.0 if k["kernel"].startswith("gemm_q4k") else 157.3)
+        assert k["mfma_busy_frac"] is None or 0.0 < k["mfma_busy_frac"] < 1.0
+    fc1 = next(k for k in p["kernels"] if k["kernel"] == "gemm_q4k vit fc1")
+    assert fc1["shape_MNK"] == [1024, 5120, 1280] and fc1["flops_per_launch"] == 2.0 * 1024 * 5120 * 1280
+    c = d["cpu_baseline"]
+    assert c["host_cpus"] >= c["cores"] >= 1
 
 
 def test_bench_fails_loudly_without_a_hip_device():
