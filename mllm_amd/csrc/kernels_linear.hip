@@ -611,236 +611,6 @@ __global__ __launch_bounds__(256, 2) void gemm_q4k_kernel(const uint8_t *__restr
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// The same GEMM with the chains of a tile spread over FOUR waves (round 4): workgroup = 512 threads = the same 32 (m) x 64 (n) tile, the same packed operands and
-// the same ring of half-super-block slots, but wave (nw = wid >> 2, cw = wid & 3) owns, of n-tile nw, the two column classes {cw, cw + 4} and the mins lane cw:
-// 48 accumulator registers instead of 96, nothing carried across the barrier but the accumulators and dd, no register above 128 -- so a SIMD holds FOUR waves
-// (two workgroups per CU as before), and what the two-wave form exposed (barrier -> DMA issue -> LDS reads -> expand -> MFMA -> retire, one dependent stream per
-// wave) runs under the other three waves' streams.  Per half-step hb a wave takes ONE class (4 hb + cw): two MFMAs (k-halves), on the odd half the mins MFMA.
-// The class pairs the reference's hsum adds first, (a_t + a_{t+4}), are the two accumulators of one wave; the tile's four waves then meet once through LDS for
-// (s0 + s2) + (s1 + s3) and (m0 + m2) + (m1 + m3) (IEEE adds commute: who performs an add does not matter), each finishing four of the sixteen rows-registers.
-// The block scales (y.d, x.d, x.dmin) arrive twice per block -- in the even slot's aux fragment and again in the odd slot's spare one -- so the mins scale
-// dm = -y.d * x.dmin is formed where it is used instead of living in sixteen registers across the barrier.
-// DMA: every wave issues exactly two 1-KiB fragments per half-step: wave w fragment w (activations) and fragment 8 + w (w < 4: nibbles; w >= 4: aux).
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void gemm_q4k_kernel8(const uint8_t *__restrict__ Wp, const uint8_t *__restrict__ Xp, const float *__restrict__ bias,
-                                                           void *__restrict__ y, int y_f16, int64_t ldy, const float *__restrict__ residual, int M, int N,
-                                                           int nb, int m_fastest) {
-    extern __shared__ __attribute__((aligned(16))) char ring[];
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) const char *lds_cp;
-    const int GXt = (N + 63) / 64, MTt = (M + 31) / 32;
-    const int tile_x = m_fastest ? (int)blockIdx.x / MTt : (int)blockIdx.x % GXt, tile_y = m_fastest ? (int)blockIdx.x % MTt : (int)blockIdx.x / GXt;
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = lane & 31, h = lane >> 5;
-    const int NT = (N + 31) / 32;
-    const int nw = wid >> 2, cw = wid & 3;
-    const int mt = tile_y, nt = tile_x * 2 + nw;
-    const bool active = nt < NT;
-    const size_t tbw = q4kp_tile_blocks(N, nb), tbx = q4kp_tile_blocks(M, nb);
-    const int nts0 = min(tile_x * 2, NT - 1), nts1 = min(tile_x * 2 + 1, NT - 1);
-    const uint8_t *XpM = Xp + tbx * Q4KP_W_PER_BLK, *XpD = XpM + tbx * Q4KP_M_PER_BLK;
-    const uint8_t *WpS = Wp + tbw * Q4KW_Q_PER_BLK, *WpM = WpS + tbw * Q4KW_S_PER_BLK, *WpD = WpM + tbw * Q4KW_M_PER_BLK;
-    const unsigned ring0 = (unsigned)(size_t)ring;
-    // ---- this wave's two DMA streams: per-lane source pointers, advanced by a per-lane stride per half-step (A, nibbles) or per block (aux) ----
-    const uint8_t *pA = Xp + (size_t)mt * nb * Q4KP_W_PER_BLK + (size_t)wid * 1024 + lane * 16;      // fragment wid of every half-step: 8 KiB further per half-step
-    const uint8_t *pe = Xp + lane * 16, *po = Xp + lane * 16;     // second fragment, even / odd half (lanes without a job re-read a valid address into an unused KiB)
-    unsigned se = 0, so = 0;                                      // their strides per BLOCK (the nibble streams advance 2 KiB per half-step: both = 4096, po starts 2 KiB in)
-    if (wid < 4) {
-        pe = Wp + (size_t)((wid >> 1) ? nts1 : nts0) * nb * Q4KW_Q_PER_BLK + (size_t)(wid & 1) * 1024 + lane * 16;
-        po = pe + 2048;
-        se = so = 4096u;
-    } else if (wid == 4) {          // even: [Ad | Bd n0 | Bd n1]; odd: Am
-        pe = lane < 8    ? XpD + (size_t)mt * nb * 128 + lane * 16
-             : lane < 24 ? WpD + (size_t)nts0 * nb * 256 + (lane - 8) * 16
-             : lane < 40 ? WpD + (size_t)nts1 * nb * 256 + (lane - 24) * 16
-                         : Xp + lane * 16;
-        se = lane < 8 ? 128u : (lane < 40 ? 256u : 0u);
-        po = XpM + (size_t)mt * nb * 1024 + lane * 16;
-        so = 1024u;
-    } else if (wid == 5) {          // even: [Bs n0 | Bs n1]; odd: Bm n0
-        pe = WpS + (size_t)(lane < 32 ? nts0 : nts1) * nb * 512 + (lane & 31) * 16;
-        se = 512u;
-        po = WpM + (size_t)nts0 * nb * 1024 + lane * 16;
-        so = 1024u;
-    } else if (wid == 6) {          // even: --; odd: Bm n1
-        po = WpM + (size_t)nts1 * nb * 1024 + lane * 16;
-        so = 1024u;
-    } else {                        // even: --; odd: [Ad | Bd n0 | Bd n1] again (the mins scale is formed on the odd half)
-        po = lane < 8    ? XpD + (size_t)mt * nb * 128 + lane * 16
-             : lane < 24 ? WpD + (size_t)nts0 * nb * 256 + (lane - 8) * 16
-             : lane < 40 ? WpD + (size_t)nts1 * nb * 256 + (lane - 24) * 16
-                         : Xp + lane * 16;
-        so = lane < 8 ? 128u : (lane < 40 ? 256u : 0u);
-    }
-    unsigned islot = ring0;
-    auto issue = [&](int hb) __attribute__((always_inline)) {
-        const unsigned d0 = __builtin_amdgcn_readfirstlane(islot + (unsigned)wid * 1024u);
-        const uint8_t *pb = hb == 0 ? pe : po;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                     "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(d0), "v"(pA), "v"(pb) : "memory", "scc");
-        pA += 8192;
-        islot = islot + (unsigned)GQ_SLOT == ring0 + (unsigned)GQ_LDS ? ring0 : islot + (unsigned)GQ_SLOT;
-        if (hb == 0) pe += se; else po += so;
-    };
-    const int TS = 2 * nb;
-    issue(0);
-    issue(1);
-    if (TS > 2) issue(0);
-    __builtin_amdgcn_sched_barrier(0);
-    v16f acc[2], accm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; accm[r] = 0.0f; }
-    v16f zero;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
-    float dd[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dd[r] = 0.0f;
-    v2h sc[2] = {{0, 0}, {0, 0}}, o1024[2] = {{0, 0}, {0, 0}}, o64[2] = {{0, 0}, {0, 0}};
-    const uint32_t k1024 = 0x64006400u, k64 = 0x54005400u;
-    const uint32_t m0f = __builtin_amdgcn_readfirstlane(0x000F000F), mf0 = __builtin_amdgcn_readfirstlane(0x00F000F0);
-    // per-lane LDS read addresses inside slot 0
-    const unsigned lA = ring0 + (unsigned)(2 * cw * 1024 + lane * 16), lQ = ring0 + (unsigned)((8 + 2 * nw + (cw >> 1)) * 1024 + lane * 16 + (cw & 1) * 8);
-    const unsigned lS = ring0 + (unsigned)(13312 + nw * 512 + lane * 8);
-    const unsigned lXe = ring0 + (unsigned)(12288 + 16 * h), lWe = ring0 + (unsigned)(12288 + 128 + nw * 256 + col * 8);      // even slot: fragment 12
-    const unsigned lXo = ring0 + (unsigned)(15360 + 16 * h), lWo = ring0 + (unsigned)(15360 + 128 + nw * 256 + col * 8);      // odd slot: fragment 15
-    const unsigned lAm = ring0 + (unsigned)(12288 + cw * 256 + col * 8), lBm = ring0 + (unsigned)(13312 + nw * 1024 + cw * 256 + col * 8);
-    unsigned cslot = 0;
-    auto step = [&](auto HB, auto REM) __attribute__((always_inline)) {
-        constexpr int hb = decltype(HB)::value, rem = decltype(REM)::value;
-        // this wave's two DMAs of the half-step have landed when at most the (up to two) younger half-steps are outstanding
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (rem >= 3) issue(1 - hb);
-        if (active) {
-            const unsigned cs = __builtin_amdgcn_readfirstlane(cslot);
-            const u32x2 qv = *reinterpret_cast<__attribute__((address_space(3))) const u32x2 *>((lds_cp)(size_t)(lQ + cs));
-            u32x2 sraw;
-            if (hb == 0) sraw = *reinterpret_cast<__attribute__((address_space(3))) const u32x2 *>((lds_cp)(size_t)(lS + cs));
-            const __attribute__((address_space(3))) v8h *A = reinterpret_cast<__attribute__((address_space(3))) const v8h *>((lds_cp)(size_t)(lA + cs));
-            const v8h a0 = A[0], a1 = A[64];
-            const f32x2 dwv = *reinterpret_cast<__attribute__((address_space(3))) const f32x2 *>((lds_cp)(size_t)((hb == 0 ? lWe : lWo) + cs));
-            f32x4 dx[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) dx[g4] = *reinterpret_cast<__attribute__((address_space(3))) const f32x4 *>((lds_cp)(size_t)((hb == 0 ? lXe : lXo) + cs) + 32 * g4);
-            v4h a4, b4;
-            if (hb == 1) {
-                a4 = *reinterpret_cast<__attribute__((address_space(3))) const v4h *>((lds_cp)(size_t)(lAm + cs));
-                b4 = *reinterpret_cast<__attribute__((address_space(3))) const v4h *>((lds_cp)(size_t)(lBm + cs));
-            }
-            if (hb == 0) {
-                const v2h n1024 = {(_Float16)-1024.0f, (_Float16)-1024.0f}, n64 = {(_Float16)-64.0f, (_Float16)-64.0f};
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const unsigned sv = p == 0 ? sraw.x : sraw.y;
-                    sc[p] = __builtin_bit_cast(v2h, sv);
-                    o1024[p] = sc[p] * n1024;
-                    o64[p] = sc[p] * n64;
-                }
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dd[4 * g4 + e] = dx[g4][e] * dwv[0];        // y.d * fp16(x.d)
-            }
-            const v8h b0 = q4_expand(qv[0], sc[0], o1024[0], o64[0], m0f, mf0, k1024, k64);
-            v16f cp = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0);
-            const v8h b1 = q4_expand(qv[1], sc[1], o1024[1], o64[1], m0f, mf0, k1024, k64);
-            cp = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, cp, 0, 0, 0);
-            if (hb == 1) {
-                const u32x2 ua = __builtin_bit_cast(u32x2, a4), ub = __builtin_bit_cast(u32x2, b4);
-                const u32x4 wa = {h == 0 ? ua[0] : 0u, h == 0 ? ua[1] : 0u, 0u, 0u}, wb = {h == 0 ? ub[0] : 0u, h == 0 ? ub[1] : 0u, 0u, 0u};
-                const v16f cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, wa), __builtin_bit_cast(v8h, wb), zero, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[1][r] = __fmaf_rn(dd[r], cp[r], acc[1][r]);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dmr = (-dx[g4][e]) * dwv[1];                             // -y.d * fp16(x.dmin)
-                        accm[4 * g4 + e] = __fmaf_rn(dmr, cm[4 * g4 + e], accm[4 * g4 + e]);
-                    }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][r] = __fmaf_rn(dd[r], cp[r], acc[0][r]);
-            }
-        }
-        cslot = cslot + (unsigned)GQ_SLOT == (unsigned)GQ_LDS ? 0u : cslot + (unsigned)GQ_SLOT;
-    };
-    using std::integral_constant;
-#pragma unroll 1
-    for (int i = 0; i + 2 < nb; ++i) {
-        step(integral_constant<int, 0>{}, integral_constant<int, 3>{});
-        step(integral_constant<int, 1>{}, integral_constant<int, 3>{});
-    }
-    if (nb >= 2) {
-        step(integral_constant<int, 0>{}, integral_constant<int, 3>{});
-        step(integral_constant<int, 1>{}, integral_constant<int, 2>{});
-    }
-    step(integral_constant<int, 0>{}, integral_constant<int, 1>{});
-    step(integral_constant<int, 1>{}, integral_constant<int, 0>{});
-    // ---- the tile's four waves meet: s_cw = a_cw + a_{cw+4} and m_cw go to LDS (the ring is free), wave cw finishes registers 4 cw .. 4 cw + 3 ----
-    __syncthreads();
-    float *xs = reinterpret_cast<float *>(ring) + (size_t)nw * 8192;      // [chain 0..7][lane][16]: 32 KiB per n-tile
-    {
-        f32x4 *dst_s = reinterpret_cast<f32x4 *>(xs + ((size_t)cw * 64 + lane) * 16), *dst_m = reinterpret_cast<f32x4 *>(xs + ((size_t)(4 + cw) * 64 + lane) * 16);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            f32x4 sv, mv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sv[e] = acc[0][4 * g4 + e] + acc[1][4 * g4 + e]; mv[e] = accm[4 * g4 + e]; }
-            dst_s[g4] = sv;
-            dst_m[g4] = mv;
-        }
-    }
-    __syncthreads();
-    const int n = nt * 32 + col;
-    if (!active || n >= N) return;
-    f32x4 sv[4], mv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        sv[c] = *reinterpret_cast<const f32x4 *>(xs + ((size_t)c * 64 + lane) * 16 + 4 * cw);
-        mv[c] = *reinterpret_cast<const f32x4 *>(xs + ((size_t)(4 + c) * 64 + lane) * 16 + 4 * cw);
-    }
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float hs = (sv[0][e] + sv[2][e]) + (sv[1][e] + sv[3][e]);
-        v[e] = hs + ((mv[0][e] + mv[2][e]) + (mv[1][e] + mv[3][e]));
-    }
-    if (bias) {
-        const float bv = bias[n];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] + bv;
-    }
-    const int mb = mt * 32 + 8 * cw + 4 * h;      // register r = 4 cw + e -> row (r & 3) + 8 (r >> 2) + 4 h = e + 8 cw + 4 h
-    if (y_f16) {
-        uint16_t *yp = reinterpret_cast<uint16_t *>(y) + n;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (mb + e < M) yp[(int64_t)(mb + e) * ldy] = f2h(v[e]);
-    } else {
-        float *yp = reinterpret_cast<float *>(y) + n;
-        if (residual) {
-            float res[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) res[e] = residual[(int64_t)min(mb + e, M - 1) * ldy + n];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] + res[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (mb + e < M) yp[(int64_t)(mb + e) * ldy] = v[e];
-    }
-}
 #if defined(MLLM_HIP_STAMPS)
 extern "C" int mllm_hip_debug_read_gemm_stamps(unsigned long long *host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gq_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
@@ -1136,7 +906,6 @@ static int launch_gemm_packed(const void *Wpacked, const float *bias, const void
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GQ_LDS));
-        MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4k_kernel8), hipFuncAttributeMaxDynamicSharedMemorySize, GQ_LDS));
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     // 32 x 64 workgroup tiles, two workgroups per CU (64 KiB of LDS and one wave per SIMD each)
@@ -1145,12 +914,8 @@ static int launch_gemm_packed(const void *Wpacked, const float *bias, const void
     // the operand that all eight XCD L2s re-read should be the smaller one: activations cost 2.16 B per element (fp16 fragments), weights 0.72 B
     const int order_env = option(OPT_GEMM_ORDER);      // 0 / 1 force n- / m-fastest (measurement)
     const int m_fastest = order_env >= 0 ? order_env : (q4kp_bytes(M, K) > q4kw_bytes(N, K) ? 1 : 0);
-    if (option(OPT_GEMM_WAVES) == 4)      // the round-2 form: two waves per tile, 96 accumulators each (kept for A/B measurements)
-        hipLaunchKernelGGL(gemm_q4k_kernel, dim3((unsigned)ntiles), dim3(256), GQ_LDS, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16,
-                           ldy, residual, M, N, nb, m_fastest);
-    else
-        hipLaunchKernelGGL(gemm_q4k_kernel8, dim3((unsigned)ntiles), dim3(512), GQ_LDS, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16,
-                           ldy, residual, M, N, nb, m_fastest);
+    hipLaunchKernelGGL(gemm_q4k_kernel, dim3((unsigned)ntiles), dim3(256), GQ_LDS, st, (const uint8_t *)Wpacked, (const uint8_t *)xpack, bias, y, y_dtype == MLLM_HIP_F16,
+                       ldy, residual, M, N, nb, m_fastest);
     return MH_LAUNCH_OK("gemm_q4k");
 }
 // GEMM on pre-packed weights and activations already in packed form (mllm_hip_quantize_q8k_packed / _rmsnorm_packed / _layernorm_packed)
