@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--config", default="qwen2vl", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vit-batch", type=int, default=8)
+    ap.add_argument("--no-batched", dest="batched", action="store_false", help="skip the batched-decode extra (B = 2, 4, 8 sequences per step)")
     ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU: gloo + a stub engine with fixed per-rank step times; the line says dry_run and is no measurement")
     args = ap.parse_args()
     if args.dry_run:
@@ -399,6 +400,38 @@ def main():
                                  "attention runs on fp32 MFMAs (exact fma chains), whose peak is 157 TF: its rows are priced against that",
                         "kernels": pk}
 
+    # ---- batched decode, a reported extra (never `value`): B sequences with the same prompt stepped together share one pass over the weights.  The token is launch- and
+    # latency-bound, not byte-bound, so the aggregate rate grows with B; each row is bit-identical to its batch-1 run (tests/test_batched_decode.py)
+    batched = None
+    if args.batched and rank == 0 and cfgname in ("qwen2vl", "qwen15", "tinyllama"):
+        batched = []
+        bsteps = 32
+        for Bn in (2, 4, 8, 15):
+            m.batch_begin(Bn)
+            cur = []
+            for b in range(Bn):
+                m.batch_select(b)
+                m.clear_kvcache()
+                tk, _, _ = m.prefill(ids, image, meta, want_logits=False)
+                cur.append(tk)
+            for _ in range(4):
+                cur = m.batch_decode(cur, want_logits=False)[0].tolist()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dev = 0.0
+            for _ in range(bsteps):
+                nxt, _, ms_b = m.batch_decode(cur, want_logits=False)
+                cur = nxt.tolist()
+                dev += ms_b
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            T_b = S + 4 + bsteps // 2
+            step_bytes = wbytes + Bn * cfg.layers * 2 * T_b * cfg.kv_heads * cfg.head_dim * 2
+            batched.append({"B": Bn, "steps": bsteps, "tok_s_aggregate": round(Bn * bsteps / wall, 1), "ms_per_step_wall": round(wall * 1e3 / bsteps, 4),
+                            "ms_per_step_device": round(dev / bsteps, 4), "algorithmic_bytes_per_step": int(step_bytes),
+                            "frac": round(step_bytes / (dev / bsteps * 1e-3) / 1e9 / 8000.0, 4)})
+        m.batch_select(0)
+
     base = None
     if cfgname == "qwen2vl" and not args.no_cpu_baseline and world == 1:
         base = cpu_baseline(path, rank, ids, image)
@@ -410,6 +443,7 @@ def main():
             "config": {"workload": WORKLOADS[cfgname], "prefill_tokens": S, "parallelism": "replicas" if world > 1 else "single", "rccl_world": world},
             "prefill_ms": round(prefill_ms, 3), "prefill_ms_runs": [round(v, 3) for v in pre], "prefill_tok_s": round(1000.0 * S / prefill_ms, 1),
             "decode_weight_bytes_per_token": int(wbytes), "roofline": roofline, "prefill_roofline": prefill_roofline, "cpu_baseline": base, "vit_prefill": vit,
+            "batched_decode": batched,
             "setup_s": {"weights": round(t_weights, 1), "load": round(t_load, 2)}, "load": load,
         }
         print(json.dumps(out))

@@ -319,6 +319,15 @@ int mllm_hip_model_prefill(mllm_hip_model *m, const int32_t *ids, int n_ids, con
                            const float *visual_dev, int n_visual_rows, float *logits_host, int32_t *next_token, float *elapsed_ms);
 /* One decode forward for `token` at the next position */
 int mllm_hip_model_decode(mllm_hip_model *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms);
+/* Batched decode (the reference's hook: KVCache_batch, mllm/Types.hpp:26-33): B <= 15 independent sequences share one pass over the weights per step.
+ * batch_begin(B) gives the model B sequences (sequence 0 is its own cache; the others get their own K / V slabs); batch_select(seq) makes `seq` the one that
+ * mllm_hip_model_prefill / _decode / _generate / _clear_kvcache / _cache_len act on (so every sequence is prefilled with the ordinary call, image prompts included);
+ * batch_decode(B, tokens) steps sequences 0 .. B-1 together: tokens[b] is appended to sequence b, logits_host (optional) receives `[B][vocab]`, next_tokens (optional)
+ * the B greedy ids.  Rows never mix (attention runs per sequence on its own cache; every other Op is row-wise), so row b equals, bit for bit, what sequence b
+ * produces stepping alone.  The single-sequence fused decode step stays the headline path; this is the aggregate-throughput form. */
+int mllm_hip_model_batch_begin(mllm_hip_model *m, int B);
+int mllm_hip_model_batch_select(mllm_hip_model *m, int seq);
+int mllm_hip_model_batch_decode(mllm_hip_model *m, int B, const int32_t *tokens, float *logits_host, int32_t *next_tokens, float *elapsed_ms);
 /* `steps` greedy decode forwards back to back on the device (argmax on device, no per-token D2H): SURVEY N2, the loop of
  * Module::generate (mllm/Module.cpp:63-100) with the greedy method.  tokens_host receives the generated ids. */
 int mllm_hip_model_generate(mllm_hip_model *m, int32_t first_token, int steps, int32_t *tokens_host, float *elapsed_ms);

@@ -57,4 +57,15 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
 int argmax_row_launch(const DecodeCtx &c, const float *logits, int n, int *out, hipStream_t st);      // first-maximum argmax over the chip, partials in c.part_val / c.part_idx
 int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st);
 
+// ---- batched decode (engine.hip: mllm_hip_model_batch_decode): the one Op of a step that is not row-wise, for all B sequences in one launch each ----
+// one sequence's KV slabs (bases of layer 0) and the tokens its cache holds BEFORE this step
+struct SeqKV { uint16_t *k; uint16_t *v; int t; int pad; };
+// row b of qkv ([B][ldq]: q | k | v of sequence b's new token): q rotated in place, k rotated -> fp16 row t_b of sequence b's K slab, v -> column t_b of its transposed V slab
+// (qkv_rope_append_kernel's arithmetic, S = 1 per sequence; rotary row b of sin_t / cos_t)
+int seqs_rope_append_launch(float *qkv, int64_t ldq, const float *sin_t, const float *cos_t, int ld_tab, const SeqKV *seqs_dev, int64_t layer_k_off, int64_t layer_v_off,
+                            int64_t ldk, int64_t ldvt, int B, int Hq, int Hkv, int D, hipStream_t st);
+// __fa2_decode of row b's query over sequence b's t_b + 1 keys (fa2_decode_kernel's body, grid = heads x sequences); cap = the slabs' capacity in keys
+int seqs_fa2_decode_launch(const float *q, int64_t ldq, const SeqKV *seqs_dev, int64_t layer_k_off, int64_t layer_v_off, int64_t ldk, int64_t ldvt, float *o, int64_t ldo, int B,
+                           int Hq, int Hkv, int D, int cap, hipStream_t st);
+
 }  // namespace mllm_hip

@@ -219,6 +219,15 @@ struct mllm_hip_model {
     // state
     int cache_len = 0;
     float last_pos = -1.0f;
+    // batched decode (mllm_hip_model_batch_*): B independent sequences, each with its own KV slabs and counters; sequence 0 is the model's own.  m->kslab / vslab /
+    // cache_len / last_pos always describe the SELECTED sequence (cur_seq); the others are parked in seqs[]
+    struct Seq { uint16_t *kslab = nullptr, *vslab = nullptr; int cache_len = 0; float last_pos = -1.0f; };
+    std::vector<Seq> seqs;
+    int cur_seq = 0;
+    int gemm_min_rows = 16;      // rows from which a Linear takes the packed MFMA GEMM (its 32-row tile costs the same for 1 .. 32 rows); a batched step of B >= 4 lowers it to B
+    SeqKV *seqkv_dev = nullptr;
+    bool needs_arm = false;      // a batched step moved the selected sequence on: the fused decode step's device state is re-armed before its next use
+    float *blogits = nullptr, *bnormed = nullptr; int8_t *bx80_qs = nullptr; uint16_t *bx80_d = nullptr; int *btok = nullptr; int batch_cap = 0;
     int64_t decode_weight_bytes = 0, resident_bytes = 0, released_bytes = 0;      // device bytes held after the load / raw rows and packs not kept (load_linear_q4k)
     float load_total_ms = 0, load_h2d_ms = 0, load_tail_ms = 0;
 
@@ -646,32 +655,32 @@ static int ensure_xpack(M *m, int rows, int K) {
     return 0;
 }
 static int q_quant(M *m, const float *x, const Q8Planes &p, int rows, int K) {
-    if (rows >= 16) { EH(ensure_xpack(m, rows, K)); return mllm_hip_quantize_q8k_packed(x, m->xpack, rows, K, m->st); }
+    if (rows >= m->gemm_min_rows) { EH(ensure_xpack(m, rows, K)); return mllm_hip_quantize_q8k_packed(x, m->xpack, rows, K, m->st); }
     return mllm_hip_quantize_q8k(x, p.qs, p.d, p.bs, rows, K, m->st);
 }
 // activation + quantiser in one launch for the GEMM path; the separate launches otherwise
 static int q_act_quant(M *m, const float *x, float *scratch, const uint16_t *lut, const Q8Planes &p, int rows, int K) {
-    if (rows >= 16) { EH(ensure_xpack(m, rows, K)); return mllm_hip_quantize_q8k_packed_act(x, lut, m->xpack, rows, K, m->st); }
+    if (rows >= m->gemm_min_rows) { EH(ensure_xpack(m, rows, K)); return mllm_hip_quantize_q8k_packed_act(x, lut, m->xpack, rows, K, m->st); }
     EH(mllm_hip_act_lut(x, scratch, (int64_t)rows * K, lut, m->st));
     return q_quant(m, scratch, p, rows, K);
 }
 static int q_silu_mul_quant(M *m, const float *gu, float *scratch, const Q8Planes &p, int rows, int I) {
-    if (rows >= 16) { EH(ensure_xpack(m, rows, I)); return mllm_hip_quantize_q8k_packed_silu_mul(gu, m->xpack, rows, I, m->st); }
+    if (rows >= m->gemm_min_rows) { EH(ensure_xpack(m, rows, I)); return mllm_hip_quantize_q8k_packed_silu_mul(gu, m->xpack, rows, I, m->st); }
     EH(mllm_hip_silu_mul(gu, scratch, rows, I, m->st));
     return q_quant(m, scratch, p, rows, I);
 }
 static int q_rmsnorm(M *m, const float *x, const float *w, const Q8Planes &p, int rows, int dim, float eps) {
-    if (rows >= 16) { EH(ensure_xpack(m, rows, dim)); return mllm_hip_rmsnorm_packed(x, w, nullptr, m->xpack, rows, dim, eps, 0, m->st); }
+    if (rows >= m->gemm_min_rows) { EH(ensure_xpack(m, rows, dim)); return mllm_hip_rmsnorm_packed(x, w, nullptr, m->xpack, rows, dim, eps, 0, m->st); }
     return mllm_hip_rmsnorm(x, w, nullptr, p.qs, p.d, p.bs, rows, dim, eps, 0, m->st);
 }
 static int q_layernorm(M *m, const float *x, const float *w, const float *b, const Q8Planes &p, int rows, int dim, float eps) {
-    if (rows >= 16) { EH(ensure_xpack(m, rows, dim)); return mllm_hip_layernorm_packed(x, w, b, nullptr, m->xpack, rows, dim, eps, m->st); }
+    if (rows >= m->gemm_min_rows) { EH(ensure_xpack(m, rows, dim)); return mllm_hip_layernorm_packed(x, w, b, nullptr, m->xpack, rows, dim, eps, m->st); }
     return mllm_hip_layernorm(x, w, b, nullptr, p.qs, p.d, p.bs, rows, dim, eps, m->st);
 }
 // Linear on the activations the last q_* call produced
 static int lin(M *m, const LinearW &w, const Q8Planes &x, void *y, int ydt, int64_t ldy, const float *res, int Mrows) {
-    if (Mrows >= 16 ? !w.wp : !w.w) { fprintf(stderr, "mllm_hip: a Linear met %d rows, a form it was not loaded for\n", Mrows); return MLLM_HIP_ERR_SHAPE; }
-    if (Mrows >= 16) return mllm_hip_linear_q4kp_packed(w.wp, w.bias, m->xpack, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
+    if (Mrows >= m->gemm_min_rows ? !w.wp : !w.w) { fprintf(stderr, "mllm_hip: a Linear met %d rows, a form it was not loaded for\n", Mrows); return MLLM_HIP_ERR_SHAPE; }
+    if (Mrows >= m->gemm_min_rows) return mllm_hip_linear_q4kp_packed(w.wp, w.bias, m->xpack, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
     return mllm_hip_linear_q4k_q8k(w.w, w.bias, x.qs, x.d, x.bs, y, ydt, ldy, res, Mrows, w.N, w.K, m->st);
 }
 
@@ -960,6 +969,7 @@ extern "C" int mllm_hip_model_prefill(mllm_hip_model *m, const int32_t *ids, int
     // the position the decode loop continues from: M-RoPE row 0 (t axis), last column (get_position_ids' decode branch); HF rotary: the token count
     m->last_pos = m->mrope ? pos[(size_t)n_ids - 1] : (float)(m->cache_len - 1);
     EH(finish(m, logits_host, next_token, elapsed_ms));
+    m->needs_arm = false;
     return arm_decode(m);
 }
 
@@ -1020,6 +1030,7 @@ static int resync_after_error(mllm_hip_model *m, int rc) {
 extern "C" int mllm_hip_model_decode(mllm_hip_model *m, int32_t token, float *logits_host, int32_t *next_token, float *elapsed_ms) {
     if (!m || !m->has_llm || m->cache_len <= 0) return MLLM_HIP_ERR_ARG;
     if (m->cache_len + 1 > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + 1 > %d)\n", m->cache_len, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
+    if (m->needs_arm) { EH(arm_decode(m)); m->needs_arm = false; }
     m->pin_tok[0] = token;      // (page-locked: the copy is stream-ordered and the word is not written again before finish() has synchronised)
     HH(hipMemcpyAsync(&m->d_state->token, m->pin_tok, 4, hipMemcpyHostToDevice, m->st));
     HH(hipEventRecord(m->ev0, m->st));
@@ -1032,6 +1043,7 @@ extern "C" int mllm_hip_model_decode(mllm_hip_model *m, int32_t token, float *lo
 extern "C" int mllm_hip_model_generate(mllm_hip_model *m, int32_t first_token, int steps, int32_t *tokens_host, float *elapsed_ms) {
     if (!m || !m->has_llm || m->cache_len <= 0 || steps <= 0) return MLLM_HIP_ERR_ARG;
     if (m->cache_len + steps > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + %d > %d)\n", m->cache_len, steps, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
+    if (m->needs_arm) { EH(arm_decode(m)); m->needs_arm = false; }
     DecodeState st0;
     HH(hipMemcpy(&st0, m->d_state, sizeof(st0), hipMemcpyDeviceToHost));
     const int step0 = st0.step;
@@ -1046,6 +1058,131 @@ extern "C" int mllm_hip_model_generate(mllm_hip_model *m, int32_t first_token, i
     return 0;
 }
 
+// ---- batched decode: B independent sequences share ONE pass over the weights per step ---------------------------------------------------------------------------
+// The reference's hook for this is KVCache_batch (mllm/Types.hpp:26-33: the KVCache Op's slab gets a batch dimension); its models then run [B, 1, S, H] activations
+// through the same Ops.  A decode token of this engine is launch- and latency-bound, not byte-bound, so B sequences stepped together cost little more
+// than one.  Rows never mix: every Op of the graph is row-wise (norms, Q8_K quantisation, the GEMV's per-row dot products, SiLU, residual adds) except attention, which
+// runs per sequence on that sequence's own cache -- so row b of a batched step is bit for bit what sequence b would have produced stepping alone (tests/test_batched_decode.py).
+// The step is composed from the per-Op launchers like the prefill (the M < 16 GEMV form reads each weight row once for all B rows); the fused single-sequence decode
+// kernels and their captured graph stay the headline path (bench.py's `value`); `batched_decode` is reported beside it.
+static void seq_park(M *m) {
+    if (m->seqs.empty()) m->seqs.resize(1);
+    auto &q = m->seqs[m->cur_seq];
+    q.kslab = m->kslab; q.vslab = m->vslab; q.cache_len = m->cache_len; q.last_pos = m->last_pos;
+}
+static int seq_select(M *m, int s) {
+    seq_park(m);
+    if (s == m->cur_seq) return 0;
+    const auto &q = m->seqs[s];
+    m->kslab = q.kslab; m->vslab = q.vslab; m->cache_len = q.cache_len; m->last_pos = q.last_pos;
+    m->dctx.kslab = q.kslab; m->dctx.vslab = q.vslab;
+    m->cur_seq = s;
+    m->needs_arm = m->cache_len > 0;
+    if (m->graph_exec) {      // the captured step holds the previous sequence's slab pointers
+        HH(hipStreamSynchronize(m->st));
+        HH(hipGraphExecDestroy(m->graph_exec)); m->graph_exec = nullptr;
+        if (m->graph) { HH(hipGraphDestroy(m->graph)); m->graph = nullptr; }
+    }
+    return 0;
+}
+extern "C" int mllm_hip_model_batch_begin(mllm_hip_model *m, int B) {
+    if (!m || !m->has_llm || B < 1 || B > 15) return MLLM_HIP_ERR_ARG;      // 15: the rows of a step go through the M < 16 GEMV form
+    const auto &c = m->c;
+    seq_park(m);
+    const size_t kbytes = ((size_t)c.layers * c.cache_limit + 64) * m->KVD * 2, vbytes = (size_t)c.layers * m->KVD * m->vt_ld * 2;
+    while ((int)m->seqs.size() < B) {
+        M::Seq q;
+        EH(m->dalloc(&q.kslab, kbytes)); EH(m->dalloc(&q.vslab, vbytes));
+        HH(hipMemsetAsync(q.kslab, 0, kbytes, m->st));
+        HH(hipMemsetAsync(q.vslab, 0, vbytes, m->st));
+        m->seqs.push_back(q);
+    }
+    if (B > m->batch_cap) {
+        EH(m->dalloc(&m->blogits, (size_t)B * c.vocab * 4)); EH(m->dalloc(&m->bnormed, (size_t)B * c.hidden * 4));
+        EH(m->dalloc(&m->bx80_qs, (size_t)B * c.hidden)); EH(m->dalloc(&m->bx80_d, (size_t)B * (c.hidden / 32) * 2 + 64)); EH(m->dalloc(&m->btok, (size_t)B * 4));
+        EH(m->dalloc(&m->seqkv_dev, (size_t)B * sizeof(SeqKV)));
+        m->batch_cap = B;
+    }
+    HH(hipStreamSynchronize(m->st));
+    return MLLM_HIP_OK;
+}
+extern "C" int mllm_hip_model_batch_select(mllm_hip_model *m, int seq) {
+    if (!m || !m->has_llm) return MLLM_HIP_ERR_ARG;
+    seq_park(m);
+    if (seq < 0 || seq >= (int)m->seqs.size()) return MLLM_HIP_ERR_ARG;
+    return seq_select(m, seq);
+}
+extern "C" int mllm_hip_model_batch_decode(mllm_hip_model *m, int B, const int32_t *tokens, float *logits_host, int32_t *next_tokens, float *elapsed_ms) {
+    if (!m || !m->has_llm || !tokens || B < 1 || B > m->batch_cap) return MLLM_HIP_ERR_ARG;
+    const auto &c = m->c;
+    seq_park(m);
+    if ((int)m->seqs.size() < B) return MLLM_HIP_ERR_ARG;
+    for (int b = 0; b < B; ++b) {
+        if (m->seqs[b].cache_len <= 0) { set_error_msg("mllm_hip_model_batch_decode: sequence %d has no prefill", b); return MLLM_HIP_ERR_ARG; }
+        if (m->seqs[b].cache_len + 1 > c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + 1 > %d)\n", m->seqs[b].cache_len, c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
+    }
+    const int H = c.hidden, I = c.inter, D = m->D, half = D / 2;
+    hipStream_t st = m->st;
+    // the rotary row of every sequence's next position (QWEN2VL: all three axes = last_pos + 1, modeling_qwen2_vl.hpp:423-432; HF rotary: position = tokens in its cache)
+    std::vector<float> idf(B), s((size_t)B * half), co((size_t)B * half);
+    for (int b = 0; b < B; ++b) idf[b] = (float)tokens[b];
+    if (m->mrope) {
+        std::vector<float> pos((size_t)3 * B);
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < B; ++b) pos[(size_t)a * B + b] = m->seqs[b].last_pos + 1.0f;
+        EH(mllm_hip_mrope_table(c.rope_theta, D, pos.data(), B, c.mrope_section, 3, s.data(), co.data()));
+    } else {
+        for (int b = 0; b < B; ++b) {
+            memcpy(s.data() + (size_t)b * half, m->hf_sin.data() + (size_t)m->seqs[b].cache_len * half, (size_t)half * 4);
+            memcpy(co.data() + (size_t)b * half, m->hf_cos.data() + (size_t)m->seqs[b].cache_len * half, (size_t)half * 4);
+        }
+    }
+    HH(hipMemcpyAsync(m->rope_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice, st));
+    HH(hipMemcpyAsync(m->rope_cos, co.data(), co.size() * 4, hipMemcpyHostToDevice, st));
+    HH(hipMemcpyAsync(m->ids_f, idf.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    std::vector<SeqKV> desc(B);
+    for (int b = 0; b < B; ++b) desc[b] = SeqKV{m->seqs[b].kslab, m->seqs[b].vslab, m->seqs[b].cache_len, 0};
+    HH(hipMemcpyAsync(m->seqkv_dev, desc.data(), (size_t)B * sizeof(SeqKV), hipMemcpyHostToDevice, st));
+    HH(hipStreamSynchronize(st));      // the host vectors go out of scope; inputs resident when the clock starts
+    // from four rows on the Linears take the packed MFMA GEMM: its 32-row tile costs the same for 1 .. 32 rows, the M < 16 GEMV form pays its chain tables per row
+    struct MinRows { M *m; int keep; ~MinRows() { m->gemm_min_rows = keep; } } restore{m, m->gemm_min_rows};
+    if (B >= 4) m->gemm_min_rows = B;
+    HH(hipEventRecord(m->ev0, st));
+    EH(mllm_hip_embedding_q40(m->ids_f, m->emb_qs, m->emb_d, m->h0, B, H, c.vocab, st));
+    float *h = m->h0, *h2 = m->h1;
+    for (int li = 0; li < c.layers; ++li) {
+        auto &L = m->layers[li];
+        EH(q_rmsnorm(m, h, L.in_norm, m->xq, B, H, c.rms_eps));
+        EH(lin(m, L.qkv, m->xq, m->qkv, MLLM_HIP_F32, m->QKV, nullptr, B));
+        // attention is the one Op that is not row-wise: sequence b's new key / value go to ITS slabs at ITS position, its query walks ITS cache -- all B in one launch each
+        const int64_t koff = (int64_t)li * c.cache_limit * m->KVD, voff = (int64_t)li * m->KVD * m->vt_ld;
+        EH(seqs_rope_append_launch(m->qkv, m->QKV, m->rope_sin, m->rope_cos, half, m->seqkv_dev, koff, voff, m->KVD, m->vt_ld, B, c.heads, c.kv_heads, D, st));
+        EH(seqs_fa2_decode_launch(m->qkv, m->QKV, m->seqkv_dev, koff, voff, m->KVD, m->vt_ld, m->attn, m->HD, B, c.heads, c.kv_heads, D, c.cache_limit, st));
+        EH(q_quant(m, m->attn, m->xq, B, m->HD));
+        EH(lin(m, L.o, m->xq, h2, MLLM_HIP_F32, H, h, B));
+        EH(q_rmsnorm(m, h2, L.post_norm, m->xq, B, H, c.rms_eps));
+        EH(lin(m, L.gu, m->xq, m->gu, MLLM_HIP_F32, 2 * I, nullptr, B));
+        EH(q_silu_mul_quant(m, m->gu, m->act, m->xq2, B, I));
+        EH(lin(m, L.down, m->xq2, h, MLLM_HIP_F32, H, h2, B));
+    }
+    if (c.tie_embedding) {
+        EH(mllm_hip_rmsnorm(h, m->final_norm, m->bnormed, nullptr, nullptr, nullptr, B, H, c.final_eps, 0, st));
+        EH(mllm_hip_quantize_q80(m->bnormed, m->bx80_qs, m->bx80_d, B, H, st));
+        EH(mllm_hip_linear_q40_q80(m->emb_qs, m->emb_d, nullptr, m->bx80_qs, m->bx80_d, m->blogits, c.vocab, B, c.vocab, H, st));
+    } else {
+        EH(mllm_hip_rmsnorm(h, m->final_norm, nullptr, m->xq.qs, m->xq.d, m->xq.bs, B, H, c.final_eps, 0, st));
+        EH(mllm_hip_linear_q4k_q8k(m->head.w, nullptr, m->xq.qs, m->xq.d, m->xq.bs, m->blogits, MLLM_HIP_F32, c.vocab, nullptr, B, c.vocab, H, st));
+    }
+    for (int b = 0; b < B; ++b) EH(argmax_row_launch(m->dctx, m->blogits + (size_t)b * c.vocab, c.vocab, m->btok + b, st));
+    HH(hipEventRecord(m->ev1, st));
+    if (logits_host) HH(hipMemcpyAsync(logits_host, m->blogits, (size_t)B * c.vocab * 4, hipMemcpyDeviceToHost, st));
+    if (next_tokens) HH(hipMemcpyAsync(next_tokens, m->btok, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HH(hipStreamSynchronize(st));
+    if (elapsed_ms) HH(hipEventElapsedTime(elapsed_ms, m->ev0, m->ev1));
+    for (int b = 0; b < B; ++b) { m->seqs[b].cache_len += 1; m->seqs[b].last_pos += 1.0f; }
+    if (m->cur_seq < B) { m->cache_len = m->seqs[m->cur_seq].cache_len; m->last_pos = m->seqs[m->cur_seq].last_pos; m->needs_arm = true; }
+    return MLLM_HIP_OK;
+}
+
 // Module::generate's loop (mllm/Module.cpp:63-100) with the method switch of :76-88: greedy / top-k / top-p.  The forward and the candidate selection
 // run on the device; what crosses PCIe per step is the k candidates (top-k) or the sorted prefix that reaches the nucleus mass (top-p, in chunks), and
 // the chosen id going back.  The temperature softmax over the candidates (Generate.cpp:69-87 / :120-136: float exp results, double sum, float
@@ -1058,6 +1195,7 @@ extern "C" int mllm_hip_model_generate_sampled(mllm_hip_model *m, int32_t first_
     if (method == 1 && (top_k < 0 || top_k > 64 || top_k > m->c.vocab)) return MLLM_HIP_ERR_SHAPE;
     if (method == 2 && !(top_p > 0.0f)) return MLLM_HIP_ERR_ARG;      // p <= 0 or NaN keeps no candidate at all (the reference then indexes an empty vector, Generate.cpp:116-118)
     if (m->cache_len + steps > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + %d > %d)\n", m->cache_len, steps, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
+    if (m->needs_arm) { EH(arm_decode(m)); m->needs_arm = false; }
     const int V = m->c.vocab;
     if (method != 0 && !m->samp_val) {
         EH(m->dalloc(&m->samp_val, (size_t)V * 4)); EH(m->dalloc(&m->samp_idx, (size_t)V * 4)); EH(m->dalloc(&m->samp_prob, (size_t)V * 4));

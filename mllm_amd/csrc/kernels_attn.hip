@@ -14,6 +14,7 @@
 // the tile whose row end meets its column end is masked j > i, nothing else is.  Leftover columns: Sk % 4 for fp32 K/V (:152),
 // Sk % (Sk / 4) for fp16 K/V (:1277) -- both kept.
 #include "common.h"
+#include "decode_launch.h"
 #include "kernels_attn_core.h"
 
 namespace mllm_hip {
@@ -330,6 +331,45 @@ __global__ __launch_bounds__(NT) void fa2_decode_kernel(const float *__restrict_
     __syncthreads();
     fa2_decode_head<D, F16, NT, VT>(L, P, K, ldk, V, ldv, kvh * D, kvh * D, Sk, cap, nullptr, nullptr, -1);
     if (threadIdx.x < D) O[head * D + threadIdx.x] = L.ob[threadIdx.x];
+}
+// the same for B sequences in one launch (batched decode): blockIdx.y = sequence, whose slabs and key count come from its descriptor; fp16 K rows, transposed fp16 V
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void fa2_decode_seqs_kernel(const float *__restrict__ Q, int64_t ldq, const SeqKV *__restrict__ seqs, int64_t layer_k_off, int64_t layer_v_off,
+                                                             int64_t ldk, int64_t ldv, float *__restrict__ O, int64_t ldo, int cap, int nslots, int Hq, int Hkv) {
+    extern __shared__ __attribute__((aligned(16))) char fa_smem[];
+    const int head = blockIdx.x, kvh = head / (Hq / Hkv), b = blockIdx.y;
+    const SeqKV sq = seqs[b];
+    const void *K = sq.k + layer_k_off, *V = sq.v + layer_v_off;
+    DecodePrefetch<D, true, NT, true> P;
+    fa2_decode_prefetch<D, true, NT, true>(P, K, ldk, V, ldv, kvh * D, cap, nslots);
+    const int Sk = min(sq.t + 1, cap);
+    const DecodeLds L = carve_decode(fa_smem, cap, D, NT, nslots);
+    if (threadIdx.x < D) L.qs[threadIdx.x] = Q[(int64_t)b * ldq + head * D + threadIdx.x];
+    __syncthreads();
+    fa2_decode_head<D, true, NT, true>(L, P, K, ldk, V, ldv, kvh * D, kvh * D, Sk, cap, nullptr, nullptr, -1);
+    if (threadIdx.x < D) O[(int64_t)b * ldo + head * D + threadIdx.x] = L.ob[threadIdx.x];
+}
+template <int D>
+static int launch_fa2_seqs(const float *q, int64_t ldq, const SeqKV *seqs_dev, int64_t layer_k_off, int64_t layer_v_off, int64_t ldk, int64_t ldvt, float *o, int64_t ldo, int B,
+                           int Hq, int Hkv, int cap, hipStream_t st) {
+    constexpr int NT = 1024;
+    const int nslots = decode_lds_slots(cap, D, NT, 2, true);
+    const size_t lds = decode_lds_bytes(cap, D, NT, 2, nslots, true);
+    if (lds > 160 * 1024) return MLLM_HIP_ERR_SHAPE;
+    auto kern = fa2_decode_seqs_kernel<D, NT>;
+    if (lds > 48 * 1024) MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(Hq, B), dim3(NT), lds, st, q, ldq, seqs_dev, layer_k_off, layer_v_off, ldk, ldvt, o, ldo, cap, nslots, Hq, Hkv);
+    return MH_LAUNCH_OK("fa2_decode_seqs");
+}
+int seqs_fa2_decode_launch(const float *q, int64_t ldq, const SeqKV *seqs_dev, int64_t layer_k_off, int64_t layer_v_off, int64_t ldk, int64_t ldvt, float *o, int64_t ldo, int B,
+                           int Hq, int Hkv, int D, int cap, hipStream_t st) {
+    if (B <= 0) return MLLM_HIP_OK;
+    if (!q || !o || !seqs_dev || Hq <= 0 || Hkv <= 0 || Hq % Hkv || (ldk % 8) || (ldvt % 8)) return MLLM_HIP_ERR_ARG;
+    switch (D) {
+    case 64: return launch_fa2_seqs<64>(q, ldq, seqs_dev, layer_k_off, layer_v_off, ldk, ldvt, o, ldo, B, Hq, Hkv, cap, st);
+    case 128: return launch_fa2_seqs<128>(q, ldq, seqs_dev, layer_k_off, layer_v_off, ldk, ldvt, o, ldo, B, Hq, Hkv, cap, st);
+    default: return MLLM_HIP_ERR_SHAPE;
+    }
 }
 }  // namespace mllm_hip
 

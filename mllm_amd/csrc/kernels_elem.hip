@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "decode_launch.h"
 
 namespace mllm_hip {
 
@@ -753,6 +754,32 @@ __global__ __launch_bounds__(256) void qkv_rope_append_kernel(float *__restrict_
         }
     }
 }
+// the same for B sequences that each append ONE token to their own slabs (batched decode): row b of qkv, rotary row b, destination = sequence b's slabs at its position t_b
+__global__ __launch_bounds__(256) void seqs_rope_append_kernel(float *__restrict__ qkv, int64_t ldq, const float *__restrict__ sin_t, const float *__restrict__ cos_t, int ld_tab,
+                                                               const SeqKV *__restrict__ seqs, int64_t layer_k_off, int64_t layer_v_off, int64_t ldk, int64_t ldv, int Hq, int Hkv,
+                                                               int D) {
+    const int b = blockIdx.y, half = D >> 1;
+    const SeqKV sq = seqs[b];
+    uint16_t *kout = sq.k + layer_k_off + (int64_t)sq.t * ldk, *vout = sq.v + layer_v_off + sq.t;
+    float *row = qkv + (int64_t)b * ldq;
+    const int nq = Hq * half, nk = Hkv * half, nv = Hkv * D;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < nq + nk + nv; t += gridDim.x * 256) {
+        if (t < nq + nk) {
+            const bool isk = t >= nq;
+            const int u = isk ? t - nq : t;
+            const int d = u % half, h = u / half;
+            float *x = row + (isk ? Hq * D : 0) + h * D + d;
+            const float a = x[0], bb = x[half];
+            const float sv = sin_t[(int64_t)b * ld_tab + d], cv = cos_t[(int64_t)b * ld_tab + d];
+            const float v1 = __fmaf_rn(a, cv, -__fmul_rn(bb, sv)), v2 = __fmaf_rn(a, sv, __fmul_rn(bb, cv));
+            if (isk) { uint16_t *o = kout + h * D + d; o[0] = f2h(v1); o[half] = f2h(v2); }
+            else { x[0] = v1; x[half] = v2; }
+        } else {
+            const int c = t - nq - nk;
+            vout[(int64_t)c * ldv] = f2h(row[(Hq + Hkv) * D + c]);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void store_f16_kernel(const float *__restrict__ x, int64_t ldx, uint16_t *__restrict__ out, int64_t ldo, int S, int n) {
     const int64_t total = (int64_t)S * n;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -1132,6 +1159,16 @@ extern "C" int mllm_hip_qkv_rope_append(float *qkv, int64_t ldq, const float *si
     hipLaunchKernelGGL(qkv_rope_append_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), qkv, ldq, sin_t, cos_t, ld_tab, k_rows, ldk, v_t, ldv, S, Hq, Hkv, D);
     return MH_LAUNCH_OK("qkv_rope_append");
 }
+namespace mllm_hip {
+int seqs_rope_append_launch(float *qkv, int64_t ldq, const float *sin_t, const float *cos_t, int ld_tab, const SeqKV *seqs_dev, int64_t layer_k_off, int64_t layer_v_off,
+                            int64_t ldk, int64_t ldvt, int B, int Hq, int Hkv, int D, hipStream_t st) {
+    if (B <= 0) return MLLM_HIP_OK;
+    if (D % 2 || !qkv || !seqs_dev) return MLLM_HIP_ERR_ARG;
+    const int n = (Hq + Hkv) * (D / 2) + Hkv * D;
+    hipLaunchKernelGGL(seqs_rope_append_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, qkv, ldq, sin_t, cos_t, ld_tab, seqs_dev, layer_k_off, layer_v_off, ldk, ldvt, Hq, Hkv, D);
+    return MH_LAUNCH_OK("seqs_rope_append");
+}
+}  // namespace mllm_hip
 extern "C" int mllm_hip_store_f16(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *stream) {
     if (S <= 0 || n <= 0) return MLLM_HIP_OK;
     hipLaunchKernelGGL(store_f16_kernel, dim3(grid_for((int64_t)S * n, 256)), dim3(256), 0, as_stream(stream), x, ldx, out, ldo, S, n);

@@ -31,13 +31,15 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 template <int NSTEPS, int ROWS>
 __global__ __launch_bounds__(256) void gemv_q4k_kernel(const uint8_t *__restrict__ W, const float *__restrict__ bias, const int8_t *__restrict__ xqs,
                                                        const float *__restrict__ xd, const int16_t *__restrict__ xbsums, void *__restrict__ y, int y_f16,
-                                                       const float *__restrict__ residual, int N, int nb, int rows_per_wave) {
+                                                       const float *__restrict__ residual, int N, int nb, int rows_per_wave, int M, int64_t ldy) {
+    // M activation rows (M < 16: batched decode, short prefills) meet every weight row while it sits in registers: the weights are streamed ONCE per launch, the
+    // activation planes of row m (a few KiB, L1 / L2 resident) are re-read per batch of weight rows.  Each (m, n) dot is the M == 1 arithmetic, unchanged.
     __shared__ float2 tab_all[4 * (ROWS < 4 ? ROWS : 4) * NSTEPS * 8 * Q4K_SLOTS];
     const int lane = threadIdx.x & 63, g = lane >> 3, wid = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wid;
     float2 *tab = tab_all + wid * (ROWS < 4 ? ROWS : 4) * NSTEPS * 8 * Q4K_SLOTS;
     Q4KAct<NSTEPS> A;
-    q4k_load_act_planes<NSTEPS>(A, xqs, xd, xbsums, nb, lane);
+    if (M == 1) q4k_load_act_planes<NSTEPS>(A, xqs, xd, xbsums, nb, lane);
     const int qoff = q4k_lane_qoff(lane);
     const int row0 = wave * rows_per_wave;
     const int row1 = min(N, row0 + rows_per_wave);
@@ -54,20 +56,23 @@ __global__ __launch_bounds__(256) void gemv_q4k_kernel(const uint8_t *__restrict
                 q[rr][st] = *reinterpret_cast<const uint4 *>(wb + 16 + qoff);
             }
         }
-        float out[ROWS];
-        wave_lds_fence();   // the previous iteration's chain reads are done before the table is overwritten
-        q4k_dot_rows<NSTEPS, ROWS>(hdr, q, A, nb, lane, tab, out);
-        if (lane == 0) {
+        for (int m = 0; m < M; ++m) {
+            if (M > 1) q4k_load_act_planes<NSTEPS>(A, xqs + (int64_t)m * nb * 256, xd + (int64_t)m * nb, xbsums + (int64_t)m * nb * 16, nb, lane);
+            float out[ROWS];
+            wave_lds_fence();   // the previous iteration's chain reads are done before the table is overwritten
+            q4k_dot_rows<NSTEPS, ROWS>(hdr, q, A, nb, lane, tab, out);
+            if (lane == 0) {
 #pragma unroll
-            for (int rr = 0; rr < ROWS; ++rr) {
-                const int rw = row + rr;
-                if (rw < row1) {
-                    float v = out[rr];
-                    if (bias) v = v + bias[rw];
-                    if (y_f16) reinterpret_cast<uint16_t *>(y)[rw] = f2h(v);
-                    else {
-                        if (residual) v = v + residual[rw];
-                        reinterpret_cast<float *>(y)[rw] = v;
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    const int rw = row + rr;
+                    if (rw < row1) {
+                        float v = out[rr];
+                        if (bias) v = v + bias[rw];
+                        if (y_f16) reinterpret_cast<uint16_t *>(y)[(int64_t)m * ldy + rw] = f2h(v);
+                        else {
+                            if (residual) v = v + residual[(int64_t)m * ldy + rw];
+                            reinterpret_cast<float *>(y)[(int64_t)m * ldy + rw] = v;
+                        }
                     }
                 }
             }
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void gemv_q4k_kernel(const uint8_t *__restrict
 template <int BPL, int LPR>
 __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict__ Wqs, const uint16_t *__restrict__ Wd, const float *__restrict__ bias,
                                                        const int8_t *__restrict__ xqs, const uint16_t *__restrict__ xd, float *__restrict__ y, int N,
-                                                       int rows_per_wave) {
+                                                       int rows_per_wave, int M, int64_t ldy) {
     extern __shared__ __attribute__((aligned(16))) char q40_smem[];
     constexpr int RPW = 64 / LPR;            // rows per load pass
     constexpr int NPASS = 8 / RPW;           // load passes per 8-row chain pass
@@ -93,8 +98,8 @@ __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, wid = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wid;
     float *ts = reinterpret_cast<float *>(q40_smem) + wid * q40_tab_floats(nblk), *td = ts + 8 * q40_ts_stride(nblk);
-    Q40Act<BPL> A;
-    q40_load_act<BPL, LPR>(A, xqs, nullptr, xd, sub);
+    Q40Act<BPL> A;      // (M rows: as in gemv_q4k_kernel, the weight rows of a pass stay in registers while every activation row meets them)
+    if (M == 1) q40_load_act<BPL, LPR>(A, xqs, nullptr, xd, sub);
     const int row0 = wave * rows_per_wave, row1 = min(N, row0 + rows_per_wave);
     for (int base = row0; base < row1; base += 8) {
         uint4 q[NPASS][BPL];
@@ -109,16 +114,19 @@ __global__ __launch_bounds__(256) void gemv_q40_kernel(const uint8_t *__restrict
                 dw[u][b] = Wd[bi];
             }
         }
-        wave_lds_fence();
+        for (int m = 0; m < M; ++m) {
+            if (M > 1) q40_load_act<BPL, LPR>(A, xqs + (int64_t)m * nblk * 32, nullptr, xd + (int64_t)m * nblk, sub);
+            wave_lds_fence();
 #pragma unroll
-        for (int u = 0; u < NPASS; ++u) {
-            const int rl = RPW * u + rsel;
-            q40_emit<BPL, LPR>(q[u], dw[u], A, sub, ts + (size_t)rl * q40_ts_stride(nblk), td + (size_t)rl * q40_td_stride(nblk));
+            for (int u = 0; u < NPASS; ++u) {
+                const int rl = RPW * u + rsel;
+                q40_emit<BPL, LPR>(q[u], dw[u], A, sub, ts + (size_t)rl * q40_ts_stride(nblk), td + (size_t)rl * q40_td_stride(nblk));
+            }
+            wave_lds_fence();
+            const float acc = q40_chain(ts, td, nblk, min(8, row1 - base), lane);
+            const int rw = base + (lane >> 3);
+            if ((lane & 7) == 0 && rw < row1) y[(int64_t)m * ldy + rw] = bias ? acc + bias[rw] : acc;
         }
-        wave_lds_fence();
-        const float acc = q40_chain(ts, td, nblk, min(8, row1 - base), lane);
-        const int rw = base + (lane >> 3);
-        if ((lane & 7) == 0 && rw < row1) y[rw] = bias ? acc + bias[rw] : acc;
     }
 }
 
@@ -856,7 +864,7 @@ __global__ __launch_bounds__(256) void gemm_f32_bhsd_kernel(const float *__restr
 }
 
 static int launch_gemv_q4k(const void *W, const float *bias, const int8_t *xqs, const float *xd, const int16_t *xbsums, void *y, int y_f16,
-                           const float *residual, int N, int K, hipStream_t st) {
+                           const float *residual, int N, int K, hipStream_t st, int M = 1, int64_t ldy = 0) {
     const int nb = K / 256;
     const int nsteps = (nb + 7) / 8;
     // Little's law: ~6.3 TB/s x ~2 us of HBM latency = ~50 KB in flight per CU.  Every wave issues all the loads of its
@@ -869,7 +877,7 @@ static int launch_gemv_q4k(const void *W, const float *bias, const int8_t *xqs, 
         rows_per_wave = ((rows_per_wave + RW - 1) / RW) * RW;                                                                   \
         const int waves = (N + rows_per_wave - 1) / rows_per_wave;                                                              \
         hipLaunchKernelGGL((gemv_q4k_kernel<NS, RW>), dim3((waves + 3) / 4), dim3(256), 0, st, (const uint8_t *)W, bias, xqs, xd, \
-                           xbsums, y, y_f16, residual, N, nb, rows_per_wave);                                                   \
+                           xbsums, y, y_f16, residual, N, nb, rows_per_wave, M, ldy);                                           \
     } break;
     switch (nsteps) {
         GEMV_CASE(1, 4)
@@ -954,14 +962,8 @@ extern "C" int mllm_hip_linear_q4k_q8k(const void *W, const float *bias, const i
     const int y_f16 = y_dtype == MLLM_HIP_F16;
     hipStream_t st = as_stream(stream);
     if (M < 16) {
-        const int nb = K / 256;
-        for (int m = 0; m < M; ++m) {
-            void *ym = y_f16 ? (void *)((uint16_t *)y + (int64_t)m * ldy) : (void *)((float *)y + (int64_t)m * ldy);
-            int rc = launch_gemv_q4k(W, bias, xqs + (int64_t)m * K, xd + (int64_t)m * nb, xbsums + (int64_t)m * (K / 16), ym, y_f16,
-                                     residual ? residual + (int64_t)m * ldy : nullptr, N, K, st);
-            if (rc) return rc;
-        }
-        return MLLM_HIP_OK;
+        // one launch: every weight row is fetched once and meets all M activation rows in registers (gemv_q4k_kernel's m loop)
+        return launch_gemv_q4k(W, bias, xqs, xd, xbsums, y, y_f16, residual, N, K, st, M, ldy);
     }
     // raw Q4_K blocks with M >= 16: pack both sides into stream-ordered scratch, then the packed GEMM (callers that keep the
     // weights resident pre-pack once with mllm_hip_q4k_prepack and call mllm_hip_linear_q4kp_q8k)
@@ -994,11 +996,13 @@ extern "C" int mllm_hip_linear_q40_q80(const uint8_t *Wqs, const uint16_t *Wd, c
     int rows_per_wave = (N + target_waves - 1) / target_waves;
     rows_per_wave = ((rows_per_wave + rpp - 1) / rpp) * rpp;
     const int waves = (N + rows_per_wave - 1) / rows_per_wave;
-    for (int m = 0; m < M; ++m) {
-        const int8_t *xq = xqs + (int64_t)m * K;
-        const uint16_t *xdd = xd + (int64_t)m * (K / 32);
-        float *ym = y + (int64_t)m * ldy;
-#define Q40_CASE(B, L) if (bpl == B && lpr == L) hipLaunchKernelGGL((gemv_q40_kernel<B, L>), dim3((waves + 3) / 4), dim3(256), lds, st, Wqs, Wd, bias, xq, xdd, ym, N, rows_per_wave);
+    // one launch per 15 activation rows: the table rows are fetched once per launch and meet every activation row in registers (gemv_q40_kernel's m loop)
+    for (int m0 = 0; m0 < M; m0 += 15) {
+        const int mc = M - m0 < 15 ? M - m0 : 15;
+        const int8_t *xq = xqs + (int64_t)m0 * K;
+        const uint16_t *xdd = xd + (int64_t)m0 * (K / 32);
+        float *ym = y + (int64_t)m0 * ldy;
+#define Q40_CASE(B, L) if (bpl == B && lpr == L) hipLaunchKernelGGL((gemv_q40_kernel<B, L>), dim3((waves + 3) / 4), dim3(256), lds, st, Wqs, Wd, bias, xq, xdd, ym, N, rows_per_wave, mc, ldy);
         Q40_CASE(1, 16) Q40_CASE(2, 16) Q40_CASE(3, 16) Q40_CASE(4, 16) Q40_CASE(5, 16) Q40_CASE(6, 16) Q40_CASE(7, 16) Q40_CASE(8, 16)
         Q40_CASE(1, 8) Q40_CASE(3, 8) Q40_CASE(5, 8) Q40_CASE(7, 8)
 #undef Q40_CASE

@@ -224,6 +224,24 @@ class Model:
     def clear_kvcache(self):
         check(load().mllm_hip_model_clear_kvcache(self._h))
 
+    def batch_begin(self, B: int):
+        """B independent sequences (own KV slabs) on this model; sequence 0 is the model's own cache."""
+        check(load().mllm_hip_model_batch_begin(self._h, C.c_int(B)), "batch_begin")
+
+    def batch_select(self, seq: int):
+        """Make `seq` the sequence prefill / decode / generate / clear_kvcache / cache_len act on."""
+        check(load().mllm_hip_model_batch_select(self._h, C.c_int(seq)), "batch_select")
+
+    def batch_decode(self, tokens, want_logits=True):
+        """One step for sequences 0 .. len(tokens) - 1 together: (next greedy ids [B], logits [B][vocab] or None, device ms)."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        B = int(t.size)
+        nxt = np.empty(B, dtype=np.int32)
+        lg = np.empty((B, self.vocab), dtype=np.float32) if want_logits else None
+        ms = C.c_float()
+        check(load().mllm_hip_model_batch_decode(self._h, C.c_int(B), vp(t), vp(lg), vp(nxt), C.byref(ms)), "batch_decode")
+        return nxt, lg, ms.value
+
     def cache_len(self) -> int:
         """Tokens the KV cache holds (0 on a fresh or cleared model)."""
         return int(load().mllm_hip_model_cache_len(self._h))
