@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +30,64 @@ HIPBackend::HIPBackend(int device) {
     registerOps();
     registerFuncs();
     dump_dir_ = getenv("MLLM_HIP_DUMP_DIR");
+    inline_launch_ = getenv("MLLM_HIP_INLINE_LAUNCH") != nullptr;
+    ring_.resize(kRing);
+    worker_ = std::thread([this] { worker_loop(); });
+}
+
+// ---- deferred launches (see HIPBackend.hpp) ---------------------------------------------------------------------------------------------------------------------
+void HIPBackend::worker_loop() {
+    int idle = 0;
+    for (;;) {
+        const size_t t = tail_.load(std::memory_order_relaxed);
+        if (t == head_.load(std::memory_order_acquire)) {
+            if (stop_.load(std::memory_order_acquire)) return;
+            // inside a forward the next call is a microsecond away: spin.  After about half a millisecond without work (between generations, at the prompt) fall back to
+            // polling every 100 us -- the producer never signals, so publishing a call costs it one plain store
+            if (++idle < 12000) { __builtin_ia32_pause(); continue; }
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+            continue;
+        }
+        idle = 0;
+        Deferred &d = ring_[t % kRing];
+        if (!failed_.load(std::memory_order_relaxed)) {      // after a failure the rest of the queue is dropped: the caller's next drain() throws
+            int rc = MLLM_HIP_OK;
+            std::string msg;
+            try { rc = d.thunk ? d.thunk(d) : d.call(); } catch (const std::exception &e) { rc = -1; msg = e.what(); }
+            if (rc != MLLM_HIP_OK) {
+                failure_ = std::string("mllm_hip: ") + d.what + " failed (" + std::to_string(rc) + "): " + (msg.empty() ? mllm_hip_last_error() : msg.c_str());
+                failed_.store(true, std::memory_order_release);
+            }
+        }
+        if (!d.thunk) d.call = nullptr;
+        tail_.store(t + 1, std::memory_order_release);
+    }
+}
+HIPBackend::Deferred &HIPBackend::claim_slot() {
+    const size_t h = head_.load(std::memory_order_relaxed);
+    if (h - tail_seen_ >= kRing)      // ring full by the cached view: look at the worker's real position (it is behind by 4096 calls only if something is stuck)
+        while (h - (tail_seen_ = tail_.load(std::memory_order_acquire)) >= kRing) __builtin_ia32_pause();
+    return ring_[h % kRing];
+}
+void HIPBackend::publish_slot() {
+    head_.store(head_.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+}
+void HIPBackend::enqueue(std::function<int()> call, const char *what) {
+    if (inline_launch_) { check(call(), what); return; }
+    Deferred &d = claim_slot();
+    d.thunk = nullptr;
+    d.call = std::move(call);
+    d.what = what;
+    publish_slot();
+}
+void HIPBackend::drain() {
+    const size_t h = head_.load(std::memory_order_relaxed);
+    while (tail_.load(std::memory_order_acquire) != h) __builtin_ia32_pause();
+    if (failed_.load(std::memory_order_acquire)) {
+        const std::string msg = failure_;
+        failed_.store(false, std::memory_order_release);
+        throw std::runtime_error(msg);
+    }
 }
 
 // ---- reference-counted blocks ---------------------------------------------------------------------------------------------------------------------------------
@@ -54,17 +113,23 @@ void HIPBackend::release(const void *p) {
     if (mrope_key_.pos && inside(mrope_key_.pos)) mrope_key_ = MropeKey();
     if (it->second.pooled) {
         if (idle_bytes_ + it->second.size <= kIdleLimit) { idle_[it->second.size].push_back((void *)lo); idle_bytes_ += it->second.size; }
-        else check(mllm_hip_pool_free((void *)lo, stream_), "mllm_hip_pool_free");
-    } else check(mllm_hip_free((void *)lo), "mllm_hip_free");
+        else defer("mllm_hip_pool_free", mllm_hip_pool_free, (void *)lo, stream_);      // stream-ordered behind the launches that still use the block
+    } else { drain(); check(mllm_hip_free((void *)lo), "mllm_hip_free"); }
     blocks_.erase(it);
 }
 void HIPBackend::drain_idle() {
+    try { drain(); } catch (...) {}
     for (auto &kv : idle_)
         for (void *p : kv.second) (void)mllm_hip_pool_free(p, stream_);
     idle_.clear();
     idle_bytes_ = 0;
 }
-HIPBackend::~HIPBackend() { drain_idle(); }
+HIPBackend::~HIPBackend() {
+    try { drain(); } catch (...) {}
+    stop_.store(true, std::memory_order_release);
+    if (worker_.joinable()) worker_.join();
+    drain_idle();
+}
 void HIPBackend::alloc_device(DeviceMemory &mem, DataType) {
     mem.type = MEM_TYPE_GENERIC;
     mem.handle = nullptr;
@@ -103,7 +168,17 @@ void HIPBackend::view_of(const std::shared_ptr<Tensor> &view, void *handle, size
     m.size_in_bytes = bytes;
 }
 
-void HIPBackend::upload(void *dst, const void *src, size_t bytes) { check(mllm_hip_upload(dst, src, bytes, stream_), "mllm_hip_upload"); }
+void HIPBackend::upload(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return;
+    if (bytes <= (256u << 10)) {      // ids, positions, rotary rows, index tensors: the bytes travel with the deferred call, in order with the launches around them
+        auto buf = std::make_shared<std::vector<char>>((const char *)src, (const char *)src + bytes);
+        void *st = stream_;
+        enqueue([dst, buf, bytes, st]() -> int { return mllm_hip_upload(dst, buf->data(), bytes, st); }, "mllm_hip_upload");
+        return;
+    }
+    drain();      // weights at load time, images: straight from the caller's buffer
+    check(mllm_hip_upload(dst, src, bytes, stream_), "mllm_hip_upload");
+}
 void HIPBackend::copy_from_host(const DeviceMemory &dest, const void *src) {
     if (!dest.handle || !src || dest.size_in_bytes == 0) return;
     upload(dest.handle, src, dest.size_in_bytes);
@@ -112,17 +187,18 @@ void HIPBackend::copy_from_host(const DeviceMemory &dest, const void *src) {
 }
 void HIPBackend::copy_to_host(void *dest, const DeviceMemory &src) {
     if (!dest || !src.handle || src.size_in_bytes == 0) return;
+    drain();
     check(mllm_hip_d2h(dest, src.handle, src.size_in_bytes, stream_), "mllm_hip_d2h");      // synchronises
 }
 void HIPBackend::convert_fp_data(Tensor *, Tensor *) {
     // the HIP path keeps activations fp32 (the reference CPU backend's arithmetic type): nothing to convert
 }
-void HIPBackend::sync() { check(mllm_hip_sync(stream_), "mllm_hip_sync"); }
+void HIPBackend::sync() { drain(); check(mllm_hip_sync(stream_), "mllm_hip_sync"); }
 
 void *HIPBackend::scratch(int slot, size_t bytes) {
     if (bytes > scratch_bytes_[slot]) {
         // in-order stream: the old block is freed behind the work that still reads it
-        if (scratch_[slot]) check(mllm_hip_pool_free(scratch_[slot], stream_), "mllm_hip_pool_free");
+        if (scratch_[slot]) defer("mllm_hip_pool_free", mllm_hip_pool_free, scratch_[slot], stream_);
         bytes += bytes / 4;
         check(mllm_hip_pool_alloc(&scratch_[slot], bytes, stream_), "mllm_hip_pool_alloc");
         scratch_bytes_[slot] = bytes;
@@ -148,6 +224,7 @@ const std::vector<float> &HIPBackend::host_floats(const std::shared_ptr<Tensor> 
     if (it != shadows_.end() && it->second.size() >= (size_t)t->count()) return it->second;
     if (t->dtype() != MLLM_TYPE_F32) throw std::runtime_error("HIPBackend::host_floats: fp32 tensors only: " + t->name());
     std::vector<float> v((size_t)t->count());
+    drain();
     if (!v.empty()) check(mllm_hip_d2h(v.data(), h, v.size() * 4, stream_), "mllm_hip_d2h");
     return shadows_[h] = std::move(v);
 }
@@ -167,6 +244,7 @@ std::shared_ptr<HIPQ40Table> HIPBackend::q40_table(AbstructLoader &loader, const
     const int64_t nblk = (int64_t)rows * (cols / 32);
     t->qs = dev_alloc((size_t)nblk * 16);
     t->d = dev_alloc((size_t)nblk * 2);
+    drain();
     check(mllm_hip_repack_q40(t->raw.device_memory().handle, (uint8_t *)t->qs, (uint16_t *)t->d, nblk, stream_), "mllm_hip_repack_q40");
     q40_by_name_[name] = t;
     q40_by_handle_[t->raw.device_memory().handle] = t;
@@ -187,7 +265,7 @@ HIPBackend::RopeTables HIPBackend::mrope_tables(const std::shared_ptr<Tensor> &p
     check(mllm_hip_mrope_table(theta, D, pos.data(), S, section.data(), (int)section.size(), s.data(), c.data()), "mllm_hip_mrope_table");
     const size_t bytes = (size_t)2 * S * half * 4;
     if (bytes > mrope_bytes_) {
-        if (mrope_dev_) check(mllm_hip_pool_free(mrope_dev_, stream_), "mllm_hip_pool_free");
+        if (mrope_dev_) defer("mllm_hip_pool_free", mllm_hip_pool_free, mrope_dev_, stream_);
         mrope_bytes_ = bytes * 2;
         check(mllm_hip_pool_alloc(&mrope_dev_, mrope_bytes_, stream_), "mllm_hip_pool_alloc");
     }
@@ -245,7 +323,16 @@ Op *HIPBackend::opCreate(const OpParam &op_param, std::string name, int) {
 TensorFunction *HIPBackend::funcCreate(TensorFuncType) { throw std::runtime_error("HIPBackend: the legacy TensorFunction path is not used (OpenCLBackend throws too)"); }
 std::vector<Tensor> HIPBackend::runLayer(Layer *, std::vector<Tensor>, int) { throw std::runtime_error("runLayer is the QNN path"); }
 
+#ifdef HIP_ADAPTER_TIMING
+#include <x86intrin.h>
+static unsigned long long g_t_runop = 0, g_t_ops = 0, g_t_wrap = 0, g_n = 0;
+struct TimingDump { ~TimingDump() { fprintf(stderr, "[adapter timing] runOp calls %llu: total %.1f Mcyc, reshape+setUp+execute %.1f Mcyc, shell construction %.1f Mcyc\n", g_n, g_t_runop / 1e6, g_t_ops / 1e6, g_t_wrap / 1e6); } } g_timing_dump;
+#define TSC() __rdtsc()
+#else
+#define TSC() 0ull
+#endif
 std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::vector<std::string> out_names, bool in_place) {
+    const unsigned long long t_in = TSC();
     Module *module = inputs.empty() ? Module::llm_model_ptr : inputs[0].module();
     // fact 2: host-side scalar inputs go back to the CPU backend before anything reads them (the caller's Tensor shares the impl, so the model's own
     // `dataAt` on it works again); done in the trace passes too, where the model code runs on the dummy inputs
@@ -293,9 +380,11 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
             out_tensors.push_back(input_tensors[i]);
         }
     }
+    const unsigned long long t_a = TSC();
     op->reshape(input_tensors, out_tensors);
     op->setUp(input_tensors, out_tensors);
     op->execute(input_tensors, out_tensors);
+    const unsigned long long t_b = TSC();
     ++ops_run_;
     if (dump_dir_) dump_outputs(op, out_tensors);
     // a shadow describes what the host uploaded; an Op that wrote the block on the device (in place, or into a recycled pool block) has made it stale
@@ -304,6 +393,10 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
             for (const auto &out_tensor : out_tensors) shadows_.erase(out_tensor->device_memory().handle);
     vector<Tensor> results;
     for (const auto &out_tensor : out_tensors) results.push_back(*out_tensor);
+#ifdef HIP_ADAPTER_TIMING
+    g_t_ops += t_b - t_a; g_t_wrap += t_a - t_in; g_t_runop += TSC() - t_in; ++g_n;
+#endif
+    (void)t_in; (void)t_a; (void)t_b;
     return results;
 }
 
@@ -315,6 +408,7 @@ void HIPBackend::dump_outputs(Op *op, const std::vector<std::shared_ptr<Tensor>>
         if (!t->device_memory().handle || t->count() == 0 || (t->dtype() != MLLM_TYPE_F32 && t->dtype() != MLLM_TYPE_F16)) continue;
         const size_t bytes = (size_t)t->count() * (t->dtype() == MLLM_TYPE_F16 ? 2 : 4);
         std::vector<char> host(bytes);
+        drain();
         check(mllm_hip_d2h(host.data(), t->device_memory().handle, bytes, stream_), "mllm_hip_d2h");
         std::string nm = t->name();
         for (auto &ch : nm) if (ch == '/' || ch == ' ') ch = '_';

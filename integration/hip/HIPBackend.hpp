@@ -23,7 +23,11 @@
 #define MLLM_HIP_BACKEND_HPP
 
 #include <any>
+#include <atomic>
 #include <functional>
+#include <thread>
+#include <tuple>
+#include <type_traits>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -96,6 +100,29 @@ public:
     void *stream() const { return stream_; }        // one in-order stream; synchronised only at the end of the outermost forward and in copy_to_host
     void sync();
 
+    // ---- deferred launches ----
+    // The frontend walks the model Op by Op on the caller's thread; what an Op's execute() costs there is dominated by the HIP launch itself (about 2.5 us of host time per
+    // kernel, 480 kernels per decode step of the 2 B model -- more than the frontend's own work for the step).  So execute() does not launch: it hands the C-ABI call, with
+    // its arguments already evaluated, to ONE worker thread that issues the calls in program order on the backend's stream, while the caller's thread is already inside the
+    // next Op.  Everything that must see the device in order goes through the same queue (stream-ordered frees, small uploads); everything that reads results on the host
+    // (copy_to_host, host_floats' D2H, sync) drains it first.  A failing call is remembered on the worker (with mllm_hip_last_error's text, which is thread-local there)
+    // and thrown from the next drain().
+    template <typename Fn, typename... A>
+    void defer(const char *what, Fn fn, A... args) {
+        // the call travels as plain bytes inside its ring slot (function pointer + the argument tuple): no allocation on this thread, nothing to free on the worker's
+        if (inline_launch_) { check(fn(args...), what); return; }      // MLLM_HIP_INLINE_LAUNCH=1: the caller's thread launches (A/B measurements, debugging)
+        using Tup = std::tuple<A...>;
+        static_assert(sizeof(Tup) <= sizeof(Deferred::args) && std::is_trivially_destructible<Tup>::value, "deferred C-ABI calls carry pointers and integers only");
+        Deferred &d = claim_slot();
+        new (d.args) Tup(args...);
+        d.fn = reinterpret_cast<void (*)()>(fn);
+        d.thunk = [](Deferred &x) -> int { return std::apply(reinterpret_cast<Fn>(x.fn), *reinterpret_cast<Tup *>(x.args)); };
+        d.what = what;
+        publish_slot();
+    }
+    void enqueue(std::function<int()> call, const char *what);      // the rare calls that own memory (small uploads carry their bytes)
+    void drain();
+
     // ---- reference-counted device blocks (fact 1) ----
     void *dev_alloc(size_t bytes);                   // Op-owned memory (weights' repacks, KV slabs, tables): one reference, dropped by dev_release
     void dev_release(void *p);
@@ -158,6 +185,26 @@ private:
     RopeTables mrope_;
     std::unordered_map<const void *, RopeTables> vision_;
     std::unordered_map<std::string, std::pair<void *, size_t>> maps_;      // .mllm path -> read-only mmap (load_from_file)
+    // single-producer / single-consumer ring of deferred calls
+    struct Deferred {
+        int (*thunk)(Deferred &) = nullptr;      // unpacks args and calls fn; nullptr: `call` below is the call
+        void (*fn)() = nullptr;
+        const char *what = "";
+        alignas(16) unsigned char args[176];
+        std::function<int()> call;
+    };
+    Deferred &claim_slot();
+    void publish_slot();
+    static constexpr size_t kRing = 4096;
+    std::vector<Deferred> ring_;
+    alignas(64) std::atomic<size_t> head_{0};      // the producer (the frontend's thread) writes at head_ ...
+    alignas(64) std::atomic<size_t> tail_{0};      // ... the worker consumes at tail_ (own cache lines: the two threads do not bounce one line)
+    alignas(64) size_t tail_seen_ = 0;             // producer's cached view of tail_
+    std::atomic<bool> stop_{false}, failed_{false};
+    bool inline_launch_ = false;
+    std::thread worker_;
+    std::string failure_;
+    void worker_loop();
     long forward_serial_ = 0, ops_run_ = 0;
     const char *dump_dir_ = nullptr;      // MLLM_HIP_DUMP_DIR: bring-up dumps of every Op's outputs (HIPBackend.cpp: dump_outputs)
     void dump_outputs(Op *op, const std::vector<std::shared_ptr<Tensor>> &outs);

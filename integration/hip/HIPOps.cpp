@@ -22,7 +22,9 @@ inline float getf(const OpParam &p, const char *k, float def = 0.f) { auto it = 
 inline int rows_of(const shared_ptr<Tensor> &t) { return t->batch() * t->sequence() * t->head(); }       // BSHD: rows of `dimension()` values
 inline size_t elem_bytes(DataType dt) { return dt == MLLM_TYPE_F16 ? 2 : 4; }
 inline void need(bool ok, const char *what) { if (!ok) throw std::runtime_error(std::string("mllm_hip adapter: ") + what); }
-#define HIPCHK(call) HIPBackend::check((call), #call)
+#define HIPCHK(call) HIPBackend::check((call), #call)      // direct call (load time: the caller drains the deferred queue first)
+// an execute()-time launch: the arguments are evaluated HERE (device pointers, extents), the call itself is issued by the backend's worker thread in program order
+#define HIPQ(fn, ...) hb()->defer(#fn, fn, __VA_ARGS__)
 
 // loads `<op>.weight` / `<op>.bias` onto the device in the file's storage dtype (ParamLoader::load -> Backend::load_from_file fast path)
 void load_tensor(Tensor &t, Backend *bn, AbstructLoader &loader, const string &name, int rows, int cols) {
@@ -57,11 +59,13 @@ public:
         if (dt != MLLM_TYPE_Q4_K && dt != MLLM_TYPE_Q4_0 && dt != MLLM_TYPE_F32) throw std::runtime_error("HIPLinearOp: weight dtype not on the hot path: " + name());      // precedent OpenCLLinearOp.cpp:26-52
         if (dt == MLLM_TYPE_Q4_K) {      // resident Linears are packed once for the M >= 16 GEMM (mllm_hip_q4k_prepack)
             packed_ = hb()->dev_alloc(mllm_hip_q4k_wpack_bytes(out_, in_));
+            hb()->drain();
             HIPCHK(mllm_hip_q4k_prepack(weight_.device_memory().handle, out_, in_, packed_, hb()->stream()));
         } else if (dt == MLLM_TYPE_Q4_0) {  // 18-byte blocks -> nibble plane + fp16 scale plane (mllm_hip_repack_q40)
             const int64_t nblk = (int64_t)out_ * (in_ / 32);
             q40_qs_ = hb()->dev_alloc((size_t)nblk * 16);
             q40_d_ = hb()->dev_alloc((size_t)nblk * 2);
+            hb()->drain();
             HIPCHK(mllm_hip_repack_q40(weight_.device_memory().handle, (uint8_t *)q40_qs_, (uint16_t *)q40_d_, nblk, hb()->stream()));
         }
         if (has_bias_) load_tensor(bias_, backend_, loader, name() + ".bias", 1, out_);
@@ -79,11 +83,11 @@ public:
             // activations to Q8_K (quantize_row_q8_K_reference), then vec_dot_q4_K_q8_K per (row, output): GEMV below 16 rows, packed GEMM from 16 on
             if (M < 16) {
                 uint8_t *ws = (uint8_t *)b->scratch(0, mllm_hip_linear_workspace_bytes(MLLM_HIP_Q4_K, M, in_));
-                HIPCHK(mllm_hip_linear(weight_.device_memory().handle, MLLM_HIP_Q4_K, bias, x, y, MLLM_HIP_F32, out_, M, out_, in_, ws, b->stream()));
+                HIPQ(mllm_hip_linear, weight_.device_memory().handle, MLLM_HIP_Q4_K, bias, x, y, MLLM_HIP_F32, out_, M, out_, in_, ws, b->stream());
             } else {
                 void *xpack = b->scratch(1, mllm_hip_q4k_prepack_bytes(M, in_));
-                HIPCHK(mllm_hip_quantize_q8k_packed(x, xpack, M, in_, b->stream()));
-                HIPCHK(mllm_hip_linear_q4kp_packed(packed_, bias, xpack, y, MLLM_HIP_F32, out_, nullptr, M, out_, in_, b->stream()));
+                HIPQ(mllm_hip_quantize_q8k_packed, x, xpack, M, in_, b->stream());
+                HIPQ(mllm_hip_linear_q4kp_packed, packed_, bias, xpack, y, MLLM_HIP_F32, out_, nullptr, M, out_, in_, b->stream());
             }
             break;
         }
@@ -91,12 +95,12 @@ public:
             uint8_t *ws = (uint8_t *)b->scratch(0, mllm_hip_linear_workspace_bytes(MLLM_HIP_Q4_0, M, in_));
             int8_t *qs = (int8_t *)ws;
             uint16_t *d = (uint16_t *)(ws + (((size_t)M * in_ + 255) & ~(size_t)255));
-            HIPCHK(mllm_hip_quantize_q80(x, qs, d, M, in_, b->stream()));
-            HIPCHK(mllm_hip_linear_q40_q80((const uint8_t *)q40_qs_, (const uint16_t *)q40_d_, bias, qs, d, (float *)y, out_, M, out_, in_, b->stream()));
+            HIPQ(mllm_hip_quantize_q80, x, qs, d, M, in_, b->stream());
+            HIPQ(mllm_hip_linear_q40_q80, (const uint8_t *)q40_qs_, (const uint16_t *)q40_d_, bias, qs, d, (float *)y, out_, M, out_, in_, b->stream());
             break;
         }
         default:
-            HIPCHK(mllm_hip_linear_f32((const float *)weight_.device_memory().handle, bias, x, (float *)y, out_, M, out_, in_, b->stream()));
+            HIPQ(mllm_hip_linear_f32, (const float *)weight_.device_memory().handle, bias, x, (float *)y, out_, M, out_, in_, b->stream());
         }
         return MLLM_NO_ERROR;
     }
@@ -133,8 +137,8 @@ public:
     ErrorCode execute(TensorList inputs, TensorList outputs) override {
         const int S = inputs[0]->batch() * inputs[0]->sequence();
         if (S == 0) return MLLM_NO_ERROR;
-        if (table_) HIPCHK(mllm_hip_embedding_q40((const float *)dptr(inputs[0]), (const uint8_t *)table_->qs, (const uint16_t *)table_->d, (float *)dptr(outputs[0]), S, hidden_, vocab_, hb()->stream()));
-        else HIPCHK(mllm_hip_gather_rows((const float *)f32_.device_memory().handle, hidden_, vocab_, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), hidden_, S, hidden_, 0, hb()->stream()));      // CPUEmbedding.cpp:46-60: a row copy
+        if (table_) HIPQ(mllm_hip_embedding_q40, (const float *)dptr(inputs[0]), (const uint8_t *)table_->qs, (const uint16_t *)table_->d, (float *)dptr(outputs[0]), S, hidden_, vocab_, hb()->stream());
+        else HIPQ(mllm_hip_gather_rows, (const float *)f32_.device_memory().handle, hidden_, vocab_, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), hidden_, S, hidden_, 0, hb()->stream());      // CPUEmbedding.cpp:46-60: a row copy
         return MLLM_NO_ERROR;
     }
     ErrorCode free(TensorList, TensorList) override { if (!table_) f32_.free(); return MLLM_NO_ERROR; }
@@ -200,9 +204,9 @@ public:
         const int M = rows_of(inputs[0]);
         if (M == 0) return MLLM_NO_ERROR;
         const float *w = (const float *)weight_.device_memory().handle;
-        if (layer_) HIPCHK(mllm_hip_layernorm((const float *)dptr(inputs[0]), w, has_bias_ ? (const float *)bias_.device_memory().handle : nullptr, (float *)dptr(outputs[0]), nullptr,
-                                              nullptr, nullptr, M, dim_, eps_, hb()->stream()));
-        else HIPCHK(mllm_hip_rmsnorm((const float *)dptr(inputs[0]), w, (float *)dptr(outputs[0]), nullptr, nullptr, nullptr, M, dim_, eps_, unit_offset_ ? 1 : 0, hb()->stream()));
+        if (layer_) HIPQ(mllm_hip_layernorm, (const float *)dptr(inputs[0]), w, has_bias_ ? (const float *)bias_.device_memory().handle : nullptr, (float *)dptr(outputs[0]), nullptr,
+                                              nullptr, nullptr, M, dim_, eps_, hb()->stream());
+        else HIPQ(mllm_hip_rmsnorm, (const float *)dptr(inputs[0]), w, (float *)dptr(outputs[0]), nullptr, nullptr, nullptr, M, dim_, eps_, unit_offset_ ? 1 : 0, hb()->stream());
         return MLLM_NO_ERROR;
     }
 
@@ -253,7 +257,7 @@ public:
             dc = tab_ + (size_t)max_pos_ * D + (size_t)h_cnt_ * D;
             ld_tab = D;
         }
-        HIPCHK(mllm_hip_rope_apply((const float *)dptr(inputs[0]), (int64_t)H * D, ds, dc, ld_tab, dptr(outputs[0]), MLLM_HIP_F32, (int64_t)H * D, S, H, D, b->stream()));
+        HIPQ(mllm_hip_rope_apply, (const float *)dptr(inputs[0]), (int64_t)H * D, ds, dc, ld_tab, dptr(outputs[0]), MLLM_HIP_F32, (int64_t)H * D, S, H, D, b->stream());
         if (!multimodal_) h_cnt_ += S;
         return MLLM_NO_ERROR;
     }
@@ -329,7 +333,7 @@ public:
             b->upload(dc, c.data(), c.size() * 4);
             t = HIPBackend::RopeTables{ds, dc, S, half};
         }
-        HIPCHK(mllm_hip_rope_apply((const float *)dptr(inputs[0]), (int64_t)H * D, t.sin, t.cos, half, dptr(outputs[0]), MLLM_HIP_F32, (int64_t)H * D, S, H, D, b->stream()));
+        HIPQ(mllm_hip_rope_apply, (const float *)dptr(inputs[0]), (int64_t)H * D, t.sin, t.cos, half, dptr(outputs[0]), MLLM_HIP_F32, (int64_t)H * D, S, H, D, b->stream());
         return MLLM_NO_ERROR;
     }
 };
@@ -365,7 +369,7 @@ public:
     }
     ErrorCode execute(TensorList inputs, TensorList) override {
         const int S = inputs[0]->sequence(), n = (int)row_;
-        if (S) HIPCHK(mllm_hip_store_f16((const float *)dptr(inputs[0]), n, (uint16_t *)slab_ + (size_t)cache_seq_len_ * n, n, S, n, hb()->stream()));
+        if (S) HIPQ(mllm_hip_store_f16, (const float *)dptr(inputs[0]), n, (uint16_t *)slab_ + (size_t)cache_seq_len_ * n, n, S, n, hb()->stream());
         cache_seq_len_ += S;
         return MLLM_NO_ERROR;
     }
@@ -395,8 +399,8 @@ public:
         const int Hq = q->head(), Hkv = k->head(), D = q->dimension();
         if (q->sequence() == 0) return MLLM_NO_ERROR;
         const int kvdt = k->dtype() == MLLM_TYPE_F16 ? MLLM_HIP_F16 : MLLM_HIP_F32;
-        HIPCHK(mllm_hip_fa2((const float *)dptr(q), (int64_t)Hq * D, dptr(k), (int64_t)Hkv * D, dptr(v), (int64_t)Hkv * D, kvdt, (float *)dptr(outputs[0]), (int64_t)Hq * D, q->sequence(),
-                            k->sequence(), Hq, Hkv, D, causal_ ? 1 : 0, nullptr, nullptr, hb()->stream()));
+        HIPQ(mllm_hip_fa2, (const float *)dptr(q), (int64_t)Hq * D, dptr(k), (int64_t)Hkv * D, dptr(v), (int64_t)Hkv * D, kvdt, (float *)dptr(outputs[0]), (int64_t)Hq * D, q->sequence(),
+                            k->sequence(), Hq, Hkv, D, causal_ ? 1 : 0, nullptr, nullptr, hb()->stream());
         return MLLM_NO_ERROR;
     }
 
@@ -418,8 +422,8 @@ public:
         auto *b = hb();
         const int64_t n = inputs[0]->count();
         if (n == 0) return MLLM_NO_ERROR;
-        if (kind_ == SILU_K) HIPCHK(mllm_hip_silu((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), n, b->stream()));
-        else HIPCHK(mllm_hip_act_lut((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), n, kind_ == GELU_K ? b->gelu_lut() : b->quickgelu_lut(), b->stream()));
+        if (kind_ == SILU_K) HIPQ(mllm_hip_silu, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), n, b->stream());
+        else HIPQ(mllm_hip_act_lut, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), n, kind_ == GELU_K ? b->gelu_lut() : b->quickgelu_lut(), b->stream());
         return MLLM_NO_ERROR;
     }
 
@@ -437,7 +441,7 @@ public:
     ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode execute(TensorList inputs, TensorList outputs) override {
         auto fn = mul_ ? mllm_hip_mul : mllm_hip_add;
-        if (inputs[0]->count()) HIPCHK(fn((const float *)dptr(inputs[0]), (const float *)dptr(inputs[1]), (float *)dptr(outputs[0]), (int64_t)inputs[0]->count(), hb()->stream()));
+        if (inputs[0]->count()) HIPQ(fn, (const float *)dptr(inputs[0]), (const float *)dptr(inputs[1]), (float *)dptr(outputs[0]), (int64_t)inputs[0]->count(), hb()->stream());
         return MLLM_NO_ERROR;
     }
 
@@ -457,8 +461,8 @@ public:
     }
     ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode execute(TensorList inputs, TensorList outputs) override {
-        HIPCHK(mllm_hip_sliding_window_mask((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), inputs[0]->sequence(), inputs[0]->head(), inputs[0]->dimension(), window_,
-                                            hb()->stream()));
+        HIPQ(mllm_hip_sliding_window_mask, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), inputs[0]->sequence(), inputs[0]->head(), inputs[0]->dimension(), window_,
+                                            hb()->stream());
         return MLLM_NO_ERROR;
     }
 
@@ -482,7 +486,7 @@ public:
     ErrorCode execute(TensorList inputs, TensorList outputs) override {
         const int rows = head_ ? inputs[0]->sequence() : inputs[0]->batch() * inputs[0]->head() * inputs[0]->sequence();
         const int n = head_ ? inputs[0]->head() : inputs[0]->dimension();
-        HIPCHK(mllm_hip_topk_rows((const float *)dptr(inputs[0]), n, (float *)dptr(outputs[0]), (float *)dptr(outputs[1]), rows, n, k_, hb()->stream()));
+        HIPQ(mllm_hip_topk_rows, (const float *)dptr(inputs[0]), n, (float *)dptr(outputs[0]), (float *)dptr(outputs[1]), rows, n, k_, hb()->stream());
         return MLLM_NO_ERROR;
     }
 
@@ -499,7 +503,7 @@ public:
     ErrorCode execute(TensorList inputs, TensorList) override {
         if (inputs[1]->batch() == 0) return MLLM_NO_ERROR;
         const int D = inputs[0]->dimension();
-        HIPCHK(mllm_hip_scatter_add_rows((float *)dptr(inputs[0]), D, inputs[0]->sequence(), (const float *)dptr(inputs[1]), D, (const float *)dptr(inputs[2]), inputs[2]->dimension(), D, hb()->stream()));
+        HIPQ(mllm_hip_scatter_add_rows, (float *)dptr(inputs[0]), D, inputs[0]->sequence(), (const float *)dptr(inputs[1]), D, (const float *)dptr(inputs[2]), inputs[2]->dimension(), D, hb()->stream());
         return MLLM_NO_ERROR;
     }
 };
@@ -529,7 +533,7 @@ public:
             b->upload(dv, v.data(), v.size() * 4);
             valid = dv;
         }
-        HIPCHK(mllm_hip_softmax((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), rows, n, valid, b->stream()));
+        HIPQ(mllm_hip_softmax, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), rows, n, valid, b->stream());
         return MLLM_NO_ERROR;
     }
 
@@ -566,14 +570,14 @@ public:
         const float *w = (const float *)weight_.device_memory().handle, *bias = has_bias_ ? (const float *)bias_.device_memory().handle : nullptr;
         const int KK = in_ch_ * kt_ * kh_ * kw_;
         if (is3d_) {
-            if (inputs[0]->batch()) HIPCHK(mllm_hip_patch_gemm_f32((const float *)dptr(inputs[0]), w, bias, (float *)dptr(outputs[0]), inputs[0]->batch(), KK, out_ch_, b->stream()));
+            if (inputs[0]->batch()) HIPQ(mllm_hip_patch_gemm_f32, (const float *)dptr(inputs[0]), w, bias, (float *)dptr(outputs[0]), inputs[0]->batch(), KK, out_ch_, b->stream());
         } else {
             const int H = inputs[0]->head(), W = inputs[0]->dimension(), N = (H / kh_) * (W / kw_);
             float *patches = (float *)b->scratch(3, (size_t)N * KK * 4), *rows = (float *)b->scratch(2, (size_t)N * out_ch_ * 4);
-            HIPCHK(mllm_hip_im2patch_chw((const float *)dptr(inputs[0]), patches, H, in_ch_, W, kh_, b->stream()));      // the image Tensor [1, H, C, W] is BSHD: [C][H][W] in memory
+            HIPQ(mllm_hip_im2patch_chw, (const float *)dptr(inputs[0]), patches, H, in_ch_, W, kh_, b->stream());      // the image Tensor [1, H, C, W] is BSHD: [C][H][W] in memory
             // rows [oh*ow][OC] -> the reference's output [B, H/p, OC, W/p], which in BSHD memory order is [OC][oh][ow]
-            HIPCHK(mllm_hip_patch_gemm_f32(patches, w, bias, rows, N, KK, out_ch_, b->stream()));
-            HIPCHK(mllm_hip_transpose_f32(rows, (float *)dptr(outputs[0]), N, out_ch_, b->stream()));
+            HIPQ(mllm_hip_patch_gemm_f32, patches, w, bias, rows, N, KK, out_ch_, b->stream());
+            HIPQ(mllm_hip_transpose_f32, rows, (float *)dptr(outputs[0]), N, out_ch_, b->stream());
         }
         return MLLM_NO_ERROR;
     }
@@ -702,7 +706,7 @@ public:
     ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode execute(TensorList inputs, TensorList outputs) override {
         const int OC = inputs[0]->sequence(), N = inputs[0]->head() * inputs[0]->dimension();
-        if (OC && N) HIPCHK(mllm_hip_transpose_f32((const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), OC, N, hb()->stream()));
+        if (OC && N) HIPQ(mllm_hip_transpose_f32, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), OC, N, hb()->stream());
         return MLLM_NO_ERROR;
     }
 };
@@ -757,7 +761,7 @@ public:
         const int D = inputs[0]->dimension();
         float *dst = (float *)dptr(outputs[0]);
         for (auto &in : inputs) {
-            if (in->sequence()) HIPCHK(mllm_hip_copy_2d_f32((const float *)dptr(in), D, dst, D, in->sequence(), D, hb()->stream()));
+            if (in->sequence()) HIPQ(mllm_hip_copy_2d_f32, (const float *)dptr(in), D, dst, D, in->sequence(), D, hb()->stream());
             dst += (size_t)in->sequence() * D;
         }
         return MLLM_NO_ERROR;
@@ -784,7 +788,7 @@ public:
         const int rows = rows_of(inputs[0]), ld = inputs[0]->dimension();
         int off = 0;
         for (size_t i = 0; i < each_.size(); ++i) {
-            if (rows) HIPCHK(mllm_hip_copy_2d_f32((const float *)dptr(inputs[0]) + off, ld, (float *)dptr(outputs[i]), each_[i], rows, each_[i], hb()->stream()));
+            if (rows) HIPQ(mllm_hip_copy_2d_f32, (const float *)dptr(inputs[0]) + off, ld, (float *)dptr(outputs[i]), each_[i], rows, each_[i], hb()->stream());
             off += each_[i];
         }
         return MLLM_NO_ERROR;
@@ -821,10 +825,10 @@ public:
             uint8_t *ws = (uint8_t *)b->scratch(0, mllm_hip_linear_workspace_bytes(MLLM_HIP_Q4_0, M, K));
             int8_t *qs = (int8_t *)ws;
             uint16_t *d = (uint16_t *)(ws + (((size_t)M * K + 255) & ~(size_t)255));
-            HIPCHK(mllm_hip_quantize_q80((const float *)dptr(x), qs, d, M, K, b->stream()));
-            HIPCHK(mllm_hip_linear_q40_q80((const uint8_t *)t->qs, (const uint16_t *)t->d, nullptr, qs, d, (float *)dptr(outputs[0]), N, M, N, K, b->stream()));
+            HIPQ(mllm_hip_quantize_q80, (const float *)dptr(x), qs, d, M, K, b->stream());
+            HIPQ(mllm_hip_linear_q40_q80, (const uint8_t *)t->qs, (const uint16_t *)t->d, nullptr, qs, d, (float *)dptr(outputs[0]), N, M, N, K, b->stream());
         } else {
-            HIPCHK(mllm_hip_linear_f32((const float *)dptr(w), nullptr, (const float *)dptr(x), (float *)dptr(outputs[0]), N, M, N, K, b->stream()));
+            HIPQ(mllm_hip_linear_f32, (const float *)dptr(w), nullptr, (const float *)dptr(x), (float *)dptr(outputs[0]), N, M, N, K, b->stream());
         }
         return MLLM_NO_ERROR;
     }
@@ -882,8 +886,8 @@ public:
     ErrorCode setUp(TensorList, TensorList) override { return MLLM_NO_ERROR; }
     ErrorCode execute(TensorList inputs, TensorList) override {
         if (inputs.size() > 1 && inputs[1]->batch() == 0) return MLLM_NO_ERROR;
-        HIPCHK(mllm_hip_index_put_rows_fidx((float *)dptr(inputs[0]), inputs[0]->sequence(), (const float *)dptr(inputs[1]), (const float *)dptr(inputs[2]), inputs[2]->dimension(),
-                                            inputs[0]->dimension(), hb()->stream()));
+        HIPQ(mllm_hip_index_put_rows_fidx, (float *)dptr(inputs[0]), inputs[0]->sequence(), (const float *)dptr(inputs[1]), (const float *)dptr(inputs[2]), inputs[2]->dimension(),
+                                            inputs[0]->dimension(), hb()->stream());
         return MLLM_NO_ERROR;
     }
 };
@@ -910,9 +914,9 @@ public:
         const float *dst = (const float *)dptr(inputs[0]), *src = (const float *)dptr(inputs[1]);
         float *out = (float *)dptr(outputs[0]);
         void *st = hb()->stream();
-        if (at_) HIPCHK(mllm_hip_copy_2d_f32(dst, D, out, D, at_, D, st));
-        if (R) HIPCHK(mllm_hip_copy_2d_f32(src, D, out + (size_t)at_ * D, D, R, D, st));
-        if (S - at_ - 1 > 0) HIPCHK(mllm_hip_copy_2d_f32(dst + (size_t)(at_ + 1) * D, D, out + (size_t)(at_ + R) * D, D, S - at_ - 1, D, st));
+        if (at_) HIPQ(mllm_hip_copy_2d_f32, dst, D, out, D, at_, D, st);
+        if (R) HIPQ(mllm_hip_copy_2d_f32, src, D, out + (size_t)at_ * D, D, R, D, st);
+        if (S - at_ - 1 > 0) HIPQ(mllm_hip_copy_2d_f32, dst + (size_t)(at_ + 1) * D, D, out + (size_t)(at_ + R) * D, D, S - at_ - 1, D, st);
         return MLLM_NO_ERROR;
     }
 

@@ -3,7 +3,7 @@ import os, sys, json, subprocess, tempfile
 import numpy as np
 sys.path.insert(0, '.')
 from mllm_amd import synth
-from tests.fixtures import weights
+from mllm_amd import synthfile as weights
 from tests.test_gpu_adapter import _cfg_string, DRIVER
 cfg = synth.qwen2vl_2b(); path = weights.qwen2vl_file(cfg)
 g = np.load('tests/golden/qwen2vl_2b_ref.npz')

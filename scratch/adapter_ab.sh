@@ -1,6 +1,5 @@
 #!/bin/bash
-# kernel trace of the reference's 2B Module through the adapter (driver binary): GPU time per decode token against the wall time the driver reports
-set -e
+# the reference's 2B Module through the adapter: deferred launches (worker thread) against launches on the caller's thread, then the kernel trace of the deferred form
 R=$GRAFT_REPO_ROOT
 cd $R
 python3 - <<'PY'
@@ -15,6 +14,10 @@ os.makedirs('/tmp/ad', exist_ok=True); ids.tofile('/tmp/ad/ids.i32')
 open('/tmp/ad/cmd', 'w').write(f"{path}\n{_cfg_string(cfg)}\n")
 PY
 P=$(sed -n 1p /tmp/ad/cmd); C=$(sed -n 2p /tmp/ad/cmd)
+for i in 1 2; do
+  $R/oracle/_ref/ref_hip_qwen2vl --model $P --ids /tmp/ad/ids.i32 --steps 129 --threads 4 --out /tmp/ad --cfg $C --dump-every 0 2>&1 | grep -E "backend|Decoding" | cut -c1-200 | sed 's/^/deferred: /'
+  MLLM_HIP_INLINE_LAUNCH=1 $R/oracle/_ref/ref_hip_qwen2vl --model $P --ids /tmp/ad/ids.i32 --steps 129 --threads 4 --out /tmp/ad --cfg $C --dump-every 0 2>&1 | grep -E "backend|Decoding" | cut -c1-200 | sed 's/^/inline:   /'
+done
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pa
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pa -- $R/oracle/_ref/ref_hip_qwen2vl --model $P --ids /tmp/ad/ids.i32 --steps 33 --threads 4 --out /tmp/ad --cfg $C --dump-every 0 > /tmp/ad/log 2>&1
 grep backend /tmp/ad/log | cut -c1-260
@@ -24,6 +27,6 @@ f = glob.glob("/tmp/pa/*/*kernel_stats.csv")[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows); calls = sum(int(r["Calls"]) for r in rows)
 print("kernel time total ms", tot / 1e6, "calls", calls)
-for r in rows[:12]:
+for r in rows[:14]:
     print(r["Name"].split("(")[0][-56:], r["Calls"], round(float(r["TotalDurationNs"]) / 1e6, 2), round(float(r["AverageNs"]) / 1e3, 2))
 PY
