@@ -391,7 +391,7 @@ def main():
     pk = prefill_kernels(cfgname) if rank == 0 else []
     mname, mfma = pmc_mfma()
     for kdesc in pk:
-        key = "gemm_q4k" if kdesc["kernel"].startswith("gemm_q4k") else "fa2_prefill"
+        key = "gemm_q4k" if kdesc["kernel"].startswith("gemm_q4k") else ("fa2_prefill_80" if "x 80" in kdesc["kernel"] else "fa2_prefill_128")
         kdesc["mfma_busy_frac"] = (mfma.get(key) or {}).get("mfma_busy_frac") if cfgname == "qwen2vl" else None
     pre_tf = pre_flops / (prefill_ms * 1e-3) / 1e12
     prefill_roofline = {"bound": "mfma", "achieved": round(pre_tf, 1), "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": round(pre_tf / PEAK_F16_MFMA_TF, 4),
