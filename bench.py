@@ -381,7 +381,7 @@ def main():
                 "algorithmic_bytes_per_token": int(tok_bytes), "us_per_token_device": round(dev_ms * 1e3 / K, 2), "traffic_source": tname,
                 "traffic_note": "FETCH_SIZE x2 (L2 memory-side requests; Infinity-Cache hits are counted): every kernel's own figure is its algorithmic bytes within 2 %; the "
                                 "total is higher by the 17.1 MB per layer that the attention launch's warming workgroups request early (gate|up + o-projection rows), which the "
-                                "GEMV launches then find in the Infinity Cache (profiles/r03_pmc_fetch_size.md, r03_warm_workgroups.md)",
+                                "GEMV launches then find in the Infinity Cache (profiles/r04_pmc_fetch_size.md; mechanism: r03_warm_workgroups.md)",
                 "kernels": kernels}
 
     # ---- the prefill half of the metric: MFMA-bound.  Algorithmic FLOPs of the forward (2 M N K of every Linear, 4 H S^2 D of every attention; the vision

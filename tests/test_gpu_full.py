@@ -1,5 +1,5 @@
-"""Full-size GPU parity (BASELINE.json configs[3] shape: Qwen2-VL-2B, Q4_K, 448x448 image + 24-token prompt, KV limit 800) against
-golden outputs of the reference's own run on the same synthetic .mllm (tests/golden/qwen2vl_2b_ref*.npz, made by
+"""Full-size GPU parity; NOTE the 2 B goldens hold SAMPLED logits (the top-64 and every 97th logit of steps 0, 16, 32, 48, 64 -- not whole 151,936-wide rows) plus all 65 greedy ids.
+BASELINE.json configs[3] shape (Qwen2-VL-2B, Q4_K, 448x448 image + 24-token prompt, KV limit 800) against golden outputs of the reference's own run on the same synthetic .mllm (tests/golden/qwen2vl_2b_ref*.npz, made by
 oracle/make_golden.py --full from oracle/_ref/ref_qwen2vl / ref_ops): greedy ids identical, every sampled logit bit-identical
 (the goldens keep the top-64 logits and every 97th logit of the dumped steps), the vision tower's image_embeds bit-identical."""
 import os
