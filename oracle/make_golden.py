@@ -212,6 +212,37 @@ def e2e_tiny():
     print("qwen2vl_tiny.npz tokens", toks.tolist())
 
 
+def e2e_ragged():
+    """Non-square grids whose patch / token counts are not multiples of the kernels' tiles (the reference's own model on the toy file): grid 6 x 10 (60 patches -> 15 image
+    tokens, 24 prompt tokens), 8 x 12 (96 -> 24, 33 tokens), 4 x 18 (72 -> 18, 21 tokens); 6 greedy steps each, every logit, plus the tower's image_embeds."""
+    c = synth.qwen2vl_tiny()
+    td = tempfile.mkdtemp()
+    dst = weights.qwen2vl_file(c, cache_dir=td)
+    out = {}
+    for k, (gh, gw, nt) in enumerate([(6, 10, 7), (8, 12, 7), (4, 18, 1)]):
+        pix, grid, ids = synth.qwen2vl_inputs(c, (gh, gw), nt)
+        d = tempfile.mkdtemp()
+        pix.tofile(os.path.join(d, "pix.f32"))
+        ids.tofile(os.path.join(d, "ids.i32"))
+        subprocess.run([os.path.join(REF, "ref_qwen2vl"), "--model", dst, "--ids", os.path.join(d, "ids.i32"), "--pix", os.path.join(d, "pix.f32"), "--grid", f"1,{gh},{gw}",
+                        "--steps", "6", "--threads", "4", "--out", d, "--cfg", _cfg_q2vl(c), "--dump-every", "1"], check=True, capture_output=True)
+        (emb,), _ = run_ops("vision", dst, [[(pix, (gh * gw, 3, 2, 14, 14)), (grid.astype(np.float32), (1, 1, 1, 3))]], p=(c.hidden, c.v_dim))
+        out[f"grid{k}"] = grid
+        out[f"ntext{k}"] = np.array(nt)
+        out[f"tokens{k}"] = np.fromfile(os.path.join(d, "tokens.i32"), dtype=np.int32)
+        out[f"logits{k}"] = np.stack([np.fromfile(os.path.join(d, f"logits_{s}.f32"), dtype=np.float32) for s in range(6)])
+        out[f"image_embeds{k}"] = emb.reshape(-1, c.hidden)
+        print("ragged", grid.tolist(), out[f"tokens{k}"].tolist(), out[f"image_embeds{k}"].shape)
+    # the shortest prompt the reference's model takes: two tokens (its get_position_ids reads S == 1 as a decode step and faults on an empty cache)
+    d = tempfile.mkdtemp()
+    np.array([17, 23], dtype=np.int32).tofile(os.path.join(d, "ids.i32"))
+    subprocess.run([os.path.join(REF, "ref_qwen2vl"), "--model", dst, "--ids", os.path.join(d, "ids.i32"), "--steps", "5", "--threads", "4", "--out", d, "--cfg", _cfg_q2vl(c),
+                    "--dump-every", "1"], check=True, capture_output=True)
+    out["one_tokens"] = np.fromfile(os.path.join(d, "tokens.i32"), dtype=np.int32)
+    out["one_logits"] = np.stack([np.fromfile(os.path.join(d, f"logits_{s}.f32"), dtype=np.float32) for s in range(5)])
+    np.savez_compressed(os.path.join(GOLD, "qwen2vl_ragged.npz"), **out)
+
+
 CACHE = os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache")
 
 
@@ -535,6 +566,9 @@ def mm_bhsd_golden():
 
 
 if __name__ == "__main__":
+    if "--ragged" in sys.argv:
+        e2e_ragged()
+        sys.exit(0)
     if "--mm-bhsd" in sys.argv:
         mm_bhsd_golden()
         sys.exit(0)
@@ -564,6 +598,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--all" in sys.argv:      # every golden that depends on a synthetic model file
         e2e_tiny()
+        e2e_ragged()
         configs_tiny()
         llava_tiny()
         moe_golden()

@@ -72,6 +72,28 @@ def test_reference_module_text_only_prompt(tiny, tiny_gold, tmp_path):
 
 
 @pytest.mark.parametrize("engine", [0, 1], ids=["op-by-op", "engine-module"])
+def test_reference_module_on_ragged_grids(tiny, tmp_path, engine):
+    """Non-square grids off the kernels' tile sizes (6 x 10, 8 x 12, 4 x 18 patches; tests/golden/qwen2vl_ragged.npz): the reference's Module through the adapter, and the
+    engine-backed Module, give the reference's CPU logits for 6 greedy steps; no Op falls back."""
+    from mllm_amd import synth
+    cfg, path = tiny
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "qwen2vl_ragged.npz"))
+    for k in range(3):
+        grid = g[f"grid{k}"]
+        pix, _, ids = synth.qwen2vl_inputs(cfg, (int(grid[1]), int(grid[2])), int(g[f"ntext{k}"]))
+        d = tmp_path / f"g{k}"
+        d.mkdir()
+        report, toks, logits = _run(str(d), cfg, path, ids, 6, pix, grid, engine=engine)
+        assert report["cpu_fallback_ops"] == 0 and report["refused"] == [], report
+        assert toks.tolist() == g[f"tokens{k}"].tolist() and np.array_equal(logits, g[f"logits{k}"]), k
+    d = tmp_path / "one"                        # the shortest prompt the reference takes (two tokens)
+    d.mkdir()
+    report, toks, logits = _run(str(d), cfg, path, np.array([17, 23], dtype=np.int32), 5, engine=engine)
+    assert report["cpu_fallback_ops"] == 0, report
+    assert toks.tolist() == g["one_tokens"].tolist() and np.array_equal(logits, g["one_logits"])
+
+
+@pytest.mark.parametrize("engine", [0, 1], ids=["op-by-op", "engine-module"])
 def test_untied_lm_head_through_the_boundary(tiny, tiny_gold, tmp_path, engine):
     """config.tie_embedding_words = false (demo_qwen2_vl's larger presets): the reference's Qwen2VLModel takes its `lm_head` Linear instead of the tied embedding table
     (modeling_qwen2_vl.hpp:375-401); both the Op-by-Op adapter and the engine-backed Module (which once hard-wired the tied head) must follow the flag: every logit of

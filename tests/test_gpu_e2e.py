@@ -19,6 +19,7 @@ def tiny_model(tmp_path_factory):
     cfg = synth.qwen2vl_tiny()
     path = weights.qwen2vl_file(cfg, cache_dir=str(tmp_path_factory.mktemp("w")))
     m = lib.Qwen2VL(cfg, path)
+    m.path = path
     yield cfg, m
     m.close()
 
@@ -88,6 +89,55 @@ def test_vision_tower_matches_reference(tiny_model, tiny_gold):
     m.vision(pix, grid, out.data_ptr())
     err = float(np.max(np.abs(out.cpu().numpy() - tiny_gold["image_embeds"])))
     assert err == 0.0, err
+
+
+def test_ragged_grids_match_reference(tiny_model):
+    """Non-square grids whose patch and token counts sit off every tile size (6 x 10 = 60 patches / 24 prompt tokens, 8 x 12 = 96 / 33, 4 x 18 = 72 / 21): image embeddings and
+    every logit of 6 greedy steps equal the reference's own run (tests/golden/qwen2vl_ragged.npz, oracle/make_golden.py --ragged)."""
+    cfg, m = tiny_model
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "qwen2vl_ragged.npz"))
+    for k in range(3):
+        grid = g[f"grid{k}"]
+        pix, _, ids = synth.qwen2vl_inputs(cfg, (int(grid[1]), int(grid[2])), int(g[f"ntext{k}"]))
+        n_tok = pix.shape[0] // 4
+        out = torch.empty((n_tok, cfg.hidden), dtype=torch.float32, device="cuda")
+        m.vision(pix, grid, out.data_ptr())
+        assert np.array_equal(out.cpu().numpy(), g[f"image_embeds{k}"]), k
+        m.clear_kvcache()
+        tok, logits, _ = m.prefill(ids, pix, grid)
+        toks, rows = [tok], [logits]
+        for _ in range(5):
+            tok, logits, _ = m.decode(tok)
+            toks.append(tok)
+            rows.append(logits)
+        assert toks == g[f"tokens{k}"].tolist(), (k, toks)
+        assert np.array_equal(np.stack(rows), g[f"logits{k}"]), (k, float(np.abs(np.stack(rows) - g[f"logits{k}"]).max()))
+    m.clear_kvcache()                           # the shortest prompt the reference takes (two tokens)
+    tok, logits, _ = m.prefill(np.array([17, 23], dtype=np.int32))
+    toks, rows = [tok], [logits]
+    for _ in range(4):
+        tok, logits, _ = m.decode(tok)
+        toks.append(tok)
+        rows.append(logits)
+    assert toks == g["one_tokens"].tolist() and np.array_equal(np.stack(rows), g["one_logits"])
+    m.clear_kvcache()
+
+
+def test_one_token_prompt_is_a_prefill(tiny_model):
+    """S == 1 on an empty cache: the reference's own model faults here (its get_position_ids reads S == 1 as a decode step), so there is no golden; the engine treats it as a
+    prefill of one token and must equal the oracle's composition of the graph."""
+    from oracle import models as omodels
+    cfg, m = tiny_model
+    ref = omodels.LLM(omodels.Weights(m.path), cfg)
+    m.clear_kvcache()
+    tok, logits, _ = m.prefill(np.array([17], dtype=np.int32))
+    want = ref.prefill(np.array([17], dtype=np.int32))
+    assert np.array_equal(logits, want) and m.cache_len() == 1
+    for _ in range(3):
+        want = ref.decode(tok)
+        tok, logits, _ = m.decode(tok)
+        assert np.array_equal(logits, want)
+    m.clear_kvcache()
 
 
 def test_generate_equals_stepwise_decode_and_clear_kvcache_resets(tiny_model):

@@ -159,6 +159,32 @@ def test_composed_llm_text_and_image_bit_exact():
     assert toks == g["tokens"].tolist() and np.array_equal(np.stack(rows), g["logits"])
 
 
+def test_composed_graph_on_ragged_grids_bit_exact():
+    """Non-square grids with patch / token counts off the kernels' tile sizes (6 x 10, 8 x 12, 4 x 18; tests/golden/qwen2vl_ragged.npz, the reference's own run): the
+    oracle's tower and LLM reproduce every image embedding and every logit of 6 greedy steps."""
+    from mllm_amd import synth
+    cfg, models, w, _ = _tiny()
+    g = np.load(os.path.join(GOLD, "qwen2vl_ragged.npz"))
+    for k in range(3):
+        grid = g[f"grid{k}"]
+        pix, grid2, ids = synth.qwen2vl_inputs(cfg, (int(grid[1]), int(grid[2])), int(g[f"ntext{k}"]))
+        assert np.array_equal(grid, grid2)
+        emb = models.vision_forward(w, cfg, pix, grid)
+        assert np.array_equal(emb, g[f"image_embeds{k}"]), (k, maxdiff(emb, g[f"image_embeds{k}"]))
+        m = models.LLM(w, cfg)
+        lg = m.prefill(ids, pix, grid)
+        rows, toks = [lg], [int(lg.argmax())]
+        for _ in range(5):
+            lg = m.decode(toks[-1]); rows.append(lg); toks.append(int(lg.argmax()))
+        assert toks == g[f"tokens{k}"].tolist() and np.array_equal(np.stack(rows), g[f"logits{k}"]), k
+    m = models.LLM(w, cfg)                      # the shortest prompt the reference takes (two tokens)
+    lg = m.prefill(np.array([17, 23], dtype=np.int32))
+    rows, toks = [lg], [int(lg.argmax())]
+    for _ in range(4):
+        lg = m.decode(toks[-1]); rows.append(lg); toks.append(int(lg.argmax()))
+    assert toks == g["one_tokens"].tolist() and np.array_equal(np.stack(rows), g["one_logits"])
+
+
 def test_expf_restatement_equals_libm():
     """The attention kernels carry a restatement of glibc's expf (oracle/restate.c:orc_expf = mllm_amd/csrc/common.h:glibc_expf);
     it must agree bit for bit with the libm the reference links against, over the argument range attention produces and beyond."""
