@@ -129,6 +129,29 @@ int mllm_hip_gemm_f32_bhsd(const float *a, const void *b, int b_dtype, float *c,
 size_t mllm_hip_linear_workspace_bytes(int wdtype, int M, int K);
 int mllm_hip_linear(const void *W, int wdtype, const float *bias, const float *x, void *y, int y_dtype, int64_t ldy,
                     int M, int N, int K, void *workspace, void *stream);
+/* ---- one activation row (M = 1) through a RUN of consecutive Ops of the reference's decoder layer in ONE launch -- what integration/hip's lazy window issues when the
+ *      frontend hands it, one Op at a time (mllm/Layer.hpp:128-218 -> Backend::runOp), a run such as
+ *        F_TTADD -> RMSNORM -> LINEAR q, k, v      |   LINEAR o -> F_TTADD      |   RMSNORM -> LINEAR gate -> SILU -> LINEAR up -> F_TTMUL      |   LINEAR down -> F_TTADD
+ *      (models/qwen2_vl/modeling_qwen2_vl.hpp:204-211,248-257,307-315; models/qwen/modeling_qwen.hpp:40-47,78-86).  Every Op's own output tensor is still written and every value is
+ *      computed by the arithmetic of that Op's own entry point above (mllm_hip_add, mllm_hip_rmsnorm, mllm_hip_linear M = 1, mllm_hip_silu, mllm_hip_mul): bit-identical results.
+ *        prologue  s = xa + xb (xb optional; stored to sum_out if given) -> n = RMSNorm(s; norm_w, eps) (norm_w optional; stored to norm_out if given) -> Q8_K(n)
+ *        body      nseg <= 3 Linears of raw Q4_K rows [N][K/256] on that row: y = dot + bias
+ *        epilogue  mode 0: post_out = y + post_add per segment (optional);  mode 1 (nseg == 2, equal N): silu_out = silu(y0) (optional store), mul_out = silu_out * y1
+ *      K % 256 == 0, K <= 10240; each N >= the rows one workgroup takes (<= 32).  Fields ending in `_` are filled by the library. ---- */
+typedef struct mllm_hip_row_seg { const void *W; const float *bias; float *y; const float *post_add; float *post_out; int N; int wg0_; } mllm_hip_row_seg;
+typedef struct mllm_hip_row_fused {
+    const float *xa; const float *xb; float *sum_out;
+    const float *norm_w; float *norm_out; float eps;
+    int K; int nseg; int mode; int rpw_;
+    mllm_hip_row_seg seg[3];
+    float *silu_out; float *mul_out;
+} mllm_hip_row_fused;
+int mllm_hip_row_fused_launch(const mllm_hip_row_fused *args, void *stream);
+int mllm_hip_row_fused_supported(const mllm_hip_row_fused *args);      /* 1 when the launch covers these shapes (host-side check, no device work), else 0 */
+/* RoPE(q), RoPE(k), the fp16 store of the rotated k rows and the fp16 store of the v rows (MULTIMODALROPE / ROPE x 2 + KVCACHE x 2 of one attention block) in one launch:
+ * mllm_hip_rope_apply's and mllm_hip_store_f16's arithmetic element for element; q_out / k_out are the two RoPE Ops' fp32 outputs, k16 / v16 the cache slab rows to append to */
+int mllm_hip_rope2_store2(const float *q, const float *sin_q, const float *cos_q, int ld_tab_q, float *q_out, int Hq, const float *k, const float *sin_k, const float *cos_k, int ld_tab_k,
+                          float *k_out, uint16_t *k16, const float *v, uint16_t *v16, int Hkv, int S, int D, void *stream);
 /* Q4_0 rows `[N][K/32]` of 18-B blocks -> nibble plane `[N][K/2]` + fp16 scale plane `[N][K/32]` (load-time repack;
  * Backend::load_from_file hook, mllm/Backend.hpp:118) */
 int mllm_hip_repack_q40(const void *raw_blocks, uint8_t *qs, uint16_t *d, int64_t n_blocks, void *stream);
@@ -147,6 +170,8 @@ int mllm_hip_layernorm(const float *x, const float *w, const float *b, float *y,
 /* ---- A14/A18/A20: activations and elementwise -------------------------------------------------------------------- */
 /* CPUSiLU (op/CPUSiLU.cpp:24-52 -> mllm_v_expf polynomial, compute/ActivationFunction.hpp:96-134) */
 int mllm_hip_silu(const float *x, float *y, int64_t n, void *stream);
+/* the same per ROW of `dim` values, as CPUSiLU::execute applies it (op/CPUSiLU.cpp:35-47): the dim % 8 trailing values of each row go through libm's expf (mllm_silu_f32) */
+int mllm_hip_silu_rows(const float *x, float *y, int64_t rows, int dim, void *stream);
 /* silu(gate)*up of QWen2MLP (modeling_qwen2_vl.hpp:205-208): gu is `[M][2*I]` with gate in cols [0,I), up in [I,2I) */
 int mllm_hip_silu_mul(const float *gu, float *y, int M, int I, void *stream);
 /* CPUGELU / CPUQuickGELU through the fp16 LUTs (ggml Quantize.hpp:74-131). `lut` = 65536 fp16 entries on device;

@@ -31,6 +31,8 @@ HIPBackend::HIPBackend(int device) {
     registerFuncs();
     dump_dir_ = getenv("MLLM_HIP_DUMP_DIR");
     inline_launch_ = getenv("MLLM_HIP_INLINE_LAUNCH") != nullptr;
+    no_fuse_ = getenv("MLLM_HIP_NO_FUSE") != nullptr;
+    lazy_.reserve(64);
     ring_.resize(kRing);
     worker_ = std::thread([this] { worker_loop(); });
 }
@@ -73,6 +75,7 @@ void HIPBackend::publish_slot() {
     head_.store(head_.load(std::memory_order_relaxed) + 1, std::memory_order_release);
 }
 void HIPBackend::enqueue(std::function<int()> call, const char *what) {
+    if (!lazy_.empty() && !flushing_) flush_lazy();
     if (inline_launch_) { check(call(), what); return; }
     Deferred &d = claim_slot();
     d.thunk = nullptr;
@@ -81,6 +84,7 @@ void HIPBackend::enqueue(std::function<int()> call, const char *what) {
     publish_slot();
 }
 void HIPBackend::drain() {
+    if (!lazy_.empty() && !flushing_) flush_lazy();
     const size_t h = head_.load(std::memory_order_relaxed);
     while (tail_.load(std::memory_order_acquire) != h) __builtin_ia32_pause();
     if (failed_.load(std::memory_order_acquire)) {
@@ -124,6 +128,143 @@ void HIPBackend::drain_idle() {
     idle_.clear();
     idle_bytes_ = 0;
 }
+// ---- the lazy window (see HIPBackend.hpp) ------------------------------------------------------------------------------------------------------------------------
+void HIPBackend::lazy(const LazyOp &op) {
+    if (no_fuse_) { emit_single(op); return; }
+    lazy_.push_back(op);
+    if (lazy_.size() >= 48) flush_lazy();      // a decode layer is 17; nothing the patterns below know is longer than 6
+}
+void HIPBackend::flush_lazy() {
+    if (flushing_) return;
+    flushing_ = true;
+    try {
+        for (size_t i = 0; i < lazy_.size();) i += emit_group(i);
+    } catch (...) { lazy_.clear(); flushing_ = false; throw; }
+    lazy_.clear();
+    flushing_ = false;
+}
+// the Op's own call, exactly as its execute() used to issue it
+void HIPBackend::emit_single(const LazyOp &o) {
+    const bool was = flushing_;
+    flushing_ = true;      // defer() must not come back into the window
+    switch (o.kind) {
+    case LazyOp::NORM: defer("mllm_hip_rmsnorm", mllm_hip_rmsnorm, o.a, o.w, o.out, (int8_t *)nullptr, (float *)nullptr, (int16_t *)nullptr, 1, (int)o.n, o.eps, 0, stream_); break;
+    case LazyOp::LINEAR: defer("mllm_hip_linear", mllm_hip_linear, o.W, (int)MLLM_HIP_Q4_K, o.w, o.a, (void *)o.out, (int)MLLM_HIP_F32, (int64_t)o.n, 1, (int)o.n, o.K, o.ws, stream_); break;
+    case LazyOp::SILU: defer("mllm_hip_silu", mllm_hip_silu, o.a, o.out, o.n, stream_); break;
+    case LazyOp::MUL: defer("mllm_hip_mul", mllm_hip_mul, o.a, o.b, o.out, o.n, stream_); break;
+    case LazyOp::ADD: defer("mllm_hip_add", mllm_hip_add, o.a, o.b, o.out, o.n, stream_); break;
+    case LazyOp::ROPE: defer("mllm_hip_rope_apply", mllm_hip_rope_apply, o.a, (int64_t)o.H * o.D, o.sin, o.cos, o.ld_tab, (void *)o.out, (int)MLLM_HIP_F32, (int64_t)o.H * o.D, o.S, o.H, o.D, stream_); break;
+    case LazyOp::KVSTORE: defer("mllm_hip_store_f16", mllm_hip_store_f16, o.a, (int64_t)o.n, o.dst16, (int64_t)o.n, o.S, (int)o.n, stream_); break;
+    }
+    flushing_ = was;
+}
+// emits the longest run starting at lazy_[i] that one launch covers (else lazy_[i] alone); returns how many Ops it consumed
+size_t HIPBackend::emit_group(size_t i) {
+    const std::vector<LazyOp> &L = lazy_;
+    const size_t n = L.size();
+    auto fusable = [](const LazyOp &o) { return o.kind == LazyOp::LINEAR && o.K > 0 && o.K % 256 == 0 && (o.K / 256 + 7) / 8 <= 5; };
+    auto launch = [&](const mllm_hip_row_fused &a, size_t ops) -> size_t {
+        defer("mllm_hip_row_fused_launch", +[](mllm_hip_row_fused args, void *st) -> int { return mllm_hip_row_fused_launch(&args, st); }, a, stream_);
+        ++fused_launches_;
+        fused_ops_ += (long)ops;
+        return ops;
+    };
+    // One launch stands for a run of Ops only if no workgroup can overwrite what another still reads: the frontend hands a block it has released to the next tensor of that size
+    // (the ADD's operand becomes the norm's output, the gate's block the up projection's), which is harmless between launches and a race inside one.  So: no output of the launch
+    // may overlap an input every workgroup reads (xa, xb) or another row's post_add.  (Outputs that alias EACH OTHER are written in the Ops' order by one thread: gate then up.)
+    auto safe = [](const mllm_hip_row_fused &a) -> bool {
+        struct R { const void *p; size_t n; };
+        R in[5], out[10];
+        int ni = 0, no = 0;
+        const size_t kb = (size_t)a.K * 4;
+        in[ni++] = {a.xa, kb};
+        if (a.xb) in[ni++] = {a.xb, kb};
+        if (a.sum_out) out[no++] = {a.sum_out, kb};
+        if (a.norm_out) out[no++] = {a.norm_out, kb};
+        for (int i = 0; i < a.nseg; ++i) {
+            const size_t nbytes = (size_t)a.seg[i].N * 4;
+            out[no++] = {a.seg[i].y, nbytes};
+            if (a.seg[i].post_out) { out[no++] = {a.seg[i].post_out, nbytes}; in[ni++] = {a.seg[i].post_add, nbytes}; }
+        }
+        if (a.silu_out) out[no++] = {a.silu_out, (size_t)a.seg[0].N * 4};
+        if (a.mul_out) out[no++] = {a.mul_out, (size_t)a.seg[0].N * 4};
+        for (int o = 0; o < no; ++o)
+            for (int i = 0; i < ni; ++i)
+                if ((const char *)out[o].p < (const char *)in[i].p + in[i].n && (const char *)in[i].p < (const char *)out[o].p + out[o].n) return false;
+        return true;
+    };
+    auto seg_of = [](mllm_hip_row_seg &s, const LazyOp &lin) { s.W = lin.W; s.bias = lin.w; s.y = lin.out; s.N = (int)lin.n; s.post_add = nullptr; s.post_out = nullptr; s.wg0_ = 0; };
+    const LazyOp &o = L[i];
+    // [F_TTADD ->] RMSNORM -> LINEAR x 1..3 on the normalised row   |   ... -> LINEAR gate -> SILU -> LINEAR up -> F_TTMUL
+    {
+        size_t j = i;
+        const LazyOp *add = nullptr, *norm = nullptr;
+        if (L[j].kind == LazyOp::ADD && j + 1 < n && L[j + 1].kind == LazyOp::NORM && L[j + 1].a == L[j].out && L[j + 1].n == L[j].n) add = &L[j++];
+        if (L[j].kind == LazyOp::NORM) norm = &L[j++];
+        if (norm && j < n && fusable(L[j]) && L[j].a == norm->out && L[j].K == (int)norm->n) {
+            mllm_hip_row_fused a{};
+            a.xa = add ? add->a : norm->a;
+            a.xb = add ? add->b : nullptr;
+            a.sum_out = add ? add->out : nullptr;
+            a.norm_w = norm->w; a.norm_out = norm->out; a.eps = norm->eps; a.K = (int)norm->n;
+            const size_t head = j - i;
+            // the MLP's run
+            if (j + 3 < n && L[j + 1].kind == LazyOp::SILU && L[j + 1].a == L[j].out && L[j + 1].n == L[j].n && fusable(L[j + 2]) && L[j + 2].a == norm->out &&
+                L[j + 2].K == L[j].K && L[j + 2].n == L[j].n && L[j + 3].kind == LazyOp::MUL && L[j + 3].n == L[j].n &&
+                ((L[j + 3].a == L[j + 1].out && L[j + 3].b == L[j + 2].out) || (L[j + 3].b == L[j + 1].out && L[j + 3].a == L[j + 2].out))) {
+                a.nseg = 2; a.mode = 1;
+                seg_of(a.seg[0], L[j]); seg_of(a.seg[1], L[j + 2]);
+                a.silu_out = L[j + 1].out; a.mul_out = L[j + 3].out;
+                if (mllm_hip_row_fused_supported(&a) && safe(a)) return launch(a, head + 4);
+            }
+            a.mode = 0; a.silu_out = a.mul_out = nullptr;
+            int cnt = 0;
+            while (cnt < 3 && j + cnt < n && fusable(L[j + cnt]) && L[j + cnt].a == norm->out && L[j + cnt].K == (int)norm->n) { seg_of(a.seg[cnt], L[j + cnt]); ++cnt; }
+            for (; cnt >= 1; --cnt) {
+                a.nseg = cnt;
+                if (mllm_hip_row_fused_supported(&a) && safe(a)) return launch(a, head + cnt);
+            }
+        }
+    }
+    if (fusable(o)) {
+        mllm_hip_row_fused a{};
+        a.xa = o.a; a.K = o.K; a.mode = 0;
+        // LINEAR -> F_TTADD of its output (o / down projection + the residual)
+        if (i + 1 < n && L[i + 1].kind == LazyOp::ADD && L[i + 1].n == o.n && (L[i + 1].a == o.out || L[i + 1].b == o.out) && L[i + 1].a != L[i + 1].b) {
+            a.nseg = 1;
+            seg_of(a.seg[0], o);
+            a.seg[0].post_add = L[i + 1].a == o.out ? L[i + 1].b : L[i + 1].a;
+            a.seg[0].post_out = L[i + 1].out;
+            if (mllm_hip_row_fused_supported(&a) && safe(a)) return launch(a, 2);
+        }
+        // LINEAR x 2..3 on the same row (q | k | v without a norm in front)
+        int cnt = 0;
+        while (cnt < 3 && i + cnt < n && fusable(L[i + cnt]) && L[i + cnt].a == o.a && L[i + cnt].K == o.K) { seg_of(a.seg[cnt], L[i + cnt]); ++cnt; }
+        for (; cnt >= 2; --cnt) {
+            a.nseg = cnt;
+            if (mllm_hip_row_fused_supported(&a) && safe(a)) return launch(a, cnt);
+        }
+    }
+    // ROPE(q), ROPE(k), KVCACHE(k) of the rotated k, KVCACHE(v)
+    if (o.kind == LazyOp::ROPE && i + 3 < n && L[i + 1].kind == LazyOp::ROPE && L[i + 2].kind == LazyOp::KVSTORE && L[i + 3].kind == LazyOp::KVSTORE) {
+        const LazyOp &rq = o, &rk = L[i + 1], &sk = L[i + 2], &sv = L[i + 3];
+        // the frontend may hand q's released block to the rotated k (equal head counts): then ROPE(q)'s reads and ROPE(k)'s writes would meet inside one launch
+        auto apart = [](const void *p, size_t pn, const void *q, size_t qn) { return (const char *)p + pn <= (const char *)q || (const char *)q + qn <= (const char *)p; };
+        const size_t qb = (size_t)rq.S * rq.H * rq.D * 4, kb = (size_t)rk.S * rk.H * rk.D * 4;
+        const bool clear = apart(rq.out, qb, rq.a, qb) && apart(rq.out, qb, rk.a, kb) && apart(rq.out, qb, sv.a, kb) && apart(rk.out, kb, rq.a, qb) && apart(rk.out, kb, rk.a, kb) &&
+                           apart(rk.out, kb, sv.a, kb) && apart(rq.out, qb, rk.out, kb);
+        if (clear && rq.S == rk.S && rq.D == rk.D && sk.a == rk.out && sk.S == rk.S && sv.S == rk.S && sk.n == (int64_t)rk.H * rk.D && sv.n == sk.n) {
+            defer("mllm_hip_rope2_store2", mllm_hip_rope2_store2, rq.a, rq.sin, rq.cos, rq.ld_tab, rq.out, rq.H, rk.a, rk.sin, rk.cos, rk.ld_tab, rk.out, sk.dst16, sv.a, sv.dst16, rk.H, rk.S,
+                  rk.D, stream_);
+            ++fused_launches_;
+            fused_ops_ += 4;
+            return 4;
+        }
+    }
+    emit_single(o);
+    return 1;
+}
+
 HIPBackend::~HIPBackend() {
     try { drain(); } catch (...) {}
     stop_.store(true, std::memory_order_release);

@@ -109,6 +109,7 @@ public:
     // and thrown from the next drain().
     template <typename Fn, typename... A>
     void defer(const char *what, Fn fn, A... args) {
+        if (!lazy_.empty() && !flushing_) flush_lazy();      // program order: what the window still holds goes first
         // the call travels as plain bytes inside its ring slot (function pointer + the argument tuple): no allocation on this thread, nothing to free on the worker's
         if (inline_launch_) { check(fn(args...), what); return; }      // MLLM_HIP_INLINE_LAUNCH=1: the caller's thread launches (A/B measurements, debugging)
         using Tup = std::tuple<A...>;
@@ -122,6 +123,32 @@ public:
     }
     void enqueue(std::function<int()> call, const char *what);      // the rare calls that own memory (small uploads carry their bytes)
     void drain();
+
+    // ---- the lazy window: fusion across the Ops the frontend issues one at a time ----
+    // A decode layer reaches this backend as 18 Ops on ONE activation row (RMSNORM, LINEAR q / k / v, ROPE x 2, KVCACHE x 2, F_FA2, LINEAR o, F_TTADD, RMSNORM, LINEAR gate, SILU,
+    // LINEAR up, F_TTMUL, LINEAR down, F_TTADD), 17 launches of 2-5 us each -- the device, not the host, bounds the Op-by-Op path.  The Ops of that run do not launch: they describe
+    // themselves (LazyOp) and the window emits, in program order, the longest runs the library has one launch for (mllm_hip_row_fused_launch, mllm_hip_rope2_store2) and everything
+    // else as the Op's own call.  A fused launch still writes EVERY Op's output tensor with the value that Op's own kernel computes, so nothing the frontend can observe changes;
+    // runs are contiguous, so the order of all device work is the program's.  Anything that is not a LazyOp (another Op's defer, an upload, a drain) flushes the window first.
+    // MLLM_HIP_NO_FUSE=1 emits every Op on its own (A/B measurements).
+    struct LazyOp {
+        enum Kind : int { NORM, LINEAR, SILU, MUL, ADD, ROPE, KVSTORE } kind;
+        const float *a = nullptr, *b = nullptr;      // inputs (b: second operand of ADD / MUL)
+        float *out = nullptr;
+        int64_t n = 0;                               // elements (SILU / MUL / ADD), row width (NORM, KVSTORE), out_features (LINEAR)
+        const float *w = nullptr;                    // NORM weights / LINEAR bias
+        float eps = 0;
+        const void *W = nullptr;                     // LINEAR: raw Q4_K rows
+        int K = 0;
+        void *ws = nullptr;                          // LINEAR: the workspace of its own call
+        const float *sin = nullptr, *cos = nullptr;  // ROPE
+        int ld_tab = 0, S = 0, H = 0, D = 0;
+        uint16_t *dst16 = nullptr;                   // KVSTORE: the slab rows to append to
+    };
+    void lazy(const LazyOp &op);
+    void flush_lazy();
+    long fused_launches() const { return fused_launches_; }
+    long fused_ops() const { return fused_ops_; }
 
     // ---- reference-counted device blocks (fact 1) ----
     void *dev_alloc(size_t bytes);                   // Op-owned memory (weights' repacks, KV slabs, tables): one reference, dropped by dev_release
@@ -190,7 +217,7 @@ private:
         int (*thunk)(Deferred &) = nullptr;      // unpacks args and calls fn; nullptr: `call` below is the call
         void (*fn)() = nullptr;
         const char *what = "";
-        alignas(16) unsigned char args[176];
+        alignas(16) unsigned char args[256];
         std::function<int()> call;
     };
     Deferred &claim_slot();
@@ -201,7 +228,11 @@ private:
     alignas(64) std::atomic<size_t> tail_{0};      // ... the worker consumes at tail_ (own cache lines: the two threads do not bounce one line)
     alignas(64) size_t tail_seen_ = 0;             // producer's cached view of tail_
     std::atomic<bool> stop_{false}, failed_{false};
-    bool inline_launch_ = false;
+    bool inline_launch_ = false, no_fuse_ = false, flushing_ = false;
+    std::vector<LazyOp> lazy_;
+    long fused_launches_ = 0, fused_ops_ = 0;
+    void emit_single(const LazyOp &op);
+    size_t emit_group(size_t i);
     std::thread worker_;
     std::string failure_;
     void worker_loop();

@@ -83,6 +83,11 @@ public:
             // activations to Q8_K (quantize_row_q8_K_reference), then vec_dot_q4_K_q8_K per (row, output): GEMV below 16 rows, packed GEMM from 16 on
             if (M < 16) {
                 uint8_t *ws = (uint8_t *)b->scratch(0, mllm_hip_linear_workspace_bytes(MLLM_HIP_Q4_K, M, in_));
+                if (M == 1) {      // one row: a candidate for the lazy window's fused launches (HIPBackend::lazy)
+                    HIPBackend::LazyOp o;
+                    o.kind = HIPBackend::LazyOp::LINEAR; o.a = x; o.out = (float *)y; o.n = out_; o.w = bias; o.W = weight_.device_memory().handle; o.K = in_; o.ws = ws;
+                    b->lazy(o);
+                } else
                 HIPQ(mllm_hip_linear, weight_.device_memory().handle, MLLM_HIP_Q4_K, bias, x, y, MLLM_HIP_F32, out_, M, out_, in_, ws, b->stream());
             } else {
                 void *xpack = b->scratch(1, mllm_hip_q4k_prepack_bytes(M, in_));
@@ -206,7 +211,11 @@ public:
         const float *w = (const float *)weight_.device_memory().handle;
         if (layer_) HIPQ(mllm_hip_layernorm, (const float *)dptr(inputs[0]), w, has_bias_ ? (const float *)bias_.device_memory().handle : nullptr, (float *)dptr(outputs[0]), nullptr,
                                               nullptr, nullptr, M, dim_, eps_, hb()->stream());
-        else HIPQ(mllm_hip_rmsnorm, (const float *)dptr(inputs[0]), w, (float *)dptr(outputs[0]), nullptr, nullptr, nullptr, M, dim_, eps_, unit_offset_ ? 1 : 0, hb()->stream());
+        else if (M == 1 && !unit_offset_) {
+            HIPBackend::LazyOp o;
+            o.kind = HIPBackend::LazyOp::NORM; o.a = (const float *)dptr(inputs[0]); o.out = (float *)dptr(outputs[0]); o.n = dim_; o.w = w; o.eps = eps_;
+            hb()->lazy(o);
+        } else HIPQ(mllm_hip_rmsnorm, (const float *)dptr(inputs[0]), w, (float *)dptr(outputs[0]), nullptr, nullptr, nullptr, M, dim_, eps_, unit_offset_ ? 1 : 0, hb()->stream());
         return MLLM_NO_ERROR;
     }
 
@@ -257,7 +266,11 @@ public:
             dc = tab_ + (size_t)max_pos_ * D + (size_t)h_cnt_ * D;
             ld_tab = D;
         }
-        HIPQ(mllm_hip_rope_apply, (const float *)dptr(inputs[0]), (int64_t)H * D, ds, dc, ld_tab, dptr(outputs[0]), MLLM_HIP_F32, (int64_t)H * D, S, H, D, b->stream());
+        {
+            HIPBackend::LazyOp o;
+            o.kind = HIPBackend::LazyOp::ROPE; o.a = (const float *)dptr(inputs[0]); o.out = (float *)dptr(outputs[0]); o.sin = ds; o.cos = dc; o.ld_tab = ld_tab; o.S = S; o.H = H; o.D = D;
+            b->lazy(o);
+        }
         if (!multimodal_) h_cnt_ += S;
         return MLLM_NO_ERROR;
     }
@@ -369,7 +382,11 @@ public:
     }
     ErrorCode execute(TensorList inputs, TensorList) override {
         const int S = inputs[0]->sequence(), n = (int)row_;
-        if (S) HIPQ(mllm_hip_store_f16, (const float *)dptr(inputs[0]), n, (uint16_t *)slab_ + (size_t)cache_seq_len_ * n, n, S, n, hb()->stream());
+        if (S) {
+            HIPBackend::LazyOp o;
+            o.kind = HIPBackend::LazyOp::KVSTORE; o.a = (const float *)dptr(inputs[0]); o.dst16 = (uint16_t *)slab_ + (size_t)cache_seq_len_ * n; o.n = n; o.S = S;
+            hb()->lazy(o);
+        }
         cache_seq_len_ += S;
         return MLLM_NO_ERROR;
     }
@@ -422,7 +439,13 @@ public:
         auto *b = hb();
         const int64_t n = inputs[0]->count();
         if (n == 0) return MLLM_NO_ERROR;
-        if (kind_ == SILU_K) HIPQ(mllm_hip_silu, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), n, b->stream());
+        if (kind_ == SILU_K && inputs[0]->dimension() % 8 != 0)      // rows with a libm tail (CPUSiLU.cpp:35-47 applies the vector form per row)
+            HIPQ(mllm_hip_silu_rows, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), n / inputs[0]->dimension(), inputs[0]->dimension(), b->stream());
+        else if (kind_ == SILU_K) {
+            HIPBackend::LazyOp o;
+            o.kind = HIPBackend::LazyOp::SILU; o.a = (const float *)dptr(inputs[0]); o.out = (float *)dptr(outputs[0]); o.n = n;
+            b->lazy(o);
+        }
         else HIPQ(mllm_hip_act_lut, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), n, kind_ == GELU_K ? b->gelu_lut() : b->quickgelu_lut(), b->stream());
         return MLLM_NO_ERROR;
     }
@@ -440,8 +463,12 @@ public:
     }
     ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode execute(TensorList inputs, TensorList outputs) override {
-        auto fn = mul_ ? mllm_hip_mul : mllm_hip_add;
-        if (inputs[0]->count()) HIPQ(fn, (const float *)dptr(inputs[0]), (const float *)dptr(inputs[1]), (float *)dptr(outputs[0]), (int64_t)inputs[0]->count(), hb()->stream());
+        if (inputs[0]->count()) {
+            HIPBackend::LazyOp o;
+            o.kind = mul_ ? HIPBackend::LazyOp::MUL : HIPBackend::LazyOp::ADD;
+            o.a = (const float *)dptr(inputs[0]); o.b = (const float *)dptr(inputs[1]); o.out = (float *)dptr(outputs[0]); o.n = (int64_t)inputs[0]->count();
+            hb()->lazy(o);
+        }
         return MLLM_NO_ERROR;
     }
 

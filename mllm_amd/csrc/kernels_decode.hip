@@ -1293,6 +1293,197 @@ int dec_linear_row_q4k(const void *Wraw, const float *x, const float *addend, fl
     return MH_LAUNCH_OK("dec_proj_blk");
 }
 
+// ---- one activation row through UP TO SIX Ops of the reference's decoder layer in one launch (mllm_hip_row_fused; integration/hip's lazy window) ------------------------------
+// The reference's frontend issues a decode layer one Op at a time: F_TTADD -> RMSNorm -> Linear q, k, v ... Linear o -> F_TTADD ... RMSNorm -> Linear gate -> SiLU -> Linear up ->
+// F_TTMUL -> Linear down -> F_TTADD.  This kernel is dec_proj_blk_kernel (one lane per super-block, rows by LDS-DMA) with the neighbouring Ops folded in, every Op's own output still
+// written (the frontend owns those tensors), every value computed by the arithmetic of the Op's own kernel:
+//   prologue   s = xa + xb (F_TTADD, CPUBinaryFunc.hpp)  ->  n = RMSNorm(s) (norm_kernel's double sum, (x * inv) * w)  ->  Q8_K of n   (each optional; workgroup 0 stores s and n)
+//   body       up to three Linears on that row (q | k | v), each its own raw Q4_K rows + bias: y = dot + bias
+//   epilogue   mode 0: post_out = y + post_add (the F_TTADD behind an o / down projection);   mode 1: segment 0 = gate, 1 = up: silu_out = silu(y0), mul_out = silu_out * y1
+// A workgroup covers `rpw` consecutive rows of one segment (mode 1: rpw / 2 rows of the gate and the same rows of the up projection).
+typedef mllm_hip_row_seg RowFusedSeg;
+typedef mllm_hip_row_fused RowFusedArgs;
+static inline size_t rowf_lds_bytes(int K, int rpw, int mode) {
+    return 192 + ((gub_act_bytes(K) + 15) & ~(size_t)15) + (mode == 1 ? 2 * pjb_stage_bytes(rpw / 2, K / 256) : pjb_stage_bytes(rpw, K / 256)) + (size_t)rpw * (K / 256) * Q4K_SLOTS * 8;
+}
+template <int WPB, int NQ>
+__global__ __launch_bounds__(64 * WPB) void row_fused_kernel(const RowFusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = A.K, nb = K >> 8, RPW = A.rpw_;
+    double *red = reinterpret_cast<double *>(smem);                 // [8]
+    float *resbuf = reinterpret_cast<float *>(smem + 64);           // [32]
+    char *act0 = smem + 192;
+    ActLds a;
+    a.qs = reinterpret_cast<int8_t *>(act0);
+    a.d = reinterpret_cast<float *>(act0 + (size_t)nb * GUB_QSTRIDE);
+    a.q8s = reinterpret_cast<int *>(act0 + (size_t)nb * GUB_QSTRIDE + ((nb * 4 + 15) & ~15));
+    a.xf = nullptr;
+    a.qstride = GUB_QSTRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool gateup = A.mode == 1;
+    int s = 0;
+    if (!gateup) {
+        if (A.nseg > 1 && (int)blockIdx.x >= A.seg[1].wg0_) s = 1;
+        if (A.nseg > 2 && (int)blockIdx.x >= A.seg[2].wg0_) s = 2;
+    }
+    const uint8_t *W0 = (const uint8_t *)(s == 0 ? A.seg[0].W : (s == 1 ? A.seg[1].W : A.seg[2].W));
+    const int Ns = s == 0 ? A.seg[0].N : (s == 1 ? A.seg[1].N : A.seg[2].N);
+    const int wg0 = s == 0 ? 0 : (s == 1 ? A.seg[1].wg0_ : A.seg[2].wg0_);
+    const int half = gateup ? RPW >> 1 : RPW;      // rows of one segment in this workgroup
+    const int row0 = min(((int)blockIdx.x - wg0) * half, Ns - half);     // the last workgroup re-does rows of its neighbour (same values)
+    char *stage = act0 + ((gub_act_bytes(K) + 15) & ~(size_t)15);
+    const int run = half * nb * 144;
+    char *stage2 = stage + ((run + 1023) & ~1023);                        // mode 1: the up rows' run (1 KB steps of the LDS-DMA loop must not run into it)
+    float2 *tab = reinterpret_cast<float2 *>(stage + (gateup ? 2 * (size_t)((run + 1023) & ~1023) : pjb_stage_bytes(RPW, nb)));
+    const bool has_b = A.xb != nullptr, has_n = A.norm_w != nullptr;
+    const float *pb = has_b ? A.xb : A.xa, *pw = has_n ? A.norm_w : A.xa;      // unconditional loads (a predicated load is waited for inside its branch)
+    float4 v[NQ], vb[NQ], wv[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int blk = wid + WPB * i, o = (blk < nb ? blk : 0) * 256 + lane * 4;
+        v[i] = *reinterpret_cast<const float4 *>(A.xa + o);
+        vb[i] = *reinterpret_cast<const float4 *>(pb + o);
+        wv[i] = *reinterpret_cast<const float4 *>(pw + o);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w), "+v"(vb[i].x), "+v"(vb[i].y), "+v"(vb[i].z), "+v"(vb[i].w), "+v"(wv[i].x), "+v"(wv[i].y), "+v"(wv[i].z), "+v"(wv[i].w));
+    {
+        const uint8_t *src = W0 + (int64_t)row0 * nb * 144;
+        const unsigned st0 = (unsigned)(size_t)stage;
+        for (int o = wid * 1024; o < run; o += WPB * 1024) {
+            const int off = o + lane * 16;
+            glds16_dec(src + (off < run ? off : 0), st0 + (unsigned)o);
+        }
+        if (gateup) {
+            const uint8_t *src2 = (const uint8_t *)A.seg[1].W + (int64_t)row0 * nb * 144;
+            const unsigned st2 = (unsigned)(size_t)stage2;
+            for (int o = wid * 1024; o < run; o += WPB * 1024) {
+                const int off = o + lane * 16;
+                glds16_dec(src2 + (off < run ? off : 0), st2 + (unsigned)o);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        if (has_b) { v[i].x = __fadd_rn(v[i].x, vb[i].x); v[i].y = __fadd_rn(v[i].y, vb[i].y); v[i].z = __fadd_rn(v[i].z, vb[i].z); v[i].w = __fadd_rn(v[i].w, vb[i].w); }
+        if (wid + WPB * i >= nb) v[i] = make_float4(0, 0, 0, 0);
+        else if (A.sum_out && blockIdx.x == 0) *reinterpret_cast<float4 *>(A.sum_out + (wid + WPB * i) * 256 + lane * 4) = v[i];
+    }
+    if (has_n) {      // norm_kernel<false>: double sum of squares, inv = 1 / sqrt(mean + eps), (x * inv) * w
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) ss += (double)v[i].x * (double)v[i].x + (double)v[i].y * (double)v[i].y + (double)v[i].z * (double)v[i].z + (double)v[i].w * (double)v[i].w;
+        ss = wave_sum_d(ss);
+        if (lane == 0) red[wid] = ss;
+        __syncthreads();
+        ss = red[0];
+#pragma unroll
+        for (int w = 1; w < WPB; ++w) ss += red[w];
+        const float m = (float)(ss / (double)K);
+        const float inv = __fdiv_rn(1.0f, sqrtf(__fadd_rn(m, A.eps)));
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            v[i].x = __fmul_rn(__fmul_rn(v[i].x, inv), wv[i].x); v[i].y = __fmul_rn(__fmul_rn(v[i].y, inv), wv[i].y);
+            v[i].z = __fmul_rn(__fmul_rn(v[i].z, inv), wv[i].z); v[i].w = __fmul_rn(__fmul_rn(v[i].w, inv), wv[i].w);
+            if (wid + WPB * i >= nb) v[i] = make_float4(0, 0, 0, 0);
+            else if (A.norm_out && blockIdx.x == 0) *reinterpret_cast<float4 *>(A.norm_out + (wid + WPB * i) * 256 + lane * 4) = v[i];
+        }
+    }
+    wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // stage row r < half sits in the first run, the rest (mode 1: the up rows) in the second
+    auto blk_of = [&](int sb) -> const char * { return sb < half * nb ? stage + (size_t)sb * 144 : stage2 + (size_t)(sb - half * nb) * 144; };
+    if (RPW * nb > 64 && 2 * RPW * nb <= 64 * WPB) {
+        const int sb = tid >> 1;
+        if (sb < RPW * nb) blk_emit_pair(blk_of(sb), a, sb % nb, tid & 1, tab + (size_t)sb * Q4K_SLOTS);
+    } else if (tid < RPW * nb) {
+        blk_emit(blk_of(tid), a, tid % nb, tab + (size_t)tid * Q4K_SLOTS);
+    }
+    __syncthreads();
+    float res = 0.0f;
+    int nr = 0;
+    if (4 * wid < RPW) {
+        nr = RPW - 4 * wid < 4 ? RPW - 4 * wid : 4;
+        res = q4k_chain(tab + (size_t)4 * wid * nb * Q4K_SLOTS, nb, nb, nr, lane);
+    }
+    if (!gateup) {
+        const float *bias = s == 0 ? A.seg[0].bias : (s == 1 ? A.seg[1].bias : A.seg[2].bias);
+        float *y = s == 0 ? A.seg[0].y : (s == 1 ? A.seg[1].y : A.seg[2].y);
+        const float *padd = s == 0 ? A.seg[0].post_add : (s == 1 ? A.seg[1].post_add : A.seg[2].post_add);
+        float *pout = s == 0 ? A.seg[0].post_out : (s == 1 ? A.seg[1].post_out : A.seg[2].post_out);
+        const int rw = row0 + 4 * wid + (lane >> 4);
+        if ((lane & 15) == 8 && (lane >> 4) < nr) {
+            const float yv = bias ? __fadd_rn(res, bias[rw]) : res;
+            y[rw] = yv;
+            if (pout) pout[rw] = __fadd_rn(yv, padd[rw]);
+        }
+        return;
+    }
+    if ((lane & 15) == 8 && (lane >> 4) < nr) resbuf[4 * wid + (lane >> 4)] = res;
+    __syncthreads();
+    if (tid < half) {
+        const int rw = row0 + tid;
+        float g = resbuf[tid], u = resbuf[half + tid];
+        if (A.seg[0].bias) g = __fadd_rn(g, A.seg[0].bias[rw]);
+        if (A.seg[1].bias) u = __fadd_rn(u, A.seg[1].bias[rw]);
+        const float sg = __fdiv_rn(g, __fadd_rn(1.0f, v_expf_dec(__fsub_rn(0.0f, g))));      // silu_kernel's silu_ref
+        A.seg[0].y[rw] = g;                 // in the Ops' order: the frontend may have handed the gate's block to the up projection's output
+        if (A.silu_out) A.silu_out[rw] = sg;
+        A.seg[1].y[rw] = u;
+        A.mul_out[rw] = __fmul_rn(sg, u);
+    }
+}
+// host side of the launch: the rows a workgroup takes and where each segment's workgroups start; > 0 = the grid, < 0 = an error code (shape not covered)
+static int row_fused_plan(RowFusedArgs &A) {
+    const int K = A.K;
+    if (K <= 0 || K % 256 || A.nseg < 1 || A.nseg > 3 || !A.xa) return MLLM_HIP_ERR_SHAPE;
+    const int nb = K >> 8, nsr = (nb + 7) / 8;
+    if (nsr > 5) return MLLM_HIP_ERR_SHAPE;
+    int total = 0;
+    if (A.mode == 1) {
+        if (A.nseg != 2 || A.seg[0].N != A.seg[1].N || !A.mul_out || !A.seg[0].W || !A.seg[1].W || !A.seg[0].y || !A.seg[1].y) return MLLM_HIP_ERR_SHAPE;
+        const int N = A.seg[0].N;
+        const int half = std::max(1, std::min(std::min(256 / nb, 16), (N + 255) / 256));
+        if (N < half) return MLLM_HIP_ERR_SHAPE;
+        A.rpw_ = 2 * half;
+        total = (N + half - 1) / half;
+    } else if (A.mode == 0) {
+        int sumN = 0;
+        for (int i = 0; i < A.nseg; ++i) sumN += A.seg[i].N;
+        A.rpw_ = pjb_rows_per_wg(sumN, K);
+        for (int i = 0; i < A.nseg; ++i) {
+            if (A.seg[i].N < A.rpw_ || !A.seg[i].W || !A.seg[i].y || (A.seg[i].post_out && !A.seg[i].post_add)) return MLLM_HIP_ERR_SHAPE;
+            A.seg[i].wg0_ = total;
+            total += (A.seg[i].N + A.rpw_ - 1) / A.rpw_;
+        }
+    } else return MLLM_HIP_ERR_ARG;
+    return total;
+}
+int row_fused_supported(const RowFusedArgs &in) {
+    RowFusedArgs A = in;
+    return row_fused_plan(A) > 0 ? 1 : 0;
+}
+int row_fused_launch(const RowFusedArgs &in, hipStream_t st) {
+    RowFusedArgs A = in;
+    const int total = row_fused_plan(A);
+    if (total <= 0) return total ? total : MLLM_HIP_ERR_SHAPE;
+    const int K = A.K, nsr = (K / 256 + 7) / 8;
+    const size_t lds = rowf_lds_bytes(K, A.rpw_, A.mode);
+#define ROWF_CASE(NSV)                                                                  \
+    case NSV: {                                                                         \
+        auto bk = row_fused_kernel<8, NSV>;                                             \
+        const int rc = allow_lds(bk, lds);                                              \
+        if (rc) return rc;                                                              \
+        hipLaunchKernelGGL(bk, dim3(total), dim3(512), lds, st, A);                     \
+    } break;
+    switch (nsr) { ROWF_CASE(1) ROWF_CASE(2) ROWF_CASE(3) ROWF_CASE(4) ROWF_CASE(5) }
+#undef ROWF_CASE
+    return MH_LAUNCH_OK("row_fused");
+}
+
 #define NS_DISPATCH(K, CALL)                           \
     switch (((K) / 256 + 7) / 8) {                     \
     case 1: { constexpr int NS = 1; CALL; } break;     \
@@ -1489,3 +1680,9 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
     return MH_LAUNCH_OK("dec_next");
 }
 }  // namespace mllm_hip
+
+extern "C" int mllm_hip_row_fused_launch(const mllm_hip_row_fused *args, void *stream) {
+    if (!args) return MLLM_HIP_ERR_ARG;
+    return mllm_hip::row_fused_launch(*args, mllm_hip::as_stream(stream));
+}
+extern "C" int mllm_hip_row_fused_supported(const mllm_hip_row_fused *args) { return args ? mllm_hip::row_fused_supported(*args) : 0; }

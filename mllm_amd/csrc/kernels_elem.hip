@@ -380,6 +380,18 @@ __global__ __launch_bounds__(256) void silu_kernel(const float *__restrict__ x, 
     }
     if (i < n) for (int64_t j = i; j < n && j < i + 4; ++j) y[j] = silu_ref(x[j]);
 }
+// CPUSiLU::execute calls mllm_vec_silu_f32 per (b, h, s) ROW (op/CPUSiLU.cpp:35-47): the dim % 8 trailing values of every row take the scalar mllm_silu_f32 = x / (1 + expf(-x)) with
+// libm's expf (ActivationFunction.cpp:24-26), the rest the polynomial.  Rows of a multiple of 8 (every model on the hot path) have no such tail: silu_kernel above.
+__global__ __launch_bounds__(256) void silu_rows_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t rows, int dim) {
+    __shared__ uint64_t tab[32];
+    expf_tab_store(tab, expf_tab_fetch());
+    __syncthreads();
+    const int full = dim & ~7;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * dim; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        y[i] = (int)(i % dim) < full ? silu_ref(v) : __fdiv_rn(v, __fadd_rn(1.0f, glibc_expf(-v, tab)));
+    }
+}
 // silu(gate)*up of QWen2MLP (modeling_qwen2_vl.hpp:205-208) on a fused [M][2I] gate|up buffer
 __global__ __launch_bounds__(256) void silu_mul_kernel(const float *__restrict__ gu, float *__restrict__ y, int M, int I) {
     const int64_t total = (int64_t)M * I / 4;
@@ -754,6 +766,33 @@ __global__ __launch_bounds__(256) void qkv_rope_append_kernel(float *__restrict_
         }
     }
 }
+// RoPE(q) -> q_out, RoPE(k) -> k_out and its fp16 image in the K slab rows, v -> fp16 V slab rows: four Ops of the reference's attention block (two RoPE layers, two KVCache
+// layers) that the adapter's lazy window hands over together; rope_apply_kernel's and store_f16's arithmetic (the fp16 k is the rounding of the stored fp32 k_out)
+__global__ __launch_bounds__(256) void rope2_store2_kernel(const float *__restrict__ q, const float *__restrict__ sin_q, const float *__restrict__ cos_q, int ld_tab_q,
+                                                           float *__restrict__ q_out, int Hq, const float *__restrict__ k, const float *__restrict__ sin_k,
+                                                           const float *__restrict__ cos_k, int ld_tab_k, float *__restrict__ k_out, uint16_t *__restrict__ k16,
+                                                           const float *__restrict__ v, uint16_t *__restrict__ v16, int Hkv, int S, int D) {
+    const int half = D >> 1;
+    const int64_t nq = (int64_t)S * Hq * half, nk = (int64_t)S * Hkv * half, nv = (int64_t)S * Hkv * D;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nq + nk + nv; t += (int64_t)gridDim.x * 256) {
+        if (t < nq + nk) {
+            const bool isk = t >= nq;
+            const int64_t u = isk ? t - nq : t;
+            const int H = isk ? Hkv : Hq;
+            const int d = (int)(u % half), h = (int)((u / half) % H), s_ = (int)(u / ((int64_t)half * H));
+            const int64_t o = (int64_t)s_ * H * D + h * D + d;
+            const float *x = isk ? k : q;
+            const float a = x[o], b = x[o + half];
+            const float sv = isk ? sin_k[(int64_t)s_ * ld_tab_k + d] : sin_q[(int64_t)s_ * ld_tab_q + d], cv = isk ? cos_k[(int64_t)s_ * ld_tab_k + d] : cos_q[(int64_t)s_ * ld_tab_q + d];
+            const float v1 = __fmaf_rn(a, cv, -__fmul_rn(b, sv)), v2 = __fmaf_rn(a, sv, __fmul_rn(b, cv));
+            if (isk) { k_out[o] = v1; k_out[o + half] = v2; k16[o] = f2h(v1); k16[o + half] = f2h(v2); }
+            else { q_out[o] = v1; q_out[o + half] = v2; }
+        } else {
+            const int64_t u = t - nq - nk;
+            v16[u] = f2h(v[u]);
+        }
+    }
+}
 // the same for B sequences that each append ONE token to their own slabs (batched decode): row b of qkv, rotary row b, destination = sequence b's slabs at its position t_b
 __global__ __launch_bounds__(256) void seqs_rope_append_kernel(float *__restrict__ qkv, int64_t ldq, const float *__restrict__ sin_t, const float *__restrict__ cos_t, int ld_tab,
                                                                const SeqKV *__restrict__ seqs, int64_t layer_k_off, int64_t layer_v_off, int64_t ldk, int64_t ldv, int Hq, int Hkv,
@@ -916,6 +955,12 @@ extern "C" int mllm_hip_silu(const float *x, float *y, int64_t n, void *stream) 
     if (n <= 0) return MLLM_HIP_OK;
     hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, as_stream(stream), x, y, n);
     return MH_LAUNCH_OK("silu");
+}
+extern "C" int mllm_hip_silu_rows(const float *x, float *y, int64_t rows, int dim, void *stream) {
+    if (rows <= 0 || dim <= 0) return MLLM_HIP_OK;
+    if (dim % 8 == 0) return mllm_hip_silu(x, y, rows * dim, stream);
+    hipLaunchKernelGGL(silu_rows_kernel, dim3(grid_for(rows * dim, 256)), dim3(256), 0, as_stream(stream), x, y, rows, dim);
+    return MH_LAUNCH_OK("silu_rows");
 }
 extern "C" int mllm_hip_silu_mul(const float *gu, float *y, int M, int I, void *stream) {
     if (I % 4 != 0) return MLLM_HIP_ERR_SHAPE;
@@ -1141,6 +1186,15 @@ extern "C" int mllm_hip_rope_apply(const float *x, int64_t ldx, const float *sin
         hipLaunchKernelGGL(rope_apply_kernel<false>, dim3(g), dim3(256), 0, as_stream(stream), x, ldx, sin_t, cos_t, ld_tab, out, ldo, S, H, D, 0);
     else return MLLM_HIP_ERR_DTYPE;
     return MH_LAUNCH_OK("rope_apply");
+}
+extern "C" int mllm_hip_rope2_store2(const float *q, const float *sin_q, const float *cos_q, int ld_tab_q, float *q_out, int Hq, const float *k, const float *sin_k, const float *cos_k,
+                                     int ld_tab_k, float *k_out, uint16_t *k16, const float *v, uint16_t *v16, int Hkv, int S, int D, void *stream) {
+    if (D % 2 != 0 || Hq <= 0 || Hkv <= 0) return MLLM_HIP_ERR_SHAPE;
+    if (S <= 0) return MLLM_HIP_OK;
+    const int64_t n = (int64_t)S * (Hq + Hkv) * (D / 2) + (int64_t)S * Hkv * D;
+    hipLaunchKernelGGL(rope2_store2_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), q, sin_q, cos_q, ld_tab_q, q_out, Hq, k, sin_k, cos_k, ld_tab_k, k_out, k16, v, v16, Hkv,
+                       S, D);
+    return MH_LAUNCH_OK("rope2_store2");
 }
 namespace mllm_hip {
 // fp32 in place over `rows` rows whose table row is (row % period): the images of one vision pass in one launch

@@ -154,6 +154,14 @@ def silu(x):
     return _unary("mllm_hip_silu", x)
 
 
+def silu_rows(x):
+    """CPUSiLU on rows `[rows][dim]`: the dim % 8 trailing values of every row take libm's expf (mllm_hip_silu_rows)."""
+    x = _dev(x, torch.float32)
+    y = torch.empty_like(x)
+    check(L.load().mllm_hip_silu_rows(vp(x), vp(y), i64(x.shape[0]), C.c_int(x.shape[1]), _stream()), "silu_rows")
+    return y
+
+
 _luts = None
 
 
@@ -404,3 +412,73 @@ def moe_block(x, router_raw, w1_raw, w3_raw, w2_raw, inter, per_tok):
     check(L.load().mllm_hip_moe_block(vp(x), vp(out), C.c_int(S), C.c_int(H), C.c_int(inter), C.c_int(E), C.c_int(per_tok), vp(router), arrs[0], arrs[1], arrs[2],
                                       _stream()), "moe_block")
     return out
+
+
+class _RowSeg(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("post_add", C.c_void_p), ("post_out", C.c_void_p), ("N", C.c_int), ("wg0_", C.c_int)]
+
+
+class _RowFused(C.Structure):
+    _fields_ = [("xa", C.c_void_p), ("xb", C.c_void_p), ("sum_out", C.c_void_p), ("norm_w", C.c_void_p), ("norm_out", C.c_void_p), ("eps", C.c_float), ("K", C.c_int),
+                ("nseg", C.c_int), ("mode", C.c_int), ("rpw_", C.c_int), ("seg", _RowSeg * 3), ("silu_out", C.c_void_p), ("mul_out", C.c_void_p)]
+
+
+def row_fused(xa, segs, xb=None, norm_w=None, eps=1e-6, gateup=False):
+    """mllm_hip_row_fused_launch (include/mllm_hip.h): one activation row `xa [K]` (+ `xb`) -> [RMSNorm] -> up to three Q4_K Linears `segs = [(W_raw, N, bias, post_add), ...]` with the
+    F_TTADD behind each (mode 0) or the SiLU / F_TTMUL of a gate / up pair (mode 1).  Returns a dict of every Op output the launch wrote."""
+    xa = _dev(xa, torch.float32).reshape(-1)
+    K = xa.numel()
+    a = _RowFused()
+    keep = [xa]
+
+    def dv(t):
+        t = _dev(t, torch.float32).reshape(-1)
+        keep.append(t)
+        return t
+
+    out = {}
+    a.xa = xa.data_ptr()
+    if xb is not None:
+        a.xb = dv(xb).data_ptr()
+        out["sum"] = torch.full((K,), float("nan"), dtype=torch.float32, device="cuda")
+        a.sum_out = out["sum"].data_ptr()
+    if norm_w is not None:
+        a.norm_w = dv(norm_w).data_ptr()
+        out["norm"] = torch.full((K,), float("nan"), dtype=torch.float32, device="cuda")
+        a.norm_out = out["norm"].data_ptr()
+    a.eps, a.K, a.nseg, a.mode = eps, K, len(segs), 1 if gateup else 0
+    out["y"], out["post"] = [], []
+    for i, (W, N, bias, post_add) in enumerate(segs):
+        Wd = _dev(W, torch.uint8)
+        keep.append(Wd)
+        y = torch.full((N,), float("nan"), dtype=torch.float32, device="cuda")
+        out["y"].append(y)
+        a.seg[i].W, a.seg[i].y, a.seg[i].N = Wd.data_ptr(), y.data_ptr(), N
+        if bias is not None:
+            a.seg[i].bias = dv(bias).data_ptr()
+        if post_add is not None:
+            a.seg[i].post_add = dv(post_add).data_ptr()
+            p = torch.full((N,), float("nan"), dtype=torch.float32, device="cuda")
+            out["post"].append(p)
+            a.seg[i].post_out = p.data_ptr()
+        else:
+            out["post"].append(None)
+    if gateup:
+        out["silu"] = torch.full((segs[0][1],), float("nan"), dtype=torch.float32, device="cuda")
+        out["mul"] = torch.full((segs[0][1],), float("nan"), dtype=torch.float32, device="cuda")
+        a.silu_out, a.mul_out = out["silu"].data_ptr(), out["mul"].data_ptr()
+    check(L.load().mllm_hip_row_fused_launch(C.byref(a), _stream()), "row_fused")
+    torch.cuda.synchronize()
+    return out
+
+
+def rope2_store2(q, k, v, S, Hq, Hkv, D, sin_q, cos_q, sin_k, cos_k):
+    """mllm_hip_rope2_store2: returns (q_out fp32, k_out fp32, k16, v16)."""
+    q, k, v = _dev(q, torch.float32), _dev(k, torch.float32), _dev(v, torch.float32)
+    sq, cq, sk, ck = (_dev(t, torch.float32) for t in (sin_q, cos_q, sin_k, cos_k))
+    qo, ko = torch.empty_like(q), torch.empty_like(k)
+    k16 = torch.empty(k.shape, dtype=torch.float16, device="cuda")
+    v16 = torch.empty(v.shape, dtype=torch.float16, device="cuda")
+    check(L.load().mllm_hip_rope2_store2(vp(q), vp(sq), vp(cq), C.c_int(sq.shape[-1]), vp(qo), C.c_int(Hq), vp(k), vp(sk), vp(ck), C.c_int(sk.shape[-1]), vp(ko), vp(k16), vp(v),
+                                         vp(v16), C.c_int(Hkv), C.c_int(S), C.c_int(D), _stream()), "rope2_store2")
+    return qo, ko, k16, v16

@@ -92,6 +92,7 @@ int mllm_hip_layernorm(const float *x, const float *w, const float *b, float *y,
     return 0;
 }
 int mllm_hip_silu(const float *x, float *y, int64_t n, void *) { rd(x, n * 4); wr(y, n * 4); return 0; }
+int mllm_hip_silu_rows(const float *x, float *y, int64_t rows, int dim, void *) { rd(x, rows * dim * 4); wr(y, rows * dim * 4); return 0; }
 int mllm_hip_act_lut(const float *x, float *y, int64_t n, const uint16_t *lut, void *) { rd(x, n * 4); rd(lut, 65536 * 2); wr(y, n * 4); return 0; }
 int mllm_hip_add(const float *a, const float *b, float *y, int64_t n, void *) { rd(a, n * 4); rd(b, n * 4); wr(y, n * 4); return 0; }
 int mllm_hip_mul(const float *a, const float *b, float *y, int64_t n, void *) { rd(a, n * 4); rd(b, n * 4); wr(y, n * 4); return 0; }
@@ -105,6 +106,32 @@ int mllm_hip_copy_2d_f32(const float *src, int64_t lds, float *dst, int64_t ldd,
 int mllm_hip_transpose_f32(const float *x, float *y, int rows, int cols, void *) { rd(x, (size_t)rows * cols * 4); wr(y, (size_t)rows * cols * 4); return 0; }
 int mllm_hip_rope_apply(const float *x, int64_t ldx, const float *s, const float *c, int ld_tab, void *out, int odt, int64_t ldo, int S, int H, int D, void *) {
     rd2(x, ldx, S, (int64_t)H * D, 4); rd2(s, ld_tab, S, D / 2, 4); rd2(c, ld_tab, S, D / 2, 4); wr2(out, ldo, S, (int64_t)H * D, esz(odt));
+    return 0;
+}
+// the lazy window's fused launches: every Op output of the run is written, every input read, with the extents of the Ops the launch replaces
+int mllm_hip_row_fused_launch(const mllm_hip_row_fused *a, void *) {
+    if (!mllm_hip_row_fused_supported(a)) { fprintf(stderr, "mock: row_fused launched with a shape the library refuses\n"); abort(); }
+    const size_t K = (size_t)a->K;
+    rd(a->xa, K * 4);
+    if (a->xb) rd(a->xb, K * 4);
+    if (a->sum_out) wr(a->sum_out, K * 4);
+    if (a->norm_w) rd(a->norm_w, K * 4);
+    if (a->norm_out) wr(a->norm_out, K * 4);
+    for (int i = 0; i < a->nseg; ++i) {
+        const mllm_hip_row_seg &s = a->seg[i];
+        rd(s.W, (size_t)s.N * (K / 256) * 144);
+        if (s.bias) rd(s.bias, (size_t)s.N * 4);
+        wr(s.y, (size_t)s.N * 4);
+        if (s.post_out) { rd(s.post_add, (size_t)s.N * 4); wr(s.post_out, (size_t)s.N * 4); }
+    }
+    if (a->mode == 1) { if (a->silu_out) wr(a->silu_out, (size_t)a->seg[0].N * 4); wr(a->mul_out, (size_t)a->seg[0].N * 4); }
+    return 0;
+}
+int mllm_hip_rope2_store2(const float *q, const float *sq, const float *cq, int ldq, float *qo, int Hq, const float *k, const float *sk, const float *ck, int ldk, float *ko, uint16_t *k16,
+                          const float *v, uint16_t *v16, int Hkv, int S, int D, void *) {
+    rd(q, (size_t)S * Hq * D * 4); rd2(sq, ldq, S, D / 2, 4); rd2(cq, ldq, S, D / 2, 4); wr(qo, (size_t)S * Hq * D * 4);
+    rd(k, (size_t)S * Hkv * D * 4); rd2(sk, ldk, S, D / 2, 4); rd2(ck, ldk, S, D / 2, 4); wr(ko, (size_t)S * Hkv * D * 4); wr(k16, (size_t)S * Hkv * D * 2);
+    rd(v, (size_t)S * Hkv * D * 4); wr(v16, (size_t)S * Hkv * D * 2);
     return 0;
 }
 int mllm_hip_store_f16(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *) { rd2(x, ldx, S, n, 4); wr2(out, ldo, S, n, 2); return 0; }

@@ -45,9 +45,9 @@ static void hip_report(mllm::HIPBackend *hip, size_t prefill_tokens, const std::
         refused += std::string(i ? ", " : "") + "[" + std::to_string(hip->refused()[i].first) + ", \"" + hip->refused()[i].second + "\"]";
     refused += "]";
     printf("{\"backend\": \"hip\", \"prefill_tokens\": %zu, \"prefill_ms\": %.3f, \"decode_steps\": %zu, \"decode_ms_mean\": %.4f, \"decode_tok_s\": %.3f, %s"
-           "\"hip_ops_run\": %ld, \"cpu_fallback_ops\": %zu, \"refused\": %s, \"live_device_blocks\": %zu}\n",
+           "\"hip_ops_run\": %ld, \"fused_launches\": %ld, \"fused_ops\": %ld, \"cpu_fallback_ops\": %zu, \"refused\": %s, \"live_device_blocks\": %zu}\n",
            prefill_tokens, ms.empty() ? 0.0 : ms[0], ms.empty() ? (size_t)0 : ms.size() - 1, ms.size() > 1 ? dec / (ms.size() - 1) : 0.0,
-           ms.size() > 1 ? 1000.0 * (ms.size() - 1) / dec : 0.0, extra, hip->ops_run(), hip->refused().size(), refused.c_str(), hip->live_blocks());
+           ms.size() > 1 ? 1000.0 * (ms.size() - 1) / dec : 0.0, extra, hip->ops_run(), hip->fused_launches(), hip->fused_ops(), hip->refused().size(), refused.c_str(), hip->live_blocks());
     fflush(stdout);
 }
 #endif

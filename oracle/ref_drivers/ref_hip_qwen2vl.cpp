@@ -170,9 +170,9 @@ int main(int argc, char **argv) {
         refused += std::string(i ? ", " : "") + "[" + std::to_string(hip->refused()[i].first) + ", \"" + hip->refused()[i].second + "\"]";
     refused += "]";
     printf("{\"backend\": \"hip\", \"prefill_tokens\": %zu, \"prefill_ms\": %.3f, \"decode_steps\": %zu, \"decode_ms_mean\": %.4f, "
-           "\"decode_tok_s\": %.3f, \"hip_ops_run\": %ld, \"cpu_fallback_ops\": %zu, \"refused\": %s, \"live_device_blocks\": %zu}\n",
+           "\"decode_tok_s\": %.3f, \"hip_ops_run\": %ld, \"fused_launches\": %ld, \"fused_ops\": %ld, \"cpu_fallback_ops\": %zu, \"refused\": %s, \"live_device_blocks\": %zu}\n",
            ids.size(), ms[0], ms.size() - 1, ms.size() > 1 ? dec / (ms.size() - 1) : 0.0,
-           ms.size() > 1 ? 1000.0 * (ms.size() - 1) / dec : 0.0, hip->ops_run(), hip->refused().size(), refused.c_str(), hip->live_blocks());
+           ms.size() > 1 ? 1000.0 * (ms.size() - 1) / dec : 0.0, hip->ops_run(), hip->fused_launches(), hip->fused_ops(), hip->refused().size(), refused.c_str(), hip->live_blocks());
     fflush(stdout);
     if (engine) engine_model->profiling(); else graph_model->profiling();
     return 0;

@@ -329,6 +329,14 @@ def test_silu_mul_add_mul_bit_exact():
     assert eq(ops.add(a, b), a + b) and eq(ops.mul(a, b), a * b)
 
 
+@pytest.mark.parametrize("rows,dim", [(1, 1030), (5, 13), (3, 8), (7, 4), (2, 8967)])
+def test_silu_rows_with_the_scalar_tail(rows, dim):
+    """CPUSiLU applies mllm_vec_silu_f32 per row: the dim % 8 trailing values of EVERY row go through mllm_silu_f32 (libm expf), the rest through the polynomial."""
+    x = (rng(rows * dim).standard_normal((rows, dim)) * 3).astype(np.float32)
+    want = np.stack([orc.silu(x[r]) for r in range(rows)])
+    assert eq(ops.silu_rows(x), want)
+
+
 def test_softmax_argmax_index_put(ops_gold):
     g = ops_gold
     y = ops.softmax(g["sm_x"].reshape(6, 24))
@@ -482,3 +490,87 @@ def test_transpose_f32_moves_every_element():
         lib.check(lib.load().mllm_hip_transpose_f32(lib.vp(x), lib.vp(y), C.c_int(rows), C.c_int(cols), None), "transpose_f32")
         torch.cuda.synchronize()
         assert torch.equal(y, x.t().contiguous()), (rows, cols)
+
+
+# ---- the adapter's fused M = 1 launches: one launch = the run of Ops it replaces, output for output, bit for bit ----------------------------------------------------
+def _rows_case(K, Ns, seed):
+    r = rng(seed)
+    Ws = [synth.quantized_blocks(lib.Q4_K, r, N * K, std=0.05, full_range=True) for N in Ns]
+    xa = r.standard_normal(K).astype(np.float32)
+    xb = r.standard_normal(K).astype(np.float32)
+    w = (1.0 + 0.1 * r.standard_normal(K)).astype(np.float32)
+    return r, Ws, xa, xb, w
+
+
+@pytest.mark.parametrize("K,Ns", [(1536, (1536, 256, 256)), (256, (64, 64, 32)), (2048, (2048, 2048, 2048)), (4096, (4096,)), (1536, (151936,)), (768, (768, 128, 128)), (4096, (4096, 4096, 4096)), (1536, (1536, 250))])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_row_fused_add_norm_linears(K, Ns, with_add):
+    """F_TTADD -> RMSNORM -> up to three LINEARs (the q | k | v run): every output equals the separate entry points' and the oracle's."""
+    r, Ws, xa, xb, w = _rows_case(K, Ns, K + sum(Ns))
+    biases = [(r.standard_normal(N) * 0.1).astype(np.float32) if i != 1 else None for i, N in enumerate(Ns)]
+    out = ops.row_fused(xa, [(W, N, b, None) for W, N, b in zip(Ws, Ns, biases)], xb=xb if with_add else None, norm_w=w, eps=1e-6)
+    s = ops.add(xa, xb) if with_add else torch.from_numpy(xa).cuda()
+    if with_add:
+        assert eq(out["sum"], s.cpu().numpy()) and eq(out["sum"], xa + xb)
+    n = ops.rmsnorm(s.reshape(1, K), w, 1e-6)
+    assert eq(out["norm"], n.reshape(-1).cpu().numpy())
+    for W, N, b, y in zip(Ws, Ns, biases, out["y"]):
+        want = ops.linear_q4k(W, n, N, bias=b)
+        assert eq(y, want.reshape(-1).cpu().numpy()), md(y, want.reshape(-1).cpu().numpy())
+        assert eq(y, orc.linear(n.cpu().numpy(), W, orc.Q4_K, N, b).reshape(-1))
+
+
+@pytest.mark.parametrize("K,N", [(1536, 1536), (8960, 1536), (256, 40), (4096, 4096), (2816, 1024)])
+def test_row_fused_linear_then_add(K, N):
+    """LINEAR -> F_TTADD (o / down projection and the residual add behind it), no prologue."""
+    r, (W,), xa, _, _ = _rows_case(K, (N,), K * 3 + N)
+    res = r.standard_normal(N).astype(np.float32)
+    out = ops.row_fused(xa, [(W, N, None, res)])
+    y = ops.linear_q4k(W, xa.reshape(1, K), N).reshape(-1)
+    assert eq(out["y"][0], y.cpu().numpy())
+    assert eq(out["post"][0], ops.add(y, res).cpu().numpy())
+    assert eq(out["y"][0], orc.linear(xa.reshape(1, K), W, orc.Q4_K, N).reshape(-1))
+
+
+@pytest.mark.parametrize("K,I", [(1536, 8960), (256, 48), (2048, 5632), (1024, 2816), (4096, 11008), (768, 4864), (512, 1030)])
+def test_row_fused_norm_gate_silu_up_mul(K, I):
+    """RMSNORM -> LINEAR gate -> SILU -> LINEAR up -> F_TTMUL (the MLP's first five Ops), with and without the F_TTADD in front."""
+    r, (Wg, Wu), xa, xb, w = _rows_case(K, (I, I), K + I)
+    for with_add in (False, True):
+        out = ops.row_fused(xa, [(Wg, I, None, None), (Wu, I, None, None)], xb=xb if with_add else None, norm_w=w, eps=1e-5, gateup=True)
+        s = ops.add(xa, xb) if with_add else torch.from_numpy(xa).cuda()
+        n = ops.rmsnorm(s.reshape(1, K), w, 1e-5)
+        g = ops.linear_q4k(Wg, n, I).reshape(-1)
+        u = ops.linear_q4k(Wu, n, I).reshape(-1)
+        sg = ops.silu(g)
+        assert eq(out["norm"], n.reshape(-1).cpu().numpy())
+        assert eq(out["y"][0], g.cpu().numpy()) and eq(out["y"][1], u.cpu().numpy())
+        assert eq(out["silu"], sg.cpu().numpy()) and eq(out["mul"], ops.mul(sg, u).cpu().numpy())
+        if I % 8 == 0:
+            assert eq(out["silu"], orc.silu(g.cpu().numpy()))
+
+
+def test_row_fused_refuses_what_it_does_not_cover():
+    r, (W,), xa, _, _ = _rows_case(256, (4,), 1)
+    with pytest.raises(lib.MllmHipError):
+        ops.row_fused(np.zeros(11264, dtype=np.float32), [(np.zeros(144 * 44 * 8, dtype=np.uint8), 8, None, None)])      # K / 256 = 44 super-blocks: beyond the five register steps
+    with pytest.raises(lib.MllmHipError):
+        ops.row_fused(np.zeros(300, dtype=np.float32), [(W, 4, None, None)])                                              # K % 256 != 0
+
+
+@pytest.mark.parametrize("S,Hq,Hkv,D", [(1, 12, 2, 128), (7, 4, 4, 64), (282, 12, 2, 128), (1, 32, 32, 128)])
+def test_rope2_store2_equals_the_four_ops(S, Hq, Hkv, D):
+    r = rng(S + Hq + D)
+    q = r.standard_normal((S, Hq * D)).astype(np.float32)
+    k = r.standard_normal((S, Hkv * D)).astype(np.float32)
+    v = r.standard_normal((S, Hkv * D)).astype(np.float32)
+    ang = r.standard_normal((S, D // 2)).astype(np.float32)
+    sq, cq = np.sin(ang).astype(np.float32), np.cos(ang).astype(np.float32)
+    sk, ck = np.sin(ang * 0.5).astype(np.float32), np.cos(ang * 0.5).astype(np.float32)
+    qo, ko, k16, v16 = ops.rope2_store2(q, k, v, S, Hq, Hkv, D, sq, cq, sk, ck)
+    assert eq(qo, ops.rope_apply(q, S, Hq, D, sq, cq).cpu().numpy())
+    kw = ops.rope_apply(k, S, Hkv, D, sk, ck)
+    assert eq(ko, kw.cpu().numpy())
+    assert eq(k16.view(torch.int16), kw.to(torch.float16).view(torch.int16).cpu().numpy())
+    assert eq(k16.view(torch.int16), ops.rope_apply(k, S, Hkv, D, sk, ck, out_f16=True).view(torch.int16).cpu().numpy())
+    assert eq(v16.view(torch.int16), torch.from_numpy(v).to(torch.float16).view(torch.int16).numpy())
