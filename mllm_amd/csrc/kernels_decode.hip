@@ -311,7 +311,7 @@ __device__ __forceinline__ void load_rows2(float4 (&xv)[NV], float4 (&wv)[NV], c
 }
 // thread (wid, lane) holds values [(wid + WPB*i)*256 + 4*lane, +4): exactly the 4 values of lane `lane` of quant block wid + WPB*i
 template <int NV, int WPB>
-__device__ __forceinline__ void wg_rmsnorm_quant(const float4 (&xv)[NV], const float4 (&wv)[NV], int dim, float eps, const ActLds &a, double *red) {
+__device__ __forceinline__ void wg_rmsnorm_quant(const float4 (&xv)[NV], const float4 (&wv)[NV], int dim, float eps, const ActLds &a, double *red, float *norm_out = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     double ss = 0.0;
 #pragma unroll
@@ -332,6 +332,7 @@ __device__ __forceinline__ void wg_rmsnorm_quant(const float4 (&xv)[NV], const f
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         o[i].x = (xv[i].x * inv) * wv[i].x; o[i].y = (xv[i].y * inv) * wv[i].y; o[i].z = (xv[i].z * inv) * wv[i].z; o[i].w = (xv[i].w * inv) * wv[i].w;
+        if (norm_out && wid + WPB * i < nblk) *reinterpret_cast<float4 *>(norm_out + (wid + WPB * i) * 256 + lane * 4) = o[i];      // the RMSNORM Op's own output (adapter runs)
     }
     wave_quant_blocks<NV, WPB>(o, lane, wid, nblk, a);
     __syncthreads();
@@ -634,9 +635,12 @@ __device__ __forceinline__ void blk_emit_pair(const char *blk, const ActLds &a, 
     e[8 + h] = make_float2(dm, (float)pa); e[10 + h] = make_float2(dm, (float)pb);
 }
 
-template <int PAIRS, int NV, int WPB>
+// ADAPT (integration/hip's lazy window, mllm_hip_row_fused_launch mode 1): the gate and the up projection are two Linears' own row sets (W = gate rows, E.Wup = up rows), the row may
+// come as xa + xb (the F_TTADD in front), and every Op of the run keeps its output: the sum, the normalised row (workgroup 0 stores both), gate, silu(gate), up, and the product
+struct GubExtra { const uint8_t *Wup; const float *xb; float *sum_out, *norm_out, *g_out, *silu_out, *u_out; };
+template <int PAIRS, int NV, int WPB, bool ADAPT = false>
 __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *__restrict__ x, const float *__restrict__ norm_w, float eps,
-                                                                  const uint8_t *__restrict__ W, float *__restrict__ act, int I, int K) {
+                                                                  const uint8_t *__restrict__ W, float *__restrict__ act, int I, int K, const GubExtra E = GubExtra{}) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[(WPB + 1) & ~1];      // a multiple of 16 bytes: statics precede the dynamic region unpadded
     const int nb = K >> 8;
@@ -656,6 +660,16 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
     float4 xv[NV], wv[NV];
     GSTAMP(0);
     load_rows2<NV, WPB>(xv, wv, x, norm_w, K);
+    float4 bv[ADAPT ? NV : 1];
+    if constexpr (ADAPT) {
+        const float *pb = E.xb ? E.xb : x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int d = threadIdx.x * 4 + i * WPB * 256;
+            bv[i] = *reinterpret_cast<const float4 *>(pb + (d < K ? d : 0));
+            asm volatile("" : "+v"(bv[i].x), "+v"(bv[i].y), "+v"(bv[i].z), "+v"(bv[i].w));
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #if MLLM_HIP_GUB_DMA_FIRST
     // ---- the wave's rows: two contiguous runs of PAIRS * nb super-blocks -> LDS (global_load_lds_dwordx4, 1 KiB per instruction) ----------------
@@ -664,7 +678,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
         const unsigned st0 = (unsigned)(size_t)stage;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const uint8_t *src = W + ((int64_t)(r ? I + p0 : p0) * nb) * 144;
+            const uint8_t *src = (ADAPT && r ? E.Wup : W) + ((int64_t)(r && !ADAPT ? I + p0 : p0) * nb) * 144;
             for (int o = 0; o < run; o += 1024) {
                 const int off = o + lane * 16;
                 glds16_dec(src + (off < run ? off : 0), st0 + (unsigned)(r * half) + (unsigned)o);   // past the run: a dummy 16 bytes into the pad
@@ -677,6 +691,18 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (diagnostic build: the activation row and, in the DMA-first order, the weight rows have landed)
     GSTAMP(1);
 #endif
+    if constexpr (ADAPT) {
+        if (E.xb) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int d = threadIdx.x * 4 + i * WPB * 256;
+                xv[i].x = __fadd_rn(xv[i].x, bv[i].x); xv[i].y = __fadd_rn(xv[i].y, bv[i].y); xv[i].z = __fadd_rn(xv[i].z, bv[i].z); xv[i].w = __fadd_rn(xv[i].w, bv[i].w);
+                if (d >= K) xv[i] = make_float4(0, 0, 0, 0);
+                else if (E.sum_out && blockIdx.x == 0) *reinterpret_cast<float4 *>(E.sum_out + d) = xv[i];
+            }
+        }
+        wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red, blockIdx.x == 0 ? E.norm_out : nullptr);
+    } else
     wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
     GSTAMP(2);
 #if !MLLM_HIP_GUB_DMA_FIRST
@@ -686,7 +712,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
         const unsigned st0 = (unsigned)(size_t)stage;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const uint8_t *src = W + ((int64_t)(r ? I + p0 : p0) * nb) * 144;
+            const uint8_t *src = (ADAPT && r ? E.Wup : W) + ((int64_t)(r && !ADAPT ? I + p0 : p0) * nb) * 144;
             for (int o = 0; o < run; o += 1024) {
                 const int off = o + lane * 16;
                 glds16_dec(src + (off < run ? off : 0), st0 + (unsigned)(r * half) + (unsigned)o);   // past the run: a dummy 16 bytes into the pad
@@ -714,6 +740,13 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
     GSTAMP(5);
     if (live && lane < PAIRS) {
         const float g = outv[2 * lane], u = outv[2 * lane + 1];
+        if constexpr (ADAPT) {
+            const float sg = g / (1.0f + v_expf_dec(0.0f - g));
+            E.g_out[p0 + lane] = g;      // in the Ops' order: the frontend may have handed the gate's block to the up projection's output
+            if (E.silu_out) E.silu_out[p0 + lane] = sg;
+            E.u_out[p0 + lane] = u;
+            act[p0 + lane] = sg * u;
+        } else
         act[p0 + lane] = (g / (1.0f + v_expf_dec(0.0f - g))) * u;   // mllm_v_silu then F_TTMUL
     }
     GSTAMP(6);
@@ -1221,7 +1254,7 @@ static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *
         auto bk = dec_gateup_blk_kernel<BP, BNV, BW>;
         int brc = allow_lds(bk, blds);
         if (brc) return brc;
-        hipLaunchKernelGGL(bk, dim3((bw + BW - 1) / BW), dim3(64 * BW), blds, st, x, L.post_norm, c.eps, L.Wgu_raw, c.act, c.I, c.H);
+        hipLaunchKernelGGL(bk, dim3((bw + BW - 1) / BW), dim3(64 * BW), blds, st, x, L.post_norm, c.eps, L.Wgu_raw, c.act, c.I, c.H, GubExtra{});
         return MH_LAUNCH_OK("dec_gateup_blk");
     }
     constexpr int PAIRS = NS == 1 ? GU_PAIRS : 1, WPB = GU_WPB;
@@ -1304,15 +1337,15 @@ int dec_linear_row_q4k(const void *Wraw, const float *x, const float *addend, fl
 typedef mllm_hip_row_seg RowFusedSeg;
 typedef mllm_hip_row_fused RowFusedArgs;
 static inline size_t rowf_lds_bytes(int K, int rpw, int mode) {
-    return 192 + ((gub_act_bytes(K) + 15) & ~(size_t)15) + (mode == 1 ? 2 * pjb_stage_bytes(rpw / 2, K / 256) : pjb_stage_bytes(rpw, K / 256)) + (size_t)rpw * (K / 256) * Q4K_SLOTS * 8;
+    return 384 + ((gub_act_bytes(K) + 15) & ~(size_t)15) + (mode == 1 ? 2 * pjb_stage_bytes(rpw / 2, K / 256) : pjb_stage_bytes(rpw, K / 256)) + (size_t)rpw * (K / 256) * Q4K_SLOTS * 8;
 }
 template <int WPB, int NQ>
 __global__ __launch_bounds__(64 * WPB) void row_fused_kernel(const RowFusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = A.K, nb = K >> 8, RPW = A.rpw_;
-    double *red = reinterpret_cast<double *>(smem);                 // [8]
-    float *resbuf = reinterpret_cast<float *>(smem + 64);           // [32]
-    char *act0 = smem + 192;
+    double *red = reinterpret_cast<double *>(smem);                 // [WPB <= 16]
+    float *resbuf = reinterpret_cast<float *>(smem + 128);          // [rpw <= 64]
+    char *act0 = smem + 384;
     ActLds a;
     a.qs = reinterpret_cast<int8_t *>(act0);
     a.d = reinterpret_cast<float *>(act0 + (size_t)nb * GUB_QSTRIDE);
@@ -1446,6 +1479,7 @@ static int row_fused_plan(RowFusedArgs &A) {
     if (A.mode == 1) {
         if (A.nseg != 2 || A.seg[0].N != A.seg[1].N || !A.mul_out || !A.seg[0].W || !A.seg[1].W || !A.seg[0].y || !A.seg[1].y) return MLLM_HIP_ERR_SHAPE;
         const int N = A.seg[0].N;
+        // 16 rows of each projection per 512-thread workgroup (32 rows on 1024 threads halve the repeated prologues but measured slower: 11.7 against 9.8 us on 1536 x 8960)
         const int half = std::max(1, std::min(std::min(256 / nb, 16), (N + 255) / 256));
         if (N < half) return MLLM_HIP_ERR_SHAPE;
         A.rpw_ = 2 * half;
@@ -1460,6 +1494,7 @@ static int row_fused_plan(RowFusedArgs &A) {
             total += (A.seg[i].N + A.rpw_ - 1) / A.rpw_;
         }
     } else return MLLM_HIP_ERR_ARG;
+    if (rowf_lds_bytes(K, A.rpw_, A.mode) > 160 * 1024) return MLLM_HIP_ERR_SHAPE;
     return total;
 }
 int row_fused_supported(const RowFusedArgs &in) {
@@ -1471,6 +1506,18 @@ int row_fused_launch(const RowFusedArgs &in, hipStream_t st) {
     const int total = row_fused_plan(A);
     if (total <= 0) return total ? total : MLLM_HIP_ERR_SHAPE;
     const int K = A.K, nsr = (K / 256 + 7) / 8;
+    // the MLP's run on the 2 B model's shape: the engine's own gate|up kernel (a wave per five row pairs, no workgroup barrier behind the prologue) with the Ops' outputs added
+    if (A.mode == 1 && option(OPT_NO_GUB) <= 0 && 2 * 5 * (K >> 8) <= 64 && (K >> 8) <= 7 && A.seg[0].N % 5 == 0 && !A.seg[0].bias && !A.seg[1].bias && A.norm_w) {
+        constexpr int BP = 5, BW = 7;
+        const int I = A.seg[0].N, bw = I / BP;
+        const size_t blds = gub_lds_bytes(K, BP, BW);
+        auto bk = dec_gateup_blk_kernel<BP, 1, BW, true>;
+        const int brc = allow_lds(bk, blds);
+        if (brc) return brc;
+        const GubExtra E{(const uint8_t *)A.seg[1].W, A.xb, A.sum_out, A.norm_out, A.seg[0].y, A.silu_out, A.seg[1].y};
+        hipLaunchKernelGGL(bk, dim3((bw + BW - 1) / BW), dim3(64 * BW), blds, st, A.xa, A.norm_w, A.eps, (const uint8_t *)A.seg[0].W, A.mul_out, I, K, E);
+        return MH_LAUNCH_OK("dec_gateup_blk(adapt)");
+    }
     const size_t lds = rowf_lds_bytes(K, A.rpw_, A.mode);
 #define ROWF_CASE(NSV)                                                                  \
     case NSV: {                                                                         \

@@ -772,14 +772,14 @@ __global__ __launch_bounds__(256) void rope2_store2_kernel(const float *__restri
                                                            float *__restrict__ q_out, int Hq, const float *__restrict__ k, const float *__restrict__ sin_k,
                                                            const float *__restrict__ cos_k, int ld_tab_k, float *__restrict__ k_out, uint16_t *__restrict__ k16,
                                                            const float *__restrict__ v, uint16_t *__restrict__ v16, int Hkv, int S, int D) {
-    const int half = D >> 1;
-    const int64_t nq = (int64_t)S * Hq * half, nk = (int64_t)S * Hkv * half, nv = (int64_t)S * Hkv * D;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nq + nk + nv; t += (int64_t)gridDim.x * 256) {
+    // blockIdx.y = position; x walks the (Hq + Hkv) * D / 2 rotation pairs and the Hkv * D values of v of that position (32-bit index arithmetic: a decode step is one position)
+    const int half = D >> 1, s_ = blockIdx.y;
+    const int nq = Hq * half, nk = Hkv * half, nv = Hkv * D;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < nq + nk + nv; t += gridDim.x * 256) {
         if (t < nq + nk) {
             const bool isk = t >= nq;
-            const int64_t u = isk ? t - nq : t;
-            const int H = isk ? Hkv : Hq;
-            const int d = (int)(u % half), h = (int)((u / half) % H), s_ = (int)(u / ((int64_t)half * H));
+            const int u = isk ? t - nq : t, H = isk ? Hkv : Hq;
+            const int h = u / half, d = u - h * half;
             const int64_t o = (int64_t)s_ * H * D + h * D + d;
             const float *x = isk ? k : q;
             const float a = x[o], b = x[o + half];
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256) void rope2_store2_kernel(const float *__restri
             if (isk) { k_out[o] = v1; k_out[o + half] = v2; k16[o] = f2h(v1); k16[o + half] = f2h(v2); }
             else { q_out[o] = v1; q_out[o + half] = v2; }
         } else {
-            const int64_t u = t - nq - nk;
+            const int64_t u = (int64_t)s_ * nv + (t - nq - nk);
             v16[u] = f2h(v[u]);
         }
     }
@@ -1191,8 +1191,8 @@ extern "C" int mllm_hip_rope2_store2(const float *q, const float *sin_q, const f
                                      int ld_tab_k, float *k_out, uint16_t *k16, const float *v, uint16_t *v16, int Hkv, int S, int D, void *stream) {
     if (D % 2 != 0 || Hq <= 0 || Hkv <= 0) return MLLM_HIP_ERR_SHAPE;
     if (S <= 0) return MLLM_HIP_OK;
-    const int64_t n = (int64_t)S * (Hq + Hkv) * (D / 2) + (int64_t)S * Hkv * D;
-    hipLaunchKernelGGL(rope2_store2_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), q, sin_q, cos_q, ld_tab_q, q_out, Hq, k, sin_k, cos_k, ld_tab_k, k_out, k16, v, v16, Hkv,
+    const int per = (Hq + Hkv) * (D / 2) + Hkv * D;
+    hipLaunchKernelGGL(rope2_store2_kernel, dim3((per + 255) / 256, S), dim3(256), 0, as_stream(stream), q, sin_q, cos_q, ld_tab_q, q_out, Hq, k, sin_k, cos_k, ld_tab_k, k_out, k16, v, v16, Hkv,
                        S, D);
     return MH_LAUNCH_OK("rope2_store2");
 }

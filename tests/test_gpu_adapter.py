@@ -21,14 +21,14 @@ def _cfg_string(c):
             f"{c.vision_end_token_id},{c.video_token_id},{int(c.tie_embedding)}")
 
 
-def _run(td, cfg, path, ids, steps, pix=None, grid=None, engine=0):
+def _run(td, cfg, path, ids, steps, pix=None, grid=None, engine=0, env=None):
     ids.astype(np.int32).tofile(os.path.join(td, "ids.i32"))
     cmd = [DRIVER, "--model", path, "--ids", os.path.join(td, "ids.i32"), "--steps", str(steps), "--threads", "4", "--out", td, "--cfg", _cfg_string(cfg), "--dump-every", "1",
            "--engine", str(engine)]
     if pix is not None:
         pix.astype(np.float32).tofile(os.path.join(td, "pix.f32"))
         cmd += ["--pix", os.path.join(td, "pix.f32"), "--grid", ",".join(str(int(g)) for g in grid)]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env) if env else None)
     assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
     report = json.loads(next(l for l in out.stdout.splitlines() if l.startswith('{"backend"')))
     toks = np.fromfile(os.path.join(td, "tokens.i32"), dtype=np.int32)
@@ -59,6 +59,22 @@ def test_reference_module_on_the_hip_backend_matches_its_cpu_run(tiny, tiny_gold
     assert report["hip_ops_run"] > 600
     assert toks.tolist() == g["tokens"].tolist(), (toks.tolist(), g["tokens"].tolist())
     assert np.array_equal(logits, g["logits"]), float(np.max(np.abs(logits - g["logits"])))
+
+
+def test_lazy_window_fuses_the_decode_layer_and_changes_nothing(tiny, tiny_gold, tmp_path):
+    """The backend's lazy window (HIPBackend::lazy) hands a decode layer's 17 element-wise / one-row Ops to five fused launches: 8 steps x 2 layers x 5 launches
+    standing for 17 Ops each on the toy model -- and the logits of every step equal the reference's with the window on (default) and off (MLLM_HIP_NO_FUSE=1: one launch per Op,
+    the path every other test of this file also ran on before the window existed)."""
+    from mllm_amd import synth
+    cfg, path = tiny
+    g = tiny_gold
+    pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
+    steps = 9
+    a, ta, la = _run(str(tmp_path), cfg, path, ids, steps, pix, grid)
+    b, tb, lb = _run(str(tmp_path), cfg, path, ids, steps, pix, grid, env={"MLLM_HIP_NO_FUSE": "1"})
+    assert b["fused_launches"] == 0 and a["fused_launches"] >= (steps - 1) * cfg.layers * 5, (a, b)
+    assert a["fused_ops"] >= (steps - 1) * cfg.layers * 17 and a["hip_ops_run"] == b["hip_ops_run"], (a, b)
+    assert np.array_equal(la, g["logits"][:steps]) and np.array_equal(lb, g["logits"][:steps]) and ta.tolist() == tb.tolist() == g["tokens"][:steps].tolist()
 
 
 def test_reference_module_text_only_prompt(tiny, tiny_gold, tmp_path):

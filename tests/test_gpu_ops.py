@@ -532,7 +532,7 @@ def test_row_fused_linear_then_add(K, N):
     assert eq(out["y"][0], orc.linear(xa.reshape(1, K), W, orc.Q4_K, N).reshape(-1))
 
 
-@pytest.mark.parametrize("K,I", [(1536, 8960), (256, 48), (2048, 5632), (1024, 2816), (4096, 11008), (768, 4864), (512, 1030)])
+@pytest.mark.parametrize("K,I", [(1536, 8960), (256, 48), (2048, 5632), (1024, 2816), (4096, 11008), (768, 4864), (512, 1030), (512, 1280), (1280, 3840), (256, 35), (256, 40), (1536, 5)])
 def test_row_fused_norm_gate_silu_up_mul(K, I):
     """RMSNORM -> LINEAR gate -> SILU -> LINEAR up -> F_TTMUL (the MLP's first five Ops), with and without the F_TTADD in front."""
     r, (Wg, Wu), xa, xb, w = _rows_case(K, (I, I), K + I)
