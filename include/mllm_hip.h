@@ -253,6 +253,13 @@ int mllm_hip_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, const 
                  int64_t ldo, int Sq, int Sk, int Hq, int Hkv, int D, int causal, const int *sk_dev, void *workspace,
                  void *stream);
 size_t mllm_hip_fa2_workspace_bytes(int Sq, int Hq, int D, int max_sk);
+/* ONE decode position through the five Ops of the reference's attention block (models/qwen2_vl/modeling_qwen2_vl.hpp:254-262, models/transformer/modeling_transformer.hpp:169-184)
+ * in one launch: q_out = RoPE(q_raw), k_out = RoPE(k_raw) (rows of D / 2 sines / cosines of this position), row T of the fp16 slabs `[T + 1][Hkv * D]` = fp16(k_out), fp16(v_raw)
+ * (the two KVCache appends), O = F_FA2(q_out, keys 0 .. T).  mllm_hip_rope_apply's, mllm_hip_store_f16's and mllm_hip_fa2's (Sq = 1, fp16 K / V) arithmetic, element for
+ * element; D = 64 or 128.  _supported: 1 when a launch with these extents exists (host-side check). */
+int mllm_hip_fa2_decode_step(const float *q_raw, const float *sin_q, const float *cos_q, float *q_out, const float *k_raw, const float *sin_k, const float *cos_k, float *k_out,
+                             const float *v_raw, uint16_t *kslab, uint16_t *vslab, int T, float *O, int Hq, int Hkv, int D, void *stream);
+int mllm_hip_fa2_decode_step_supported(int T, int Hq, int Hkv, int D);
 /* nbatch independent attentions of one geometry in one launch (the images of a vision pass): set b uses q / k / v / o at element offsets b*bq / b*bk / b*bv / b*bo.
  * Same arithmetic as mllm_hip_fa2 per set; Sq >= 4. */
 int mllm_hip_fa2_batch(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *V, int64_t ldv, int kv_dtype, float *O,

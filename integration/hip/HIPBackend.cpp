@@ -129,10 +129,30 @@ void HIPBackend::drain_idle() {
     idle_bytes_ = 0;
 }
 // ---- the lazy window (see HIPBackend.hpp) ------------------------------------------------------------------------------------------------------------------------
+// The runs one launch covers, as strings over the Ops' kinds (N RMSNORM, L LINEAR, S SILU, M F_TTMUL, A F_TTADD, R ROPE, K KVCACHE append, F F_FA2).  The window only ever holds a
+// prefix of one of them: an Op that cannot extend the prefix sends it to the device first, an Op that completes a run nothing can extend sends the run at once.
+static const char *const kRuns[] = {"NLLL", "NLSLM", "ANLLL", "ANLSLM", "LA", "LLL", "RRKKF"};
+static char kind_char(HIPBackend::LazyOp::Kind k) { return "NLSMARKF"[(int)k]; }
+bool HIPBackend::window_extends(LazyOp::Kind k) const {
+    char w[16];
+    size_t n = 0;
+    for (const LazyOp &o : lazy_) w[n++] = kind_char(o.kind);
+    w[n++] = kind_char(k);
+    for (const char *run : kRuns)
+        if (strlen(run) >= n && strncmp(run, w, n) == 0) return true;
+    return false;
+}
 void HIPBackend::lazy(const LazyOp &op) {
     if (no_fuse_) { emit_single(op); return; }
+    if (!lazy_.empty() && (lazy_.size() >= 8 || !window_extends(op.kind))) flush_lazy();
     lazy_.push_back(op);
-    if (lazy_.size() >= 48) flush_lazy();      // a decode layer is 17; nothing the patterns below know is longer than 6
+    char w[16];
+    size_t n = 0;
+    for (const LazyOp &o : lazy_) w[n++] = kind_char(o.kind);
+    bool open = false;      // can anything still follow?
+    for (const char *run : kRuns)
+        if (strlen(run) > n && strncmp(run, w, n) == 0) open = true;
+    if (!open) flush_lazy();
 }
 void HIPBackend::flush_lazy() {
     if (flushing_) return;
@@ -155,6 +175,10 @@ void HIPBackend::emit_single(const LazyOp &o) {
     case LazyOp::ADD: defer("mllm_hip_add", mllm_hip_add, o.a, o.b, o.out, o.n, stream_); break;
     case LazyOp::ROPE: defer("mllm_hip_rope_apply", mllm_hip_rope_apply, o.a, (int64_t)o.H * o.D, o.sin, o.cos, o.ld_tab, (void *)o.out, (int)MLLM_HIP_F32, (int64_t)o.H * o.D, o.S, o.H, o.D, stream_); break;
     case LazyOp::KVSTORE: defer("mllm_hip_store_f16", mllm_hip_store_f16, o.a, (int64_t)o.n, o.dst16, (int64_t)o.n, o.S, (int)o.n, stream_); break;
+    case LazyOp::FA2:
+        defer("mllm_hip_fa2", mllm_hip_fa2, o.a, (int64_t)o.H * o.D, o.kp, (int64_t)o.Hkv * o.D, o.vp, (int64_t)o.Hkv * o.D, o.kvdt, o.out, (int64_t)o.H * o.D, 1, o.Sk, o.H, o.Hkv, o.D,
+              o.causal, (const int *)nullptr, (void *)nullptr, stream_);
+        break;
     }
     flushing_ = was;
 }
@@ -243,6 +267,29 @@ size_t HIPBackend::emit_group(size_t i) {
         for (; cnt >= 2; --cnt) {
             a.nseg = cnt;
             if (mllm_hip_row_fused_supported(&a) && safe(a)) return launch(a, cnt);
+        }
+    }
+    // ROPE(q), ROPE(k), KVCACHE(k) of the rotated k, KVCACHE(v), F_FA2 of one position over the slabs those appends extend: mllm_hip_fa2_decode_step
+    if (o.kind == LazyOp::ROPE && i + 4 < n && L[i + 1].kind == LazyOp::ROPE && L[i + 2].kind == LazyOp::KVSTORE && L[i + 3].kind == LazyOp::KVSTORE && L[i + 4].kind == LazyOp::FA2) {
+        const LazyOp &rq = o, &rk = L[i + 1], &sk = L[i + 2], &sv = L[i + 3], &fa = L[i + 4];
+        const int T = fa.Sk - 1, gsize = fa.Hkv ? fa.H / fa.Hkv : 0;
+        const size_t qb = (size_t)rq.H * rq.D * 4, kb = (size_t)rk.H * rk.D * 4;
+        // a workgroup per query head reads its head's slice of q, its group's slices of k and v, and writes its head's slices of q_out and O (the group's first: k_out and the
+        // slab rows).  A block the frontend has re-used for one of these outputs is harmless when the SAME workgroup owns the slice on both sides (the same base, and for k / v
+        // one head per group); anything else must not overlap.
+        auto apart = [](const void *p, size_t pn, const void *q, size_t qn) { return (const char *)p + pn <= (const char *)q || (const char *)q + qn <= (const char *)p; };
+        auto ok = [&](const void *out, size_t on, const void *in, size_t in_n, bool same_owner) { return apart(out, on, in, in_n) || (same_owner && out == in && on == in_n); };
+        const bool clear = ok(fa.out, qb, rq.a, qb, true) && ok(fa.out, qb, rk.a, kb, gsize == 1) && ok(fa.out, qb, sv.a, kb, gsize == 1) && ok(rq.out, qb, rq.a, qb, true) &&
+                           ok(rq.out, qb, rk.a, kb, gsize == 1) && ok(rq.out, qb, sv.a, kb, gsize == 1) && ok(rk.out, kb, rq.a, qb, gsize == 1) && ok(rk.out, kb, rk.a, kb, gsize == 1) &&
+                           ok(rk.out, kb, sv.a, kb, gsize == 1) && apart(fa.out, qb, rq.out, qb) && apart(fa.out, qb, rk.out, kb) && apart(rq.out, qb, rk.out, kb);
+        if (clear && rq.S == 1 && rk.S == 1 && sk.S == 1 && sv.S == 1 && rq.D == rk.D && rq.D == fa.D && rq.H == fa.H && rk.H == fa.Hkv && fa.kvdt == MLLM_HIP_F16 && fa.a == rq.out &&
+            sk.a == rk.out && sk.n == (int64_t)rk.H * rk.D && sv.n == sk.n && T >= 0 && sk.dst16 == (const uint16_t *)fa.kp + (size_t)T * sk.n &&
+            sv.dst16 == (const uint16_t *)fa.vp + (size_t)T * sv.n && mllm_hip_fa2_decode_step_supported(T, fa.H, fa.Hkv, fa.D)) {
+            defer("mllm_hip_fa2_decode_step", mllm_hip_fa2_decode_step, rq.a, rq.sin, rq.cos, rq.out, rk.a, rk.sin, rk.cos, rk.out, sv.a, (uint16_t *)fa.kp, (uint16_t *)fa.vp, T, fa.out,
+                  fa.H, fa.Hkv, fa.D, stream_);
+            ++fused_launches_;
+            fused_ops_ += 5;
+            return 5;
         }
     }
     // ROPE(q), ROPE(k), KVCACHE(k) of the rotated k, KVCACHE(v)

@@ -128,11 +128,12 @@ public:
     // A decode layer reaches this backend as 18 Ops on ONE activation row (RMSNORM, LINEAR q / k / v, ROPE x 2, KVCACHE x 2, F_FA2, LINEAR o, F_TTADD, RMSNORM, LINEAR gate, SILU,
     // LINEAR up, F_TTMUL, LINEAR down, F_TTADD), 17 launches of 2-5 us each -- the device, not the host, bounds the Op-by-Op path.  The Ops of that run do not launch: they describe
     // themselves (LazyOp) and the window emits, in program order, the longest runs the library has one launch for (mllm_hip_row_fused_launch, mllm_hip_rope2_store2) and everything
-    // else as the Op's own call.  A fused launch still writes EVERY Op's output tensor with the value that Op's own kernel computes, so nothing the frontend can observe changes;
+    // else as the Op's own call.  The window is emitted as soon as the next Op cannot extend the run it holds, or closes it (window_extends), so the device never waits for more than
+    // the six Ops of one run.  A fused launch still writes EVERY Op's output tensor with the value that Op's own kernel computes, so nothing the frontend can observe changes;
     // runs are contiguous, so the order of all device work is the program's.  Anything that is not a LazyOp (another Op's defer, an upload, a drain) flushes the window first.
     // MLLM_HIP_NO_FUSE=1 emits every Op on its own (A/B measurements).
     struct LazyOp {
-        enum Kind : int { NORM, LINEAR, SILU, MUL, ADD, ROPE, KVSTORE } kind;
+        enum Kind : int { NORM, LINEAR, SILU, MUL, ADD, ROPE, KVSTORE, FA2 } kind;
         const float *a = nullptr, *b = nullptr;      // inputs (b: second operand of ADD / MUL)
         float *out = nullptr;
         int64_t n = 0;                               // elements (SILU / MUL / ADD), row width (NORM, KVSTORE), out_features (LINEAR)
@@ -144,6 +145,8 @@ public:
         const float *sin = nullptr, *cos = nullptr;  // ROPE
         int ld_tab = 0, S = 0, H = 0, D = 0;
         uint16_t *dst16 = nullptr;                   // KVSTORE: the slab rows to append to
+        const void *kp = nullptr, *vp = nullptr;     // FA2 (one query row): K / V views [Sk][Hkv * D]; a = q, H = Hq
+        int Sk = 0, Hkv = 0, causal = 0, kvdt = 0;
     };
     void lazy(const LazyOp &op);
     void flush_lazy();
@@ -231,6 +234,7 @@ private:
     bool inline_launch_ = false, no_fuse_ = false, flushing_ = false;
     std::vector<LazyOp> lazy_;
     long fused_launches_ = 0, fused_ops_ = 0;
+    bool window_extends(LazyOp::Kind k) const;
     void emit_single(const LazyOp &op);
     size_t emit_group(size_t i);
     std::thread worker_;

@@ -416,6 +416,13 @@ public:
         const int Hq = q->head(), Hkv = k->head(), D = q->dimension();
         if (q->sequence() == 0) return MLLM_NO_ERROR;
         const int kvdt = k->dtype() == MLLM_TYPE_F16 ? MLLM_HIP_F16 : MLLM_HIP_F32;
+        if (q->sequence() == 1) {      // one position: the window may fold the rotary Ops and the cache appends in front of it into the launch (HIPBackend::lazy)
+            HIPBackend::LazyOp o;
+            o.kind = HIPBackend::LazyOp::FA2; o.a = (const float *)dptr(q); o.kp = dptr(k); o.vp = dptr(v); o.out = (float *)dptr(outputs[0]); o.H = Hq; o.Hkv = Hkv; o.D = D;
+            o.Sk = k->sequence(); o.causal = causal_ ? 1 : 0; o.kvdt = kvdt; o.S = 1;
+            hb()->lazy(o);
+            return MLLM_NO_ERROR;
+        }
         HIPQ(mllm_hip_fa2, (const float *)dptr(q), (int64_t)Hq * D, dptr(k), (int64_t)Hkv * D, dptr(v), (int64_t)Hkv * D, kvdt, (float *)dptr(outputs[0]), (int64_t)Hq * D, q->sequence(),
                             k->sequence(), Hq, Hkv, D, causal_ ? 1 : 0, nullptr, nullptr, hb()->stream());
         return MLLM_NO_ERROR;

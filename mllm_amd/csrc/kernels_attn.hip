@@ -332,6 +332,76 @@ __global__ __launch_bounds__(NT) void fa2_decode_kernel(const float *__restrict_
     fa2_decode_head<D, F16, NT, VT>(L, P, K, ldk, V, ldv, kvh * D, kvh * D, Sk, cap, nullptr, nullptr, -1);
     if (threadIdx.x < D) O[head * D + threadIdx.x] = L.ob[threadIdx.x];
 }
+// ONE decode position through the five Ops of the reference's attention block in one launch (mllm_hip_fa2_decode_step; integration/hip's lazy window): RoPE(q), RoPE(k), the
+// fp16 appends of the rotated k and of v to their cache slabs, and F_FA2 over the T + 1 keys.  A workgroup per query head rotates its q (and stores the RoPE Op's fp32 output),
+// rotates its group's k and rounds k / v to fp16 in LDS -- the first head of a group also stores the RoPE Op's k output and the two slab rows -- and hands those LDS rows to
+// fa2_decode_head as key T, so no workgroup depends on another's stores.  rope_apply_kernel's, store_f16's and fa2_decode_kernel's arithmetic, element for element.
+struct AttnStep {
+    const float *q_raw, *k_raw, *v_raw, *sin_q, *cos_q, *sin_k, *cos_k;
+    float *q_out, *k_out, *O;
+    uint16_t *kslab, *vslab;      // [T + 1][Hkv * D] fp16
+    int T, Hq, Hkv, nslots;
+};
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void fa2_decode_step_kernel(const AttnStep A) {
+    constexpr int HALF = D / 2;
+    extern __shared__ __attribute__((aligned(16))) char fa_smem[];
+    __shared__ __attribute__((aligned(16))) uint16_t knew[D];
+    __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
+    const int head = blockIdx.x, gsize = A.Hq / A.Hkv, kvh = head / gsize, tid = threadIdx.x, KVD = A.Hkv * D, cap = A.T + 1;
+    float qa = 0.0f, qb = 0.0f, sn = 0.0f, cs = 0.0f;
+    if (tid < HALF) { const float *qp = A.q_raw + head * D; qa = qp[tid]; qb = qp[tid + HALF]; sn = A.sin_q[tid]; cs = A.cos_q[tid]; }
+    else if (tid < D) { const float *kp = A.k_raw + kvh * D; qa = kp[tid - HALF]; qb = kp[tid]; sn = A.sin_k[tid - HALF]; cs = A.cos_k[tid - HALF]; }
+    else if (tid < 2 * D) qa = A.v_raw[kvh * D + (tid - D)];
+    __builtin_amdgcn_sched_barrier(0);
+    DecodePrefetch<D, true, NT, false> P;
+    fa2_decode_prefetch<D, true, NT, false>(P, A.kslab, KVD, A.vslab, KVD, kvh * D, cap, A.nslots);
+    __builtin_amdgcn_sched_barrier(0);
+    const DecodeLds L = carve_decode(fa_smem, cap, D, NT, A.nslots);
+    const bool writer = head == kvh * gsize;
+    if (tid < HALF) {
+        const float v1 = __fmaf_rn(qa, cs, -__fmul_rn(qb, sn)), v2 = __fmaf_rn(qa, sn, __fmul_rn(qb, cs));
+        L.qs[tid] = v1; L.qs[tid + HALF] = v2;
+        A.q_out[head * D + tid] = v1; A.q_out[head * D + tid + HALF] = v2;
+    } else if (tid < D) {
+        const float v1 = __fmaf_rn(qa, cs, -__fmul_rn(qb, sn)), v2 = __fmaf_rn(qa, sn, __fmul_rn(qb, cs));
+        knew[tid - HALF] = f2h(v1); knew[tid] = f2h(v2);
+        if (writer) { A.k_out[kvh * D + tid - HALF] = v1; A.k_out[kvh * D + tid] = v2; }
+    } else if (tid < 2 * D) {
+        vnew[tid - D] = f2h(qa);
+    }
+    __syncthreads();
+    if (writer && tid < D) {
+        A.kslab[(int64_t)A.T * KVD + kvh * D + tid] = knew[tid];
+        A.vslab[(int64_t)A.T * KVD + kvh * D + tid] = vnew[tid];
+    }
+    fa2_decode_head<D, true, NT, false>(L, P, A.kslab, KVD, A.vslab, KVD, kvh * D, kvh * D, cap, cap, knew, vnew, A.T);
+    if (tid < D) A.O[head * D + tid] = L.ob[tid];
+}
+template <int D>
+static int launch_fa2_step(AttnStep A, hipStream_t st, bool dry) {
+    constexpr int NT = 1024;
+    const int cap = A.T + 1;
+    A.nslots = decode_lds_slots(cap, D, NT, 2, false);
+    const size_t lds = decode_lds_bytes(cap, D, NT, 2, A.nslots, false);
+    if (lds > 160 * 1024) return MLLM_HIP_ERR_SHAPE;
+    if (dry) return MLLM_HIP_OK;
+    auto kern = fa2_decode_step_kernel<D, NT>;
+    if (lds > 48 * 1024) MH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(A.Hq), dim3(NT), lds, st, A);
+    return MH_LAUNCH_OK("fa2_decode_step");
+}
+static int fa2_step(const float *q_raw, const float *sin_q, const float *cos_q, float *q_out, const float *k_raw, const float *sin_k, const float *cos_k, float *k_out, const float *v_raw,
+                    uint16_t *kslab, uint16_t *vslab, int T, float *O, int Hq, int Hkv, int D, hipStream_t st, bool dry) {
+    if (T < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || (Hkv * D) % 8) return MLLM_HIP_ERR_SHAPE;
+    if (!dry && (!q_raw || !k_raw || !v_raw || !sin_q || !cos_q || !sin_k || !cos_k || !q_out || !k_out || !kslab || !vslab || !O)) return MLLM_HIP_ERR_ARG;
+    const AttnStep A{q_raw, k_raw, v_raw, sin_q, cos_q, sin_k, cos_k, q_out, k_out, O, kslab, vslab, T, Hq, Hkv, 0};
+    switch (D) {
+    case 64: return launch_fa2_step<64>(A, st, dry);
+    case 128: return launch_fa2_step<128>(A, st, dry);
+    default: return MLLM_HIP_ERR_SHAPE;
+    }
+}
 // the same for B sequences in one launch (batched decode): blockIdx.y = sequence, whose slabs and key count come from its descriptor; fp16 K rows, transposed fp16 V
 template <int D, int NT>
 __global__ __launch_bounds__(NT) void fa2_decode_seqs_kernel(const float *__restrict__ Q, int64_t ldq, const SeqKV *__restrict__ seqs, int64_t layer_k_off, int64_t layer_v_off,
@@ -375,6 +445,13 @@ int seqs_fa2_decode_launch(const float *q, int64_t ldq, const SeqKV *seqs_dev, i
 
 using namespace mllm_hip;
 
+extern "C" int mllm_hip_fa2_decode_step(const float *q_raw, const float *sin_q, const float *cos_q, float *q_out, const float *k_raw, const float *sin_k, const float *cos_k, float *k_out,
+                                        const float *v_raw, uint16_t *kslab, uint16_t *vslab, int T, float *O, int Hq, int Hkv, int D, void *stream) {
+    return fa2_step(q_raw, sin_q, cos_q, q_out, k_raw, sin_k, cos_k, k_out, v_raw, kslab, vslab, T, O, Hq, Hkv, D, as_stream(stream), false);
+}
+extern "C" int mllm_hip_fa2_decode_step_supported(int T, int Hq, int Hkv, int D) {
+    return fa2_step(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, T, nullptr, Hq, Hkv, D, nullptr, true) == MLLM_HIP_OK ? 1 : 0;
+}
 extern "C" size_t mllm_hip_fa2_workspace_bytes(int Sq, int Hq, int D, int max_sk) {
     (void)Sq; (void)Hq; (void)D; (void)max_sk;
     return 256;   // the kernels keep their state in LDS; a token allocation keeps callers' bookkeeping uniform

@@ -482,3 +482,14 @@ def rope2_store2(q, k, v, S, Hq, Hkv, D, sin_q, cos_q, sin_k, cos_k):
     check(L.load().mllm_hip_rope2_store2(vp(q), vp(sq), vp(cq), C.c_int(sq.shape[-1]), vp(qo), C.c_int(Hq), vp(k), vp(sk), vp(ck), C.c_int(sk.shape[-1]), vp(ko), vp(k16), vp(v),
                                          vp(v16), C.c_int(Hkv), C.c_int(S), C.c_int(D), _stream()), "rope2_store2")
     return qo, ko, k16, v16
+
+
+def fa2_decode_step(q_raw, k_raw, v_raw, kslab, vslab, T, Hq, Hkv, D, sin_q, cos_q, sin_k, cos_k):
+    """mllm_hip_fa2_decode_step: slabs fp16 `[>= T + 1][Hkv * D]` (modified in place: row T).  Returns (q_out, k_out, O)."""
+    q, k, v = _dev(q_raw, torch.float32), _dev(k_raw, torch.float32), _dev(v_raw, torch.float32)
+    sq, cq, sk, ck = (_dev(t, torch.float32) for t in (sin_q, cos_q, sin_k, cos_k))
+    qo, ko = torch.empty_like(q), torch.empty_like(k)
+    o = torch.empty((Hq * D,), dtype=torch.float32, device="cuda")
+    check(L.load().mllm_hip_fa2_decode_step(vp(q), vp(sq), vp(cq), vp(qo), vp(k), vp(sk), vp(ck), vp(ko), vp(v), vp(kslab), vp(vslab), C.c_int(T), vp(o), C.c_int(Hq), C.c_int(Hkv),
+                                            C.c_int(D), _stream()), "fa2_decode_step")
+    return qo, ko, o

@@ -134,6 +134,15 @@ int mllm_hip_rope2_store2(const float *q, const float *sq, const float *cq, int 
     rd(v, (size_t)S * Hkv * D * 4); wr(v16, (size_t)S * Hkv * D * 2);
     return 0;
 }
+int mllm_hip_fa2_decode_step(const float *q, const float *sq, const float *cq, float *qo, const float *k, const float *sk, const float *ck, float *ko, const float *v, uint16_t *ks,
+                             uint16_t *vs, int T, float *O, int Hq, int Hkv, int D, void *) {
+    if (!mllm_hip_fa2_decode_step_supported(T, Hq, Hkv, D)) { fprintf(stderr, "mock: fa2_decode_step launched with extents the library refuses\n"); abort(); }
+    rd(q, (size_t)Hq * D * 4); rd(sq, D / 2 * 4); rd(cq, D / 2 * 4); rd(k, (size_t)Hkv * D * 4); rd(sk, D / 2 * 4); rd(ck, D / 2 * 4); rd(v, (size_t)Hkv * D * 4);
+    rd(ks, (size_t)T * Hkv * D * 2); rd(vs, (size_t)T * Hkv * D * 2);
+    wr(qo, (size_t)Hq * D * 4); wr(ko, (size_t)Hkv * D * 4); wr(ks + (size_t)T * Hkv * D, (size_t)Hkv * D * 2); wr(vs + (size_t)T * Hkv * D, (size_t)Hkv * D * 2);
+    wr(O, (size_t)Hq * D * 4);
+    return 0;
+}
 int mllm_hip_store_f16(const float *x, int64_t ldx, uint16_t *out, int64_t ldo, int S, int n, void *) { rd2(x, ldx, S, n, 4); wr2(out, ldo, S, n, 2); return 0; }
 int mllm_hip_fa2(const float *Q, int64_t ldq, const void *K, int64_t ldk, const void *V, int64_t ldv, int kvdt, float *O, int64_t ldo, int Sq, int Sk, int Hq, int Hkv, int D, int, const int *, void *, void *) {
     rd2(Q, ldq, Sq, (int64_t)Hq * D, 4); rd2(K, ldk, Sk, (int64_t)Hkv * D, esz(kvdt)); rd2(V, ldv, Sk, (int64_t)Hkv * D, esz(kvdt)); wr2(O, ldo, Sq, (int64_t)Hq * D, 4);

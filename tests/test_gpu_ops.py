@@ -574,3 +574,29 @@ def test_rope2_store2_equals_the_four_ops(S, Hq, Hkv, D):
     assert eq(k16.view(torch.int16), kw.to(torch.float16).view(torch.int16).cpu().numpy())
     assert eq(k16.view(torch.int16), ops.rope_apply(k, S, Hkv, D, sk, ck, out_f16=True).view(torch.int16).cpu().numpy())
     assert eq(v16.view(torch.int16), torch.from_numpy(v).to(torch.float16).view(torch.int16).numpy())
+
+
+@pytest.mark.parametrize("T,Hq,Hkv,D", [(0, 4, 2, 64), (1, 12, 2, 128), (305, 12, 2, 128), (127, 16, 16, 64), (128, 32, 32, 128), (640, 14, 2, 64), (799, 12, 2, 128), (1500, 32, 4, 64)])
+def test_fa2_decode_step_equals_the_five_ops(T, Hq, Hkv, D):
+    """RoPE(q), RoPE(k), the two fp16 cache appends and F_FA2 of one decode position in one launch = the five entry points one after the other, output for output, bit for bit
+    (T = keys already in the cache: 0, across the 128-key V chunks, the 512-key score pass and the three-slot ring)."""
+    r = rng(T + Hq + D)
+    q = r.standard_normal(Hq * D).astype(np.float32)
+    k = r.standard_normal(Hkv * D).astype(np.float32)
+    v = r.standard_normal(Hkv * D).astype(np.float32)
+    ang = r.standard_normal(D // 2).astype(np.float32)
+    sq, cq = np.sin(ang).astype(np.float32), np.cos(ang).astype(np.float32)
+    sk, ck = np.sin(ang * 0.5).astype(np.float32), np.cos(ang * 0.5).astype(np.float32)
+    past_k = torch.from_numpy(r.standard_normal((T + 1, Hkv * D)).astype(np.float32)).to(torch.float16).cuda()
+    past_v = torch.from_numpy(r.standard_normal((T + 1, Hkv * D)).astype(np.float32)).to(torch.float16).cuda()
+    ks, vs = past_k.clone(), past_v.clone()
+    qo, ko, o = ops.fa2_decode_step(q, k, v, ks, vs, T, Hq, Hkv, D, sq, cq, sk, ck)
+    q_want = ops.rope_apply(q.reshape(1, -1), 1, Hq, D, sq.reshape(1, -1), cq.reshape(1, -1))
+    k_want = ops.rope_apply(k.reshape(1, -1), 1, Hkv, D, sk.reshape(1, -1), ck.reshape(1, -1))
+    kw, vw = past_k.clone(), past_v.clone()
+    kw[T] = k_want.reshape(-1).to(torch.float16)
+    vw[T] = torch.from_numpy(v).to(torch.float16).cuda()
+    o_want = ops.flash_attention2(q_want, kw, vw, 1, T + 1, Hq, Hkv, D, True)
+    assert eq(qo, q_want.reshape(-1).cpu().numpy()) and eq(ko, k_want.reshape(-1).cpu().numpy())
+    assert eq(ks.view(torch.int16), kw.view(torch.int16).cpu().numpy()) and eq(vs.view(torch.int16), vw.view(torch.int16).cpu().numpy())
+    assert eq(o, o_want.reshape(-1).cpu().numpy()), md(o, o_want.reshape(-1).cpu().numpy())
