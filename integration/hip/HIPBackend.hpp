@@ -111,9 +111,10 @@ public:
     void defer(const char *what, Fn fn, A... args) {
         if (!lazy_.empty() && !flushing_) flush_lazy();      // program order: what the window still holds goes first
         // the call travels as plain bytes inside its ring slot (function pointer + the argument tuple): no allocation on this thread, nothing to free on the worker's
-        if (inline_launch_) { check(fn(args...), what); return; }      // MLLM_HIP_INLINE_LAUNCH=1: the caller's thread launches (A/B measurements, debugging)
+        if (inline_launch_) { ++deferred_calls_; check(fn(args...), what); return; }      // MLLM_HIP_INLINE_LAUNCH=1: the caller's thread launches (A/B measurements, debugging)
         using Tup = std::tuple<A...>;
         static_assert(sizeof(Tup) <= sizeof(Deferred::args) && std::is_trivially_destructible<Tup>::value, "deferred C-ABI calls carry pointers and integers only");
+        ++deferred_calls_;
         Deferred &d = claim_slot();
         new (d.args) Tup(args...);
         d.fn = reinterpret_cast<void (*)()>(fn);
@@ -152,6 +153,7 @@ public:
     void flush_lazy();
     long fused_launches() const { return fused_launches_; }
     long fused_ops() const { return fused_ops_; }
+    long deferred_calls() const { return deferred_calls_; }      // C-ABI calls handed to the worker so far (what the window's unit test counts)
 
     // ---- reference-counted device blocks (fact 1) ----
     void *dev_alloc(size_t bytes);                   // Op-owned memory (weights' repacks, KV slabs, tables): one reference, dropped by dev_release
@@ -233,7 +235,7 @@ private:
     std::atomic<bool> stop_{false}, failed_{false};
     bool inline_launch_ = false, no_fuse_ = false, flushing_ = false;
     std::vector<LazyOp> lazy_;
-    long fused_launches_ = 0, fused_ops_ = 0;
+    long fused_launches_ = 0, fused_ops_ = 0, deferred_calls_ = 0;
     bool window_extends(LazyOp::Kind k) const;
     void emit_single(const LazyOp &op);
     size_t emit_group(size_t i);

@@ -130,3 +130,29 @@ def test_integration_doc_lists_every_registered_creator():
         if fn in ("mllm_hip_last_error", "mllm_hip_sync"):
             continue
         assert fn in doc, f"{fn} is called by the adapter but INTEGRATION.md does not mention it"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not present (GPU box)")
+def test_lazy_window_runs_and_aliasing_rule_on_the_null_device():
+    """The adapter's lazy window (HIPBackend::lazy / emit_group, INTEGRATION 4c) against hand-made runs of Ops (oracle/ref_drivers/ref_hip_window.cpp on the null device, under
+    AddressSanitizer): the runs it folds into one launch, and -- the part a race would hide in -- the aliasing patterns the frontend's block re-use produces: an output may share
+    memory with an input of the same launch only where one workgroup owns the slice on both sides; otherwise the run goes out Op by Op, in program order."""
+    import json
+
+    from mllm_amd import build as b
+    b.build()
+    subprocess.run(["make", "-f", "oracle/Makefile.ref", "-j8", "mock"], cwd=ROOT, check=True, capture_output=True, timeout=1500)
+    out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "mock_hip_window")], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert out.returncode == 0 and "AddressSanitizer" not in out.stderr, (out.returncode, out.stderr[-3000:])
+    got = {r["name"]: (r["calls"], r["fused_launches"], r["fused_ops"]) for r in json.loads(out.stdout.strip().splitlines()[-1])}
+    want = {
+        "NLLL": (1, 1, 4), "LA": (1, 1, 2), "LA_other_order": (1, 1, 2), "NLSLM": (1, 1, 5), "ANLLL": (1, 1, 5), "RRKKF_gqa": (1, 1, 5), "RRKKF_mha": (1, 1, 5),
+        "NLSLM_up_reuses_gate_block": (1, 1, 5),            # outputs that alias each other: written by one thread in the Ops' order
+        "RRKKF_out_over_q_gqa": (1, 1, 5), "RRKKF_out_over_q_mha": (1, 1, 5), "RRKKF_krot_over_q_mha": (1, 1, 5),      # the same workgroup owns the slice on both sides
+        "NLLL_output_over_input": (2, 1, 3),                # the norm alone, then q | k | v on its output (the aliased block is no input of THAT launch)
+        "LA_sum_over_input_row": (2, 0, 0),                 # other workgroups still read the row
+        "ANLLL_norm_output_over_add_operand": (2, 1, 4),    # the add alone, then norm + q | k | v (LLaVA-7B's case)
+        "RRKKF_krot_over_q_gqa": (5, 0, 0),                 # six query heads per group read what one workgroup would overwrite
+        "NLSLM_broken_chain": (4, 1, 2), "L_unfusable_then_A": (2, 0, 0), "RRKKF_wrong_row_gqa": (2, 1, 4), "RRKKF_wrong_row_mha": (2, 1, 4), "flush_before_other": (2, 0, 0),
+    }
+    assert got == want, {k: (got.get(k), want[k]) for k in want if got.get(k) != want[k]}
