@@ -513,8 +513,8 @@ std::vector<Tensor> HIPBackend::runLayer(Layer *, std::vector<Tensor>, int) { th
 
 #ifdef HIP_ADAPTER_TIMING
 #include <x86intrin.h>
-static unsigned long long g_t_runop = 0, g_t_ops = 0, g_t_wrap = 0, g_n = 0;
-struct TimingDump { ~TimingDump() { fprintf(stderr, "[adapter timing] runOp calls %llu: total %.1f Mcyc, reshape+setUp+execute %.1f Mcyc, shell construction %.1f Mcyc\n", g_n, g_t_runop / 1e6, g_t_ops / 1e6, g_t_wrap / 1e6); } } g_timing_dump;
+static unsigned long long g_t_runop = 0, g_t_ops = 0, g_t_wrap = 0, g_n = 0, g_t_reshape = 0, g_t_setup = 0, g_t_exec = 0, g_t_tail = 0;
+struct TimingDump { ~TimingDump() { fprintf(stderr, "[adapter timing] runOp calls %llu: total %.1f Mcyc, reshape+setUp+execute %.1f Mcyc (reshape %.1f, setUp %.1f, execute %.1f), shell construction %.1f Mcyc, tail %.1f Mcyc\n", g_n, g_t_runop / 1e6, g_t_ops / 1e6, g_t_reshape / 1e6, g_t_setup / 1e6, g_t_exec / 1e6, g_t_wrap / 1e6, g_t_tail / 1e6); } } g_timing_dump;
 #define TSC() __rdtsc()
 #else
 #define TSC() 0ull
@@ -570,7 +570,9 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
     }
     const unsigned long long t_a = TSC();
     op->reshape(input_tensors, out_tensors);
+    const unsigned long long t_r = TSC();
     op->setUp(input_tensors, out_tensors);
+    const unsigned long long t_s = TSC();
     op->execute(input_tensors, out_tensors);
     const unsigned long long t_b = TSC();
     ++ops_run_;
@@ -583,8 +585,9 @@ std::vector<Tensor> HIPBackend::runOp(Op *op, std::vector<Tensor> inputs, std::v
     for (const auto &out_tensor : out_tensors) results.push_back(*out_tensor);
 #ifdef HIP_ADAPTER_TIMING
     g_t_ops += t_b - t_a; g_t_wrap += t_a - t_in; g_t_runop += TSC() - t_in; ++g_n;
+    g_t_reshape += t_r - t_a; g_t_setup += t_s - t_r; g_t_exec += t_b - t_s; g_t_tail += TSC() - t_b;
 #endif
-    (void)t_in; (void)t_a; (void)t_b;
+    (void)t_in; (void)t_a; (void)t_b; (void)t_r; (void)t_s;
     return results;
 }
 
