@@ -10,7 +10,7 @@ struct DecodeState {
     int T;      // tokens already in the KV slab before this step
     int step;   // decode step since the prefill (row of the rotary tables)
     int token;  // token id to embed at this step
-    int pad;
+    int serial; // steps since the state was armed: the epoch of the in-launch hand-offs (merged attention + o-projection launch)
 };
 
 struct DecodeLayer {
@@ -45,6 +45,11 @@ struct DecodeCtx {
     int vt_ld;
     int n_layers;                       // entries of the DecodeLayer array handed to the launchers
     const WeightWarm *warm_tab;         // device, [n_layers] (decode_warm_table), or nullptr: no warming workgroups in the attention launch
+    // merged attention + o-projection launch (option "merge_o"): the attention's output row travels as {value, epoch} pairs, one row per layer, epoch = DecodeState::serial;
+    // the o-projection's workgroups ride in the attention's launch, fetch their weight rows at once and poll the pairs (profiles/r04_seam_overlap_microbench.md)
+    unsigned long long *attn_pairs;     // [n_layers][heads * D], all-ones when the state is armed
+    int *poll_err;                      // set when a poll gave up (bounded spins): the step's results are then invalid and the host reports it
+    int merge_o;
     int attn_flags;                     // decode_attn_flags() as it stood when the model was created: the warming table was built for these, and every launch of this
                                         // model uses them (option "attn_flags" must be set before mllm_hip_model_create; a later change does not reach a live model)
 };

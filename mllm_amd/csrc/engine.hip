@@ -206,6 +206,9 @@ struct mllm_hip_model {
     float *pin_img = nullptr; size_t pin_img_bytes = 0;
     // fused decode path (kernels_decode.hip): device-side step state, per-step rotary rows, captured graph
     DecodeState *d_state = nullptr;
+    unsigned long long *attn_pairs = nullptr;      // merged attention + o-projection launch: the attention's output rows as {value, epoch} pairs, [layers][heads * D]
+    int *poll_err = nullptr;
+    int *pin_err = nullptr;                        // page-locked word the flag is copied to with the step's other results
     float *dec_sin = nullptr, *dec_cos = nullptr, *part_val = nullptr, *cur_sin = nullptr, *cur_cos = nullptr;
     int *part_idx = nullptr, *history = nullptr;
     int nsplit = 0, max_parts = 4096, dec_rows = 0;
@@ -453,6 +456,9 @@ static int create_impl(M *m, const MllmFile &f) {
         EH(m->dalloc((uint8_t **)&m->fa_ws, wsb));
     }
     EH(m->dalloc(&m->d_state, sizeof(DecodeState)));
+    EH(m->dalloc(&m->attn_pairs, (size_t)c.layers * m->HD * 8)); EH(m->dalloc(&m->poll_err, 4));
+    HH(hipMemsetAsync(m->attn_pairs, 0xFF, (size_t)c.layers * m->HD * 8, m->st)); HH(hipMemsetAsync(m->poll_err, 0, 4, m->st));
+    HH(hipHostMalloc((void **)&m->pin_err, 4)); *m->pin_err = 0;
     EH(m->dalloc(&m->dec_sin, (size_t)T * (m->D / 2) * 4)); EH(m->dalloc(&m->dec_cos, (size_t)T * (m->D / 2) * 4));
     EH(m->dalloc(&m->cur_sin, (size_t)m->D * 4)); EH(m->dalloc(&m->cur_cos, (size_t)m->D * 4));
     EH(m->dalloc(&m->part_val, (size_t)m->max_parts * 4)); EH(m->dalloc(&m->part_idx, (size_t)m->max_parts * 4));
@@ -464,6 +470,7 @@ static int create_impl(M *m, const MllmFile &f) {
         d.Whead = (const uint8_t *)m->head.wd;
         d.x0 = m->h0; d.x1 = m->h1; d.qkv = m->qkv; d.act = m->act; d.logits = m->logits; d.fa_ws = (float *)m->fa_ws; d.part_val = m->part_val;
         d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos; d.cur_sin = m->cur_sin; d.cur_cos = m->cur_cos;
+        d.attn_pairs = m->attn_pairs; d.poll_err = m->poll_err; d.merge_o = option(OPT_MERGE_O) == 0 ? 0 : 1;      // default on; option "merge_o" = 0 keeps the two launches      // as it stood when the model was created (the captured graph holds the choice)
         d.kslab = m->kslab; d.vslab = m->vslab; d.vt_ld = m->vt_ld; d.n_layers = c.layers; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
         for (auto &L : m->layers) {
             DecodeLayer dl;
@@ -582,6 +589,7 @@ extern "C" void mllm_hip_model_destroy(mllm_hip_model *m) {
     m->ld.destroy();
     for (int b = 0; b < 2; ++b) { if (m->vup[b]) (void)hipEventDestroy(m->vup[b]); if (m->vfree[b]) (void)hipEventDestroy(m->vfree[b]); }
     if (m->pin_tok) (void)hipHostFree(m->pin_tok);
+    if (m->pin_err) (void)hipHostFree(m->pin_err);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->st) (void)hipStreamDestroy(m->st);
@@ -913,7 +921,14 @@ static int finish(M *m, float *logits_host, int32_t *next_token, float *elapsed_
     // the copies ride the stream behind the step and ONE synchronisation covers the step and both of them
     if (logits_host) HH(hipMemcpyAsync(logits_host, m->logits, (size_t)m->c.vocab * 4, hipMemcpyDeviceToHost, m->st));
     if (next_token) HH(hipMemcpyAsync(m->pin_tok + 1, m->tok_dev, 4, hipMemcpyDeviceToHost, m->st));
+    if (m->dctx.merge_o) HH(hipMemcpyAsync(m->pin_err, m->poll_err, 4, hipMemcpyDeviceToHost, m->st));
     HH(hipStreamSynchronize(m->st));
+    if (m->dctx.merge_o && *m->pin_err) {      // a polled hand-off inside a merged launch gave up: the results of the step(s) are not valid
+        *m->pin_err = 0;
+        HH(hipMemset(m->poll_err, 0, 4));
+        set_error_msg("a merged decode launch timed out waiting for its producer workgroups (option merge_o)");
+        return MLLM_HIP_ERR_ARG;
+    }
     if (next_token) *next_token = m->pin_tok[1];
     if (elapsed_ms) HH(hipEventElapsedTime(elapsed_ms, m->ev0, m->ev1));
     return 0;
@@ -997,6 +1012,7 @@ static int arm_decode(M *m) {
     HH(hipMemcpy(&tok, m->tok_dev, 4, hipMemcpyDeviceToHost));
     DecodeState st0 = {m->cache_len, 0, tok, 0};
     HH(hipMemcpy(m->d_state, &st0, sizeof(st0), hipMemcpyHostToDevice));
+    if (m->dctx.merge_o) HH(hipMemset(m->attn_pairs, 0xFF, (size_t)m->c.layers * m->HD * 8));      // no pair of an earlier run may carry an epoch this run will count up to      // no pair of an earlier run may carry an epoch this run will count up to
     return 0;
 }
 

@@ -755,32 +755,61 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
 // ------------------------------------------------------------------------------------------------------------------------
 // dec_down / dec_oproj: fp32 activation row (act, or the attention output row) -> Q8_K -> W rows + residual -> y
 // ------------------------------------------------------------------------------------------------------------------------
-template <int NSTEPS, int ROWS, int WPB>
-__global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const float *__restrict__ xin, const uint8_t *__restrict__ W, const float *__restrict__ residual,
-                                                            float *__restrict__ y, int N, int K) {
+// POLL (the merged attention + o-projection launch): the activation row arrives as {value, epoch} pairs written by workgroups of the SAME launch (agent-scope relaxed 64-bit
+// atomics, the data is the flag: profiles/r04_seam_overlap_microbench.md); this workgroup has its weight rows in flight before it starts to poll.  Spins are bounded: a time-out
+// sets *poll_err and the workgroup goes on with what it has (the host reports the step as failed).
+template <int NSTEPS, int ROWS, int WPB, bool POLL>
+__device__ __forceinline__ void dec_proj_body(const float *__restrict__ xin, const unsigned long long *__restrict__ xpairs, unsigned epoch, int *__restrict__ poll_err, int wg,
+                                              const uint8_t *__restrict__ W, const float *__restrict__ residual, float *__restrict__ y, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ActLds a = carve_act(smem, K);
     constexpr int NQ = (NSTEPS * 8 + WPB - 1) / WPB;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wave = blockIdx.x * WPB + wid, nb = K >> 8;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wave = wg * WPB + wid, nb = K >> 8;
     int rows[ROWS];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) rows[rr] = min(wave * ROWS + rr, N - 1);
     RowLoads<NSTEPS, ROWS> L;
     STAMP(0);
     float4 v[NQ];
+    if constexpr (POLL) {
+        static_assert(NSTEPS == 1, "the polled form issues its rows first: short rows only");
+        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const int blk = wid + WPB * i;
-        v[i] = blk < nb ? *reinterpret_cast<const float4 *>(xin + blk * 256 + lane * 4) : make_float4(0, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < NQ; ++i) {
+            const int blk = wid + WPB * i;
+            v[i] = make_float4(0, 0, 0, 0);
+            if (blk < nb) {
+                const unsigned long long *p = xpairs + blk * 256 + lane * 4;
+                unsigned long long e0, e1, e2, e3;
+                int polls = 0;
+                for (;;) {
+                    e0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); e1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    e2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); e3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = (unsigned)(e0 >> 32) == epoch && (unsigned)(e1 >> 32) == epoch && (unsigned)(e2 >> 32) == epoch && (unsigned)(e3 >> 32) == epoch;
+                    if (ok) break;
+                    if (++polls > (1 << 18)) { __hip_atomic_store(poll_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                v[i] = make_float4(__uint_as_float((unsigned)e0), __uint_as_float((unsigned)e1), __uint_as_float((unsigned)e2), __uint_as_float((unsigned)e3));
+            }
+        }
+        wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int blk = wid + WPB * i;
+            v[i] = blk < nb ? *reinterpret_cast<const float4 *>(xin + blk * 256 + lane * 4) : make_float4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #if MLLM_HIP_EARLY_ROWS
-    // short rows (o-proj: 1.3 MB of weights in all): the rows go out right behind the activation loads and fly underneath the
-    // quantisation -- the burst is too small to hold the activation row up, unlike the 15 MB of gate|up
-    if (NSTEPS == 1) { issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane); __builtin_amdgcn_sched_barrier(0); }
+        // short rows (o-proj: 1.3 MB of weights in all): the rows go out right behind the activation loads and fly underneath the
+        // quantisation -- the burst is too small to hold the activation row up, unlike the 15 MB of gate|up
+        if (NSTEPS == 1) { issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane); __builtin_amdgcn_sched_barrier(0); }
 #endif
-    wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
-    if (!(MLLM_HIP_EARLY_ROWS && NSTEPS == 1)) issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+        wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
+        if (!(MLLM_HIP_EARLY_ROWS && NSTEPS == 1)) issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+    }
     __syncthreads();
     STAMP(5);
     float out[ROWS];
@@ -793,6 +822,11 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const float *__restr
             if (rw < N) y[rw] = residual ? out[rr] + residual[rw] : out[rr];
         }
     }
+}
+template <int NSTEPS, int ROWS, int WPB>
+__global__ __launch_bounds__(64 * WPB) void dec_proj_kernel(const float *__restrict__ xin, const uint8_t *__restrict__ W, const float *__restrict__ residual,
+                                                            float *__restrict__ y, int N, int K) {
+    dec_proj_body<NSTEPS, ROWS, WPB, false>(xin, nullptr, 0u, nullptr, blockIdx.x, W, residual, y, N, K);
 }
 
 // dec_proj_blk: the down projection with one lane per super-block (blk_emit), a workgroup per RPW consecutive rows.  The rows (one
@@ -959,11 +993,13 @@ __device__ __forceinline__ void warm_weights(const WeightWarm *__restrict__ wt, 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-template <int D, int DS>
-__global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_pipe_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
-                                                                    const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
-                                                                    float *__restrict__ out, int Hq, int Hkv, int cache_limit, int vt_ld, int flags, int attn_groups,
-                                                                    const WeightWarm *__restrict__ ww) {
+// PAIRS (the merged attention + o-projection launch): the output row is stored as {value, DecodeState::serial} pairs for the o-projection workgroups of the same launch
+// to poll (dec_proj_body<.., POLL>); grid_attn = the workgroups of the launch that belong to the attention (the o-projection's come behind them)
+template <int D, int DS, bool PAIRS>
+__device__ __forceinline__ void dec_attn_pipe_body(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
+                                                   const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
+                                                   float *__restrict__ out, unsigned long long *__restrict__ out_pairs, int Hq, int Hkv, int cache_limit, int vt_ld, int flags,
+                                                   int attn_groups, const WeightWarm *__restrict__ ww, int grid_attn) {
     constexpr int HALF = D / 2, DV = D / DS, NWK = (DV + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint16_t knew[D];
@@ -976,7 +1012,7 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_pipe_kernel(const Decode
         // warming workgroups (only when the layer has a table): the extra ones behind the attention's grid, and -- on an XCD column no K/V head lives on -- the attention slots too
         const bool col_dead = col >= Hkv;
         if (ww && (idx >= attn_groups || col_dead)) {
-            const int ext = (int)(gridDim.x >> 3) - attn_groups;
+            const int ext = (grid_attn >> 3) - attn_groups;
             const int nw = ext + (col_dead ? attn_groups : 0), slot = idx >= attn_groups ? idx - attn_groups + (col_dead ? attn_groups : 0) : idx;
             warm_weights(ww, smem, col, slot, nw);
             return;
@@ -992,6 +1028,7 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_pipe_kernel(const Decode
     STAMPV(14, (unsigned long long)(__builtin_amdgcn_s_getreg(0x1814) & 15));      // HW_REG_XCC_ID of this workgroup (diagnostic build only)
     // the step's own small operands first (vmcnt retires in issue order), then -- speculatively, T only masks them afterwards -- the first-round block of every producer wave
     const int T_raw = state->T;
+    const unsigned serial = PAIRS ? (unsigned)state->serial : 0u;
     float qa = 0.0f, qb = 0.0f, sn = 0.0f, cs = 0.0f;
     if (tid < HALF) { const float *qp = qkv + head * D; qa = qp[tid]; qb = qp[tid + HALF]; sn = sin_t[tid]; cs = cos_t[tid]; }
     else if (tid < D) { const float *kp = qkv + HD + kvh * D; qa = kp[tid - HALF]; qb = kp[tid]; sn = sin_t[tid - HALF]; cs = cos_t[tid - HALF]; }
@@ -1034,9 +1071,36 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_pipe_kernel(const Decode
         vslab[(int64_t)(kvh * D + tid) * vt_ld + T] = vnew[tid];
     }
     fa2_decode_head_pipe<D, DV, DEC_PIPE_NT>(L, R, kslab, KVD, vslab, vt_ld, kvh * D, kvh * D + vdim0, Sk, cache_limit, knew, vnew + vdim0, T);
-    if (tid < DV) out[head * D + vdim0 + tid] = L.ob[tid];
+    if (tid < DV) {
+        if constexpr (PAIRS) __hip_atomic_store(out_pairs + head * D + vdim0 + tid, ((unsigned long long)serial << 32) | (unsigned long long)__float_as_uint(L.ob[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[head * D + vdim0 + tid] = L.ob[tid];
+    }
     STAMP(5);
 }
+template <int D, int DS>
+__global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_pipe_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
+                                                                    const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
+                                                                    float *__restrict__ out, int Hq, int Hkv, int cache_limit, int vt_ld, int flags, int attn_groups,
+                                                                    const WeightWarm *__restrict__ ww) {
+    dec_attn_pipe_body<D, DS, false>(state, qkv, sin_t, cos_t, kslab, vslab, out, nullptr, Hq, Hkv, cache_limit, vt_ld, flags, attn_groups, ww, (int)gridDim.x);
+}
+// The attention of a decode step and the o-projection behind it in ONE launch: workgroups [0, grid_attn) are the attention's (heads, dim halves, warmers), the rest the
+// o-projection's (dec_proj_kernel<1, 2, 8>'s body on the first 512 threads).  The latter are dispatched behind the former, issue their weight rows at once, and poll the
+// attention's output row -- {value, epoch} pairs -- instead of waiting for a kernel boundary: the launch, the row fetch and the weight stream of the projection run under the
+// attention (profiles/r04_seam_overlap_microbench.md: a polled hand-off costs 1.6 - 1.9 us at this workgroup count against the 2.2 us of a dependent launch's start).
+struct OProjRole { const uint8_t *W; const float *residual; float *y; unsigned long long *pairs; int *poll_err; int N, K, grid_attn; };
+template <int D, int DS>
+__global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_oproj_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
+                                                                     const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab, int Hq, int Hkv,
+                                                                     int cache_limit, int vt_ld, int flags, int attn_groups, const WeightWarm *__restrict__ ww, const OProjRole P) {
+    if ((int)blockIdx.x < P.grid_attn) {
+        dec_attn_pipe_body<D, DS, true>(state, qkv, sin_t, cos_t, kslab, vslab, nullptr, P.pairs, Hq, Hkv, cache_limit, vt_ld, flags, attn_groups, ww, P.grid_attn);
+        return;
+    }
+    if (threadIdx.x >= 512) return;      // the projection's body is an eight-wave workgroup
+    dec_proj_body<1, 2, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, (int)blockIdx.x - P.grid_attn, P.W, P.residual, P.y, P.N, P.K);
+}
+
 
 // ------------------------------------------------------------------------------------------------------------------------
 // dec_head: x -> RMSNorm -> Q8_0 -> tied lm_head rows (Q4_0 planes) -> logits, plus this workgroup's (max, first index)
@@ -1185,6 +1249,7 @@ __global__ __launch_bounds__(256) void dec_next_kernel(DecodeState *__restrict__
         state->token = besti;
         state->T += 1;
         state->step += 1;
+        state->serial += 1;
     }
 }
 #if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB) || defined(MLLM_HIP_STAMPS_PJB)
@@ -1597,6 +1662,15 @@ int decode_warm_table(const DecodeCtx &c, const DecodeLayer *layers, int n_layer
     return any;
 }
 
+// whether case 1 of decode_kernel_launch carries the o-projection (the same conditions as there)
+static bool decode_merges_o(const DecodeCtx &c) {
+    if (!c.merge_o || !c.attn_pairs || (c.attn_flags & 4) || c.cache_limit > 2048 || c.D != 128) return false;
+    const int ds_env = option(OPT_ATTN_DS) > 0 ? option(OPT_ATTN_DS) : 0;
+    if (!(ds_env == 0 || ds_env == 2)) return false;
+    if ((c.heads * c.D) > 2048 || (c.heads * c.D) % 256) return false;
+    constexpr int NP_ = DEC_PIPE_NT / 64 - ((128 / 2 + 63) / 64) - 1;
+    return std::max(pipe_lds_bytes<128, 64>(c.cache_limit, NP_), fused_lds_bytes<1, 2>(c.heads * c.D, false, 8)) <= 160 * 1024 - 2 * 128 * 2 - 64;
+}
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st) {
     if ((c.D != 128 && c.D != 64) || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
     float *x = c.x0, *t = c.x1;
@@ -1629,6 +1703,21 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         const int attn_groups = (int)grid.x / 8;
         const WeightWarm *ww = (flags & 1) && !(flags & 4) && c.warm_tab ? c.warm_tab + li : nullptr;
         // bit 2 of the flags (unset by default) keeps the un-pipelined kernel; caches beyond 2048 keys (more than 64 blocks: the carry is taken by one wave pass) stay on it too
+        // option "merge_o": the o-projection rides in the attention's launch (K <= 2048: the register form dec_proj_kernel<1, 2, 8>); case 2 below is then a no-op
+        if (decode_merges_o(c)) {
+            constexpr int NP_ = DEC_PIPE_NT / 64 - ((128 / 2 + 63) / 64) - 1;
+            const size_t plds = std::max(pipe_lds_bytes<128, 64>(c.cache_limit, NP_), fused_lds_bytes<1, 2>(c.heads * c.D, false, 8));
+            if (plds <= 160 * 1024 - 2 * 128 * 2 - 64) {
+                rc = allow_lds(dec_attn_oproj_kernel<128, 2>, plds);
+                if (rc) return rc;
+                const int grid_attn = (int)grid.x + (ww ? 8 * std::max(8, WeightWarm::GROUPS - attn_groups) : 0);
+                const int K = c.heads * c.D, waves = (c.H + 1) / 2;
+                const OProjRole P{L.Wo, x, t, c.attn_pairs + (size_t)li * K, c.poll_err, c.H, K, grid_attn};
+                hipLaunchKernelGGL((dec_attn_oproj_kernel<128, 2>), dim3(grid_attn + (waves + 7) / 8), dim3(DEC_PIPE_NT), plds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.heads,
+                                   c.kv_heads, c.cache_limit, c.vt_ld, flags, attn_groups, ww, P);
+                return MH_LAUNCH_OK("dec_attn_oproj");
+            }
+        }
         if (!(flags & 4) && c.cache_limit <= 2048 && (c.D == 128 || c.D == 64)) {
 #define DEC_PIPE_CASE(DD, DSV)                                                                                                                            \
     {                                                                                                                                                     \
@@ -1659,6 +1748,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         return MH_LAUNCH_OK("dec_attn");
     }
     case 2:
+        if (decode_merges_o(c)) return MLLM_HIP_OK;      // done inside the attention's launch 
         NS_DISPATCH(c.heads * c.D, rc = (launch_proj<NS>(L.Wo, L.Wo_raw, c.fa_ws, x, t, c.H, c.heads * c.D, st)));
         return rc;
     case 3:

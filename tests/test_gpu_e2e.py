@@ -140,6 +140,36 @@ def test_one_token_prompt_is_a_prefill(tiny_model):
     m.clear_kvcache()
 
 
+def test_merged_attention_and_o_projection_launch_changes_nothing(tiny_gold, tmp_path):
+    """The decode step's attention and o-projection share one launch by default (option merge_o: the projection's workgroups ride behind the attention's, fetch their rows at once and
+    poll the attention's output row, handed over as {value, epoch} pairs): ids and every logit of 24 steps equal the reference's golden run with the merge on and off, and a
+    second generation on the re-armed state (epochs start over) repeats the first."""
+    g = tiny_gold
+    cfg = synth.qwen2vl_tiny()
+    path = weights.qwen2vl_file(cfg, cache_dir=str(tmp_path))
+    pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
+    try:
+        for mode in (0, 1):
+            lib.set_option("merge_o", mode)
+            m = lib.Qwen2VL(cfg, path)
+            for _ in range(2):
+                m.clear_kvcache()
+                tok, logits, _ = m.prefill(ids, pix, grid)
+                toks, rows = [tok], [logits]
+                for s in range(1, len(g["tokens"])):
+                    tok, logits, _ = m.decode(tok)
+                    toks.append(tok)
+                    rows.append(logits)
+                assert toks == g["tokens"].tolist() and np.array_equal(np.stack(rows), g["logits"]), mode
+            m.clear_kvcache()
+            tok, _, _ = m.prefill(ids, pix, grid)
+            gen, _ = m.generate(tok, 20)
+            assert gen.tolist() == g["tokens"][1:21].tolist(), mode
+            m.close()
+    finally:
+        lib.set_option("merge_o", -1)
+
+
 def test_generate_equals_stepwise_decode_and_clear_kvcache_resets(tiny_model):
     cfg, m = tiny_model
     pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
