@@ -1337,9 +1337,11 @@ extern "C" int mllm_hip_model_time_kernel(mllm_hip_model *m, int which, int iter
     if (!m || !m->has_llm || iters <= 0) return MLLM_HIP_ERR_ARG;
     int nl = (int)m->layers.size();
     if (option(OPT_TIME_LAYERS) > 0) nl = std::max(1, std::min(nl, option(OPT_TIME_LAYERS)));   // fewer layers: an Infinity-Cache-warm stream
+    DecodeCtx alone = m->dctx;      // the kernels one at a time: the step's merged launch (attention + o-projection) is taken apart
+    alone.merge_o = 0;
     auto launch = [&](int i) -> int {
         auto &L = m->layers[i % nl];
-        if (which >= 10) return decode_kernel_launch(m->dctx, m->dlayers.data(), i % nl == 0 && which == 10 ? 1 % nl : i % nl, which - 10, m->st);
+        if (which >= 10) return decode_kernel_launch(alone, m->dlayers.data(), i % nl == 0 && which == 10 ? 1 % nl : i % nl, which - 10, m->st);
         const LinearW &w = which == 0 ? L.gu : (which == 1 ? L.down : (which == 2 ? L.qkv : L.o));
         const Q8Planes &x = which == 1 ? m->xq2 : m->xq;
         float *y = which == 0 ? m->gu : m->h1;
