@@ -470,7 +470,7 @@ static int create_impl(M *m, const MllmFile &f) {
         d.Whead = (const uint8_t *)m->head.wd;
         d.x0 = m->h0; d.x1 = m->h1; d.qkv = m->qkv; d.act = m->act; d.logits = m->logits; d.fa_ws = (float *)m->fa_ws; d.part_val = m->part_val;
         d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos; d.cur_sin = m->cur_sin; d.cur_cos = m->cur_cos;
-        d.attn_pairs = m->attn_pairs; d.poll_err = m->poll_err; d.merge_o = option(OPT_MERGE_O) == 0 ? 0 : 1;      // default on; option "merge_o" = 0 keeps the two launches      // as it stood when the model was created (the captured graph holds the choice)
+        d.attn_pairs = m->attn_pairs; d.poll_err = m->poll_err; d.merge_o = option(OPT_MERGE_O) == 0 ? 0 : (option(OPT_MERGE_O) == 1 ? 1 : 2);      // 2 (default): one row per wave of the projection role; 1: two (the stand-alone kernel's split)      // default on; option "merge_o" = 0 keeps the two launches      // as it stood when the model was created (the captured graph holds the choice)
         d.kslab = m->kslab; d.vslab = m->vslab; d.vt_ld = m->vt_ld; d.n_layers = c.layers; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
         for (auto &L : m->layers) {
             DecodeLayer dl;

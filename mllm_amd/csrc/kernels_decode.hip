@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_pipe_kernel(const Decode
 // o-projection's (dec_proj_kernel<1, 2, 8>'s body on the first 512 threads).  The latter are dispatched behind the former, issue their weight rows at once, and poll the
 // attention's output row -- {value, epoch} pairs -- instead of waiting for a kernel boundary: the launch, the row fetch and the weight stream of the projection run under the
 // attention (profiles/r04_seam_overlap_microbench.md: a polled hand-off costs 1.6 - 1.9 us at this workgroup count against the 2.2 us of a dependent launch's start).
-struct OProjRole { const uint8_t *W; const float *residual; float *y; unsigned long long *pairs; int *poll_err; int N, K, grid_attn; };
+struct OProjRole { const uint8_t *W; const float *residual; float *y; unsigned long long *pairs; int *poll_err; int N, K, grid_attn, rows; };
 template <int D, int DS>
 __global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_oproj_kernel(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
                                                                      const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab, int Hq, int Hkv,
@@ -1098,7 +1098,8 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_oproj_kernel(const Decod
         return;
     }
     if (threadIdx.x >= 512) return;      // the projection's body is an eight-wave workgroup
-    dec_proj_body<1, 2, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, (int)blockIdx.x - P.grid_attn, P.W, P.residual, P.y, P.N, P.K);
+    if (P.rows == 1) dec_proj_body<1, 1, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, (int)blockIdx.x - P.grid_attn, P.W, P.residual, P.y, P.N, P.K);
+    else dec_proj_body<1, 2, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, (int)blockIdx.x - P.grid_attn, P.W, P.residual, P.y, P.N, P.K);
 }
 
 
@@ -1711,8 +1712,9 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
                 rc = allow_lds(dec_attn_oproj_kernel<128, 2>, plds);
                 if (rc) return rc;
                 const int grid_attn = (int)grid.x + (ww ? 8 * std::max(8, WeightWarm::GROUPS - attn_groups) : 0);
-                const int K = c.heads * c.D, waves = (c.H + 1) / 2;
-                const OProjRole P{L.Wo, x, t, c.attn_pairs + (size_t)li * K, c.poll_err, c.H, K, grid_attn};
+                const int rows = c.merge_o == 2 ? 1 : 2;      // rows per wave of the projection role (1: twice the workgroups, on CUs the attention leaves idle anyway)
+                const int K = c.heads * c.D, waves = (c.H + rows - 1) / rows;
+                const OProjRole P{L.Wo, x, t, c.attn_pairs + (size_t)li * K, c.poll_err, c.H, K, grid_attn, rows};
                 hipLaunchKernelGGL((dec_attn_oproj_kernel<128, 2>), dim3(grid_attn + (waves + 7) / 8), dim3(DEC_PIPE_NT), plds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.heads,
                                    c.kv_heads, c.cache_limit, c.vt_ld, flags, attn_groups, ww, P);
                 return MH_LAUNCH_OK("dec_attn_oproj");

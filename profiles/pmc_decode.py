@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from mllm_amd import lib, synth  # noqa: E402
 from mllm_amd import synthfile as weights  # noqa: E402
 
+lib.set_option("merge_o", 0)      # the five kernels of a layer one by one (the step itself folds the o-projection into the attention's launch; the bytes are the same)
 cfg = synth.qwen2vl_2b()
 m = lib.Qwen2VL(cfg, weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache")))
 ids = (np.arange(40) * 7919 % 150000).astype(np.int32)
