@@ -57,6 +57,7 @@ struct DecodeCtx {
 // raw Q4_K rows -> decode order: the nibble dwords of every super-block transposed so that a lane's 16 bytes are one column class (q4k_dot.h)
 int decode_order_q4k(const void *src, void *dst, int64_t n_blocks, hipStream_t st);
 int decode_attn_flags();
+bool decode_merges_o(const DecodeCtx &c);      // the step folds the o-projection into the attention's launch (option merge_o and the shapes that form covers)
 int decode_warm_table(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, int flags, WeightWarm *host_out);
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st);
 int argmax_row_launch(const DecodeCtx &c, const float *logits, int n, int *out, hipStream_t st);      // first-maximum argmax over the chip, partials in c.part_val / c.part_idx

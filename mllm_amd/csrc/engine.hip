@@ -484,7 +484,8 @@ static int create_impl(M *m, const MllmFile &f) {
             const int fl = decode_attn_flags();
             d.attn_flags = fl;
             d.warm_tab = nullptr;
-            if ((fl & 1) && !(fl & 4) && decode_warm_table(d, m->dlayers.data(), (int)m->dlayers.size(), fl, tab.data()) > 0) {
+            // (the o-projection's rows need no warming when its workgroups ride in the attention's launch and fetch them there)
+            if ((fl & 1) && !(fl & 4) && decode_warm_table(d, m->dlayers.data(), (int)m->dlayers.size(), decode_merges_o(d) ? fl & ~64 : fl, tab.data()) > 0) {
                 WeightWarm *dev = nullptr;
                 EH(m->dalloc(&dev, tab.size() * sizeof(WeightWarm)));
                 HH(hipMemcpy(dev, tab.data(), tab.size() * sizeof(WeightWarm), hipMemcpyHostToDevice));

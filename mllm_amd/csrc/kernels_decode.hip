@@ -1664,7 +1664,7 @@ int decode_warm_table(const DecodeCtx &c, const DecodeLayer *layers, int n_layer
 }
 
 // whether case 1 of decode_kernel_launch carries the o-projection (the same conditions as there)
-static bool decode_merges_o(const DecodeCtx &c) {
+bool decode_merges_o(const DecodeCtx &c) {
     if (!c.merge_o || !c.attn_pairs || (c.attn_flags & 4) || c.cache_limit > 2048 || c.D != 128) return false;
     const int ds_env = option(OPT_ATTN_DS) > 0 ? option(OPT_ATTN_DS) : 0;
     if (!(ds_env == 0 || ds_env == 2)) return false;
