@@ -368,7 +368,7 @@ def main():
     tname, traffic = pmc_traffic()
     kernels = []
     for which, label, tkey in ((13, "dec_gateup (fused RMSNorm + Q8_K + gate|up Q4_K GEMV + SiLU*mul): the dominant HBM stream; timed alone here (cold rows) -- inside the step the attention launch has warmed the L2s with them", "dec_gateup"),
-                               (11, "dec_attn (rotary + KV append + exact-order attention over the cache; its idle workgroups request the layer's gate|up + o-projection rows early: the traffic figure is theirs): the time-dominant kernel", "dec_attn"),
+                               (11, "dec_attn (rotary + KV append + exact-order attention over the cache; its idle workgroups request the layer's gate|up (+ o-projection, when that runs as its own launch) rows early: the traffic figure is theirs; timed alone here -- in the step the o-projection's workgroups ride in this launch): the time-dominant kernel", "dec_attn"),
                                (14, "dec_down (Q8_K + down Q4_K GEMV + residual)", "dec_down")):
         ms_l, b_l = m.time_kernel(which, 280)
         ach = b_l / (ms_l * 1e-3) / 1e9
