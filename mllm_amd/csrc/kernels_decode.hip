@@ -1664,13 +1664,17 @@ int decode_warm_table(const DecodeCtx &c, const DecodeLayer *layers, int n_layer
 }
 
 // whether case 1 of decode_kernel_launch carries the o-projection (the same conditions as there)
+template <int D>
+static size_t merged_o_lds(const DecodeCtx &c) {
+    constexpr int NP_ = DEC_PIPE_NT / 64 - ((D / 2 + 63) / 64) - 1;
+    return std::max(pipe_lds_bytes<D, D / 2>(c.cache_limit, NP_), fused_lds_bytes<1, 2>(c.heads * c.D, false, 8));
+}
 bool decode_merges_o(const DecodeCtx &c) {
-    if (!c.merge_o || !c.attn_pairs || (c.attn_flags & 4) || c.cache_limit > 2048 || c.D != 128) return false;
+    if (!c.merge_o || !c.attn_pairs || (c.attn_flags & 4) || c.cache_limit > 2048 || (c.D != 128 && c.D != 64)) return false;
     const int ds_env = option(OPT_ATTN_DS) > 0 ? option(OPT_ATTN_DS) : 0;
     if (!(ds_env == 0 || ds_env == 2)) return false;
-    if ((c.heads * c.D) > 2048 || (c.heads * c.D) % 256) return false;
-    constexpr int NP_ = DEC_PIPE_NT / 64 - ((128 / 2 + 63) / 64) - 1;
-    return std::max(pipe_lds_bytes<128, 64>(c.cache_limit, NP_), fused_lds_bytes<1, 2>(c.heads * c.D, false, 8)) <= 160 * 1024 - 2 * 128 * 2 - 64;
+    if ((c.heads * c.D) > 2048 || (c.heads * c.D) % 256) return false;      // the projection's register form (dec_proj_kernel<1, ..>: rows of at most eight super-blocks)
+    return (c.D == 128 ? merged_o_lds<128>(c) : merged_o_lds<64>(c)) <= (size_t)(160 * 1024 - 2 * c.D * 2 - 64);
 }
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st) {
     if ((c.D != 128 && c.D != 64) || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
@@ -1706,19 +1710,21 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         // bit 2 of the flags (unset by default) keeps the un-pipelined kernel; caches beyond 2048 keys (more than 64 blocks: the carry is taken by one wave pass) stay on it too
         // option "merge_o": the o-projection rides in the attention's launch (K <= 2048: the register form dec_proj_kernel<1, 2, 8>); case 2 below is then a no-op
         if (decode_merges_o(c)) {
-            constexpr int NP_ = DEC_PIPE_NT / 64 - ((128 / 2 + 63) / 64) - 1;
-            const size_t plds = std::max(pipe_lds_bytes<128, 64>(c.cache_limit, NP_), fused_lds_bytes<1, 2>(c.heads * c.D, false, 8));
-            if (plds <= 160 * 1024 - 2 * 128 * 2 - 64) {
-                rc = allow_lds(dec_attn_oproj_kernel<128, 2>, plds);
-                if (rc) return rc;
-                const int grid_attn = (int)grid.x + (ww ? 8 * std::max(8, WeightWarm::GROUPS - attn_groups) : 0);
-                const int rows = c.merge_o == 2 ? 1 : 2;      // rows per wave of the projection role (1: twice the workgroups, on CUs the attention leaves idle anyway)
-                const int K = c.heads * c.D, waves = (c.H + rows - 1) / rows;
-                const OProjRole P{L.Wo, x, t, c.attn_pairs + (size_t)li * K, c.poll_err, c.H, K, grid_attn, rows};
-                hipLaunchKernelGGL((dec_attn_oproj_kernel<128, 2>), dim3(grid_attn + (waves + 7) / 8), dim3(DEC_PIPE_NT), plds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.heads,
-                                   c.kv_heads, c.cache_limit, c.vt_ld, flags, attn_groups, ww, P);
-                return MH_LAUNCH_OK("dec_attn_oproj");
-            }
+            const size_t plds = c.D == 128 ? merged_o_lds<128>(c) : merged_o_lds<64>(c);
+            const int grid_attn = (int)grid.x + (ww ? 8 * std::max(8, WeightWarm::GROUPS - attn_groups) : 0);
+            const int rows = c.merge_o == 2 ? 1 : 2;      // rows per wave of the projection role (1: twice the workgroups, on CUs the attention leaves idle anyway)
+            const int K = c.heads * c.D, waves = (c.H + rows - 1) / rows;
+            const OProjRole P{L.Wo, x, t, c.attn_pairs + (size_t)li * K, c.poll_err, c.H, K, grid_attn, rows};
+#define MERGED_O_CASE(DD)                                                                                                                                      \
+    {                                                                                                                                                         \
+        rc = allow_lds(dec_attn_oproj_kernel<DD, 2>, plds);                                                                                                   \
+        if (rc) return rc;                                                                                                                                    \
+        hipLaunchKernelGGL((dec_attn_oproj_kernel<DD, 2>), dim3(grid_attn + (waves + 7) / 8), dim3(DEC_PIPE_NT), plds, st, c.state, c.qkv, c.cur_sin, c.cur_cos, kl, vl, c.heads, \
+                           c.kv_heads, c.cache_limit, c.vt_ld, flags, attn_groups, ww, P);                                                                    \
+    }
+            if (c.D == 128) MERGED_O_CASE(128) else MERGED_O_CASE(64)
+#undef MERGED_O_CASE
+            return MH_LAUNCH_OK("dec_attn_oproj");
         }
         if (!(flags & 4) && c.cache_limit <= 2048 && (c.D == 128 || c.D == 64)) {
 #define DEC_PIPE_CASE(DD, DSV)                                                                                                                            \
