@@ -61,6 +61,17 @@ public:
     // execute() registers itself (F_WHERE).  runOp drops the host shadow of every other Op's output block, which the device has just overwritten.
     virtual bool keeps_shadow() const { return false; }
 
+    // The reference's Op entry points take their tensor lists BY VALUE (mllm/Op.hpp:39,61,88): three calls per Op, two vector copies each -- a malloc and an atomic increment
+    // per tensor, six times per Op, on the thread the whole frontend runs on.  The adapter's Ops implement the by-reference forms below; the by-value ones forward to them (a caller
+    // that only knows `Op` still works), and HIPBackend::runOp calls the by-reference forms directly.
+    using TL = const std::vector<std::shared_ptr<Tensor>> &;
+    virtual ErrorCode reshape_(TL inputs, TL outputs) = 0;
+    virtual ErrorCode setUp_(TL inputs, TL outputs) = 0;
+    virtual ErrorCode execute_(TL, TL) { return MLLM_NO_ERROR; }      // views: nothing to launch (what Op::execute does, mllm/Op.hpp:88-96)
+    ErrorCode reshape(std::vector<std::shared_ptr<Tensor>> inputs, std::vector<std::shared_ptr<Tensor>> outputs) final { return reshape_(inputs, outputs); }
+    ErrorCode setUp(std::vector<std::shared_ptr<Tensor>> inputs, std::vector<std::shared_ptr<Tensor>> outputs) final { return setUp_(inputs, outputs); }
+    ErrorCode execute(std::vector<std::shared_ptr<Tensor>> inputs, std::vector<std::shared_ptr<Tensor>> outputs) final { return execute_(inputs, outputs); }
+
 protected:
     HIPBackend *hb() const;
 };

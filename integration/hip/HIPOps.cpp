@@ -15,7 +15,8 @@ namespace mllm {
 
 namespace {
 
-using TensorList = vector<shared_ptr<Tensor>>;
+using TensorList = const vector<shared_ptr<Tensor>> &;      // HIPOp::reshape_ / setUp_ / execute_: by reference (HIPBackend.hpp)
+using TensorListV = vector<shared_ptr<Tensor>>;             // Op::free keeps the reference's by-value signature
 
 inline int geti(const OpParam &p, const char *k, int def = 0) { auto it = p.find(k); return it == p.end() ? def : (int)it->second; }
 inline float getf(const OpParam &p, const char *k, float def = 0.f) { auto it = p.find(k); return it == p.end() ? def : it->second; }
@@ -47,12 +48,12 @@ void alloc_f32(const shared_ptr<Tensor> &out) {
 class HIPLinearOp final : public HIPOp {
 public:
     HIPLinearOp(Backend *bn, const string &name, int in, int out, bool bias) : HIPOp(bn, name), in_(in), out_(out), has_bias_(bias) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->dimension() == in_, "LINEAR: input width differs from in_features");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), out_);
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode load(AbstructLoader &loader) override {
         load_tensor(weight_, backend_, loader, name() + ".weight", out_, in_);
         const DataType dt = weight_.dtype();
@@ -71,7 +72,7 @@ public:
         if (has_bias_) load_tensor(bias_, backend_, loader, name() + ".bias", 1, out_);
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         auto *b = hb();
         const int M = rows_of(inputs[0]);
         if (M == 0) return MLLM_NO_ERROR;
@@ -109,7 +110,7 @@ public:
         }
         return MLLM_NO_ERROR;
     }
-    ErrorCode free(TensorList, TensorList) override {
+    ErrorCode free(TensorListV, TensorListV) override {
         weight_.free();
         if (has_bias_) bias_.free();
         for (void **p : {&packed_, &q40_qs_, &q40_d_}) if (*p) { hb()->dev_release(*p); *p = nullptr; }
@@ -127,11 +128,11 @@ private:
 class HIPEmbeddingOp final : public HIPOp {
 public:
     HIPEmbeddingOp(Backend *bn, const string &name, int hidden, int vocab) : HIPOp(bn, name), hidden_(hidden), vocab_(vocab) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         outputs[0]->reshape(inputs[0]->batch(), 1, inputs[0]->sequence(), hidden_);
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode load(AbstructLoader &loader) override {
         const DataType dt = loader.getDataType(name() + ".weight");
         if (dt == MLLM_TYPE_Q4_0) table_ = hb()->q40_table(loader, name() + ".weight", vocab_, hidden_);      // shared with the tied lm_head's PARAMETER
@@ -139,14 +140,14 @@ public:
         else throw std::runtime_error("HIPEmbeddingOp: Q4_0 or fp32 tables (what *-q4_k.mllm files hold): " + name());
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         const int S = inputs[0]->batch() * inputs[0]->sequence();
         if (S == 0) return MLLM_NO_ERROR;
         if (table_) HIPQ(mllm_hip_embedding_q40, (const float *)dptr(inputs[0]), (const uint8_t *)table_->qs, (const uint16_t *)table_->d, (float *)dptr(outputs[0]), S, hidden_, vocab_, hb()->stream());
         else HIPQ(mllm_hip_gather_rows, (const float *)f32_.device_memory().handle, hidden_, vocab_, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), hidden_, S, hidden_, 0, hb()->stream());      // CPUEmbedding.cpp:46-60: a row copy
         return MLLM_NO_ERROR;
     }
-    ErrorCode free(TensorList, TensorList) override { if (!table_) f32_.free(); return MLLM_NO_ERROR; }
+    ErrorCode free(TensorListV, TensorListV) override { if (!table_) f32_.free(); return MLLM_NO_ERROR; }
 
 private:
     int hidden_, vocab_;
@@ -160,7 +161,7 @@ class HIPParameterOp final : public HIPOp {
 public:
     HIPParameterOp(Backend *bn, const string &name, int b, int h, int s, int d) : HIPOp(bn, name), b_(b), h_(h), s_(s), d_(d) {}
     bool keeps_shadow() const override { return true; }
-    ErrorCode reshape(TensorList, TensorList outputs) override {
+    ErrorCode reshape_(TensorList, TensorList outputs) override {
         outputs[0]->reshape(b_, h_, s_, d_);
         return MLLM_NO_ERROR;
     }
@@ -176,7 +177,7 @@ public:
         loader.load(&weight_);
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override {
         Tensor &w = table_ ? table_->raw : weight_;
         outputs[0]->setDtype(w.dtype());
         hb()->view_of(outputs[0], w.device_memory().handle, w.cntSize());
@@ -194,18 +195,18 @@ class HIPNormOp final : public HIPOp {
 public:
     HIPNormOp(Backend *bn, const string &name, bool layer, int dim, float eps, bool bias, bool unit_offset) :
         HIPOp(bn, name), layer_(layer), dim_(dim), eps_(eps), has_bias_(bias), unit_offset_(unit_offset) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->dimension() == dim_, "norm: input width differs from norm_size");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode load(AbstructLoader &loader) override {
         load_tensor(weight_, backend_, loader, name() + ".weight", 1, dim_);
         if (layer_ && has_bias_) load_tensor(bias_, backend_, loader, name() + ".bias", 1, dim_);
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         const int M = rows_of(inputs[0]);
         if (M == 0) return MLLM_NO_ERROR;
         const float *w = (const float *)weight_.device_memory().handle;
@@ -235,14 +236,14 @@ class HIPRoPEOp final : public HIPOp {
 public:
     HIPRoPEOp(Backend *bn, const string &name, bool multimodal, float theta, int max_pos, std::vector<int> section) :
         HIPOp(bn, name), multimodal_(multimodal), theta_(theta), max_pos_(max_pos), section_(std::move(section)) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         if (!multimodal_ && h_cnt_ + inputs[0]->sequence() > max_pos_) throw std::runtime_error("HIPRoPEOp: position beyond max_position_embeddings");
         need(inputs[0]->batch() <= 1, "ROPE: batch 1");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         auto *b = hb();
         const int S = inputs[0]->sequence(), H = inputs[0]->head(), D = inputs[0]->dimension(), half = D / 2;
         if (S == 0) return MLLM_NO_ERROR;
@@ -292,14 +293,14 @@ class HIPVisionRoPEOp final : public HIPOp {
 public:
     HIPVisionRoPEOp(Backend *bn, const string &name, int dim, int merge) : HIPOp(bn, name), dim_(dim), merge_(merge) {}
     bool host_inputs() const override { return true; }
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         for (int i = 0; i < 3; ++i) g_[i] = (int)inputs[0]->dataAt<float>(0, 0, 0, i);
         need(g_[0] > 0 && g_[1] > 0 && g_[2] > 0 && g_[1] % merge_ == 0 && g_[2] % merge_ == 0, "VISIONROPE: grid_thw must be positive multiples of the merge size");
         outputs[0]->reshape(1, 1, g_[0] * g_[1] * g_[2], 2 * (dim_ / 2));
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList, TensorList outputs) override {
         auto *b = hb();
         const int N = g_[0] * g_[1] * g_[2], rd = 2 * (dim_ / 2);
         std::vector<float> ang((size_t)N * rd), s((size_t)N * rd), c((size_t)N * rd);
@@ -326,14 +327,14 @@ private:
 class HIPApplyVisionRoPEOp final : public HIPOp {
 public:
     HIPApplyVisionRoPEOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->batch() == 1 && inputs[1]->sequence() == inputs[0]->sequence() && inputs[1]->dimension() == inputs[0]->dimension() / 2 && inputs[0]->dtype() == MLLM_TYPE_F32,
              "F_APPLY_VISIOROPE: x [1,H,N,D] fp32 with angles [1,1,N,D/2]");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         auto *b = hb();
         const int S = inputs[0]->sequence(), H = inputs[0]->head(), D = inputs[0]->dimension(), half = D / 2;
         HIPBackend::RopeTables t;
@@ -359,7 +360,7 @@ class HIPKVCacheOp final : public HIPOp {
 public:
     HIPKVCacheOp(Backend *bn, const string &name, int cache_max) : HIPOp(bn, name), cache_max_(cache_max) {}
     bool keeps_shadow() const override { return true; }
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->batch() == 1 && inputs[0]->dtype() == MLLM_TYPE_F32, "KVCACHE: batch 1, fp32 producer");
         if (cache_seq_len_ + inputs[0]->sequence() > cache_max_) {      // CPUKVCache.cpp:121-126
             fprintf(stderr, "\n[ERROR]: Current tokens exceed cache limit: %d>%d;\n         Please set args `--limits` >%d\n", cache_seq_len_ + inputs[0]->sequence(), cache_max_, cache_max_);
@@ -368,7 +369,7 @@ public:
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), cache_seq_len_ + inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList inputs, TensorList outputs) override {
         const size_t row = (size_t)inputs[0]->head() * inputs[0]->dimension();
         if (!slab_ || row != row_) {
             need(cache_seq_len_ == 0, "KVCACHE: the row width changed with tokens in the cache");
@@ -380,7 +381,7 @@ public:
         hb()->view_of(outputs[0], slab_, (size_t)outputs[0]->sequence() * row * 2);
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(TensorList inputs, TensorList) override {
+    ErrorCode execute_(TensorList inputs, TensorList) override {
         const int S = inputs[0]->sequence(), n = (int)row_;
         if (S) {
             HIPBackend::LazyOp o;
@@ -403,15 +404,15 @@ private:
 class HIPFlashAttention2Op final : public HIPOp {
 public:
     HIPFlashAttention2Op(Backend *bn, const string &name, bool causal) : HIPOp(bn, name), causal_(causal) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         auto &q = inputs[0], &k = inputs[1], &v = inputs[2];
         need(q->batch() == 1 && q->dtype() == MLLM_TYPE_F32 && k->dtype() == v->dtype() && (k->dtype() == MLLM_TYPE_F16 || k->dtype() == MLLM_TYPE_F32), "F_FA2: batch 1, fp32 q, fp16 or fp32 k / v");
         need(k->head() == v->head() && k->head() > 0 && q->head() % k->head() == 0 && k->sequence() == v->sequence() && k->dimension() == q->dimension() && v->dimension() == q->dimension(), "F_FA2: head / length mismatch");
         outputs[0]->reshape(q->batch(), q->head(), q->sequence(), q->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         auto &q = inputs[0], &k = inputs[1], &v = inputs[2];
         const int Hq = q->head(), Hkv = k->head(), D = q->dimension();
         if (q->sequence() == 0) return MLLM_NO_ERROR;
@@ -437,12 +438,12 @@ class HIPUnaryOp final : public HIPOp {
 public:
     enum Kind { SILU_K, GELU_K, QUICKGELU_K };
     HIPUnaryOp(Backend *bn, const string &name, Kind k) : HIPOp(bn, name), kind_(k) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         auto *b = hb();
         const int64_t n = inputs[0]->count();
         if (n == 0) return MLLM_NO_ERROR;
@@ -463,13 +464,13 @@ private:
 class HIPBinaryOp final : public HIPOp {
 public:
     HIPBinaryOp(Backend *bn, const string &name, bool mul) : HIPOp(bn, name), mul_(mul) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->count() == inputs[1]->count(), "F_TTADD / F_TTMUL: operands of one shape (no broadcast on this path)");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         if (inputs[0]->count()) {
             HIPBackend::LazyOp o;
             o.kind = mul_ ? HIPBackend::LazyOp::MUL : HIPBackend::LazyOp::ADD;
@@ -488,13 +489,13 @@ private:
 class HIPSlidingWindowMaskOp final : public HIPOp {
 public:
     HIPSlidingWindowMaskOp(Backend *bn, const string &name, int window) : HIPOp(bn, name), window_(window) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->batch() == 1, "SLIDINGWINDOWMASK: batch 1");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         HIPQ(mllm_hip_sliding_window_mask, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), inputs[0]->sequence(), inputs[0]->head(), inputs[0]->dimension(), window_,
                                             hb()->stream());
         return MLLM_NO_ERROR;
@@ -508,7 +509,7 @@ private:
 class HIPTopkOp final : public HIPOp {
 public:
     HIPTopkOp(Backend *bn, const string &name, int k, bool head_axis) : HIPOp(bn, name), k_(k), head_(head_axis) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         if (head_ && (inputs[0]->dimension() != 1 || inputs[0]->batch() != 1)) throw std::runtime_error("HIPTopkOp: the HEAD axis form takes [1][H][S][1]");
         for (int o = 0; o < 2; ++o) {
             if (head_) outputs[o]->reshape(inputs[0]->batch(), k_, inputs[0]->sequence(), 1);
@@ -516,8 +517,8 @@ public:
         }
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); alloc_f32(outputs[1]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); alloc_f32(outputs[1]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         const int rows = head_ ? inputs[0]->sequence() : inputs[0]->batch() * inputs[0]->head() * inputs[0]->sequence();
         const int n = head_ ? inputs[0]->head() : inputs[0]->dimension();
         HIPQ(mllm_hip_topk_rows, (const float *)dptr(inputs[0]), n, (float *)dptr(outputs[0]), (float *)dptr(outputs[1]), rows, n, k_, hb()->stream());
@@ -532,9 +533,9 @@ private:
 class HIPScatterAddOp final : public HIPOp {
 public:
     HIPScatterAddOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
-    ErrorCode reshape(TensorList, TensorList) override { return MLLM_NO_ERROR; }
-    ErrorCode setUp(TensorList, TensorList) override { return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList) override {
+    ErrorCode reshape_(TensorList, TensorList) override { return MLLM_NO_ERROR; }
+    ErrorCode setUp_(TensorList, TensorList) override { return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList) override {
         if (inputs[1]->batch() == 0) return MLLM_NO_ERROR;
         const int D = inputs[0]->dimension();
         HIPQ(mllm_hip_scatter_add_rows, (float *)dptr(inputs[0]), D, inputs[0]->sequence(), (const float *)dptr(inputs[1]), D, (const float *)dptr(inputs[2]), inputs[2]->dimension(), D, hb()->stream());
@@ -547,13 +548,13 @@ public:
 class HIPSoftMaxOp final : public HIPOp {
 public:
     HIPSoftMaxOp(Backend *bn, const string &name, bool causal) : HIPOp(bn, name), causal_(causal) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->ctype() == BSHD, "SOFTMAX: BSHD scores");
         outputs[0]->reshape(inputs[0]->batch(), inputs[0]->head(), inputs[0]->sequence(), inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         auto *b = hb();
         const int rows = rows_of(inputs[0]), n = inputs[0]->dimension(), S = inputs[0]->sequence(), H = inputs[0]->head();
         if (rows == 0) return MLLM_NO_ERROR;
@@ -581,7 +582,7 @@ class HIPPatchConvOp final : public HIPOp {
 public:
     HIPPatchConvOp(Backend *bn, const string &name, bool is3d, int in_ch, int out_ch, int kt, int kh, int kw, bool bias) :
         HIPOp(bn, name), is3d_(is3d), in_ch_(in_ch), out_ch_(out_ch), kt_(kt), kh_(kh), kw_(kw), has_bias_(bias) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         if (is3d_) {
             need(inputs[0]->ctype() == BCTHW && inputs[0]->channel() == in_ch_ && inputs[0]->time() == kt_ && inputs[0]->height() == kh_ && inputs[0]->width() == kw_,
                  "CONVOLUTION3D: one receptive field per batch entry, [N, C, kt, kh, kw]");
@@ -592,14 +593,14 @@ public:
         }
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
     ErrorCode load(AbstructLoader &loader) override {
         load_tensor(weight_, backend_, loader, name() + ".weight", out_ch_, in_ch_ * kt_ * kh_ * kw_);
         need(weight_.dtype() == MLLM_TYPE_F32, "patch-embedding convolutions are fp32 in *-q4_k.mllm files");
         if (has_bias_) load_tensor(bias_, backend_, loader, name() + ".bias", 1, out_ch_);
         return MLLM_NO_ERROR;
     }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         auto *b = hb();
         const float *w = (const float *)weight_.device_memory().handle, *bias = has_bias_ ? (const float *)bias_.device_memory().handle : nullptr;
         const int KK = in_ch_ * kt_ * kh_ * kw_;
@@ -630,7 +631,7 @@ class HIPViewOp final : public HIPOp {
 public:
     HIPViewOp(Backend *bn, const string &name, int b, int h, int s, int d) : HIPOp(bn, name), b_(b), h_(h), s_(s), d_(d) {}
     bool keeps_shadow() const override { return true; }
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         auto &in = inputs[0];
         const bool five = in->ctype() == BCTHW;
         const int64_t n = in->count();
@@ -663,7 +664,7 @@ public:
         outputs[0]->reshape(B, H, S, D);      // a fresh shell: BSHD
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList inputs, TensorList outputs) override {
         outputs[0]->setDtype(inputs[0]->dtype());
         hb()->view_of(outputs[0], dptr(inputs[0]), inputs[0]->device_memory().size_in_bytes);
         return MLLM_NO_ERROR;
@@ -680,7 +681,7 @@ class HIPClipSeqOp final : public HIPOp {
 public:
     HIPClipSeqOp(Backend *bn, const string &name, int a, int b, bool single) : HIPOp(bn, name), a_(a), b_(b), single_(single) {}
     bool keeps_shadow() const override { return true; }
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         const int S = inputs[0]->sequence();
         lo_ = a_ < 0 ? S + a_ : a_;
         hi_ = single_ ? lo_ + 1 : (b_ < 0 ? S + b_ : b_);
@@ -688,7 +689,7 @@ public:
         outputs[0]->reshape(1, inputs[0]->head(), hi_ - lo_, inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList inputs, TensorList outputs) override {
         outputs[0]->setDtype(inputs[0]->dtype());
         const size_t row = (size_t)inputs[0]->head() * inputs[0]->dimension() * elem_bytes(inputs[0]->dtype());
         hb()->view_of(outputs[0], (char *)dptr(inputs[0]) + (size_t)lo_ * row, (size_t)(hi_ - lo_) * row);
@@ -706,7 +707,7 @@ class HIPTransposeOp final : public HIPOp {
 public:
     HIPTransposeOp(Backend *bn, const string &name, Chl a, Chl b) : HIPOp(bn, name), a_(a), b_(b) {}
     bool keeps_shadow() const override { return true; }
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->ctype() == BSHD, "F_TRANPOSE: BSHD input");
         outputs[0]->transCopyShape(inputs[0]->shape());
         outputs[0]->chls() = inputs[0]->chls();
@@ -715,7 +716,7 @@ public:
         outputs[0]->undiffusion() = true;
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList inputs, TensorList outputs) override {
         outputs[0]->setDtype(inputs[0]->dtype());
         hb()->view_of(outputs[0], dptr(inputs[0]), inputs[0]->device_memory().size_in_bytes);
         return MLLM_NO_ERROR;
@@ -732,13 +733,13 @@ private:
 class HIPPatchRowsTransposeOp final : public HIPOp {
 public:
     HIPPatchRowsTransposeOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs[0]->ctype() == BSHD && inputs[0]->batch() == 1 && inputs[0]->dtype() == MLLM_TYPE_F32, "F_TRANPOSE {(S,D),(H,S)}: one fp32 BSHD image's patch grid");
         outputs[0]->reshape(1, inputs[0]->dimension(), inputs[0]->head(), inputs[0]->sequence());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         const int OC = inputs[0]->sequence(), N = inputs[0]->head() * inputs[0]->dimension();
         if (OC && N) HIPQ(mllm_hip_transpose_f32, (const float *)dptr(inputs[0]), (float *)dptr(outputs[0]), OC, N, hb()->stream());
         return MLLM_NO_ERROR;
@@ -752,7 +753,7 @@ class HIPFlattenOp final : public HIPOp {
 public:
     HIPFlattenOp(Backend *bn, const string &name, Chl a, Chl b) : HIPOp(bn, name), a_(a), b_(b) {}
     bool keeps_shadow() const override { return true; }
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         auto &in = inputs[0];
         need(in->ctype() == BSHD, "F_FLATTEN: contiguous BSHD input (the 5-D forms are not on the five configs' path)");
         int B = in->batch(), H = in->head(), S = in->sequence(), D = in->dimension();
@@ -763,7 +764,7 @@ public:
         outputs[0]->reshape(B, H, S, D);
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList inputs, TensorList outputs) override {
         if (outputs[0].get() != inputs[0].get()) {
             outputs[0]->setDtype(inputs[0]->dtype());
             hb()->view_of(outputs[0], dptr(inputs[0]), inputs[0]->device_memory().size_in_bytes);
@@ -780,7 +781,7 @@ private:
 class HIPCatSeqOp final : public HIPOp {
 public:
     HIPCatSeqOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         int S = 0;
         for (auto &in : inputs) {
             need(in->batch() == 1 && in->head() == 1 && in->dimension() == inputs[0]->dimension() && in->dtype() == MLLM_TYPE_F32 && in->dimension() % 4 == 0,
@@ -790,8 +791,8 @@ public:
         outputs[0]->reshape(1, 1, S, inputs[0]->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         const int D = inputs[0]->dimension();
         float *dst = (float *)dptr(outputs[0]);
         for (auto &in : inputs) {
@@ -807,7 +808,7 @@ public:
 class HIPSplitOp final : public HIPOp {
 public:
     HIPSplitOp(Backend *bn, const string &name, std::vector<int> each) : HIPOp(bn, name), each_(std::move(each)) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         int total = 0;
         for (int e : each_) total += e;
         need(outputs.size() == each_.size() && total == inputs[0]->dimension() && inputs[0]->dtype() == MLLM_TYPE_F32, "F_SPLIT: the parts must add up to the fp32 input's dimension");
@@ -817,8 +818,8 @@ public:
         }
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { for (auto &o : outputs) alloc_f32(o); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { for (auto &o : outputs) alloc_f32(o); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         const int rows = rows_of(inputs[0]), ld = inputs[0]->dimension();
         int off = 0;
         for (size_t i = 0; i < each_.size(); ++i) {
@@ -838,7 +839,7 @@ private:
 class HIPMatmulOp final : public HIPOp {
 public:
     HIPMatmulOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         auto &x = inputs[0], &w = inputs[1];
         need(x->ctype() == BSHD && x->dtype() == MLLM_TYPE_F32 && x->head() == 1, "F_MM: fp32 BSHD activations [b,1,s,K]");
         need(w->chls()[SEQUENCE] == 3 && w->batch() == 1 && w->head() == 1 && (w->dtype() == MLLM_TYPE_Q4_0 || w->dtype() == MLLM_TYPE_F32),
@@ -848,8 +849,8 @@ public:
         outputs[0]->reshape(x->batch(), x->head(), x->sequence(), w->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         auto *b = hb();
         auto &x = inputs[0], &w = inputs[1];
         const int M = rows_of(x), K = x->dimension(), N = w->dimension();
@@ -875,7 +876,7 @@ class HIPWhereOp final : public HIPOp {
 public:
     HIPWhereOp(Backend *bn, const string &name, float value, int axis) : HIPOp(bn, name), value_(value), axis_(axis) {}
     bool keeps_shadow() const override { return true; }
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         auto &in = inputs[0];
         const std::vector<float> &v = hb()->host_floats(in);
         for (auto &x : idx_) x.clear();
@@ -888,8 +889,8 @@ public:
         else outputs[0]->reshape(1, 1, 1, num);
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList, TensorList outputs) override {
         const size_t num = idx_[0].size();
         if (num == 0) return MLLM_NO_ERROR;
         std::vector<float> flat;
@@ -908,7 +909,7 @@ private:
 class HIPIndexPutOp final : public HIPOp {
 public:
     HIPIndexPutOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         if (inputs.size() > 1 && inputs[1]->batch() == 0) return MLLM_NO_ERROR;      // no image: the destination passes through (:44-53)
         need(inputs.size() == 3 && outputs[0].get() == inputs[0].get(), "F_INDEX_PUT: (dest, value, indices), in place");
         auto &dst = inputs[0], &src = inputs[1], &idx = inputs[2];
@@ -917,8 +918,8 @@ public:
         need(idx->dimension() <= src->batch() * src->sequence(), "F_INDEX_PUT: more indices than value rows");
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList) override { return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList) override {
+    ErrorCode setUp_(TensorList, TensorList) override { return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList) override {
         if (inputs.size() > 1 && inputs[1]->batch() == 0) return MLLM_NO_ERROR;
         HIPQ(mllm_hip_index_put_rows_fidx, (float *)dptr(inputs[0]), inputs[0]->sequence(), (const float *)dptr(inputs[1]), (const float *)dptr(inputs[2]), inputs[2]->dimension(),
                                             inputs[0]->dimension(), hb()->stream());
@@ -932,7 +933,7 @@ public:
 class HIPIndexPutGrowOp final : public HIPOp {
 public:
     HIPIndexPutGrowOp(Backend *bn, const string &name) : HIPOp(bn, name) {}
-    ErrorCode reshape(TensorList inputs, TensorList outputs) override {
+    ErrorCode reshape_(TensorList inputs, TensorList outputs) override {
         need(inputs.size() == 3 && inputs[1]->batch() == 1 && inputs[2]->dimension() == 1, "F_INDEX_PUT(accumulate): (dest, one image's rows, one index)");
         auto &dst = inputs[0], &src = inputs[1];
         need(dst->batch() == 1 && dst->head() == 1 && src->head() == 1 && dst->dimension() == src->dimension() && dst->dimension() % 4 == 0 && dst->dtype() == MLLM_TYPE_F32 &&
@@ -942,8 +943,8 @@ public:
         outputs[0]->reshape(1, 1, dst->sequence() - 1 + src->sequence(), dst->dimension());
         return MLLM_NO_ERROR;
     }
-    ErrorCode setUp(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
-    ErrorCode execute(TensorList inputs, TensorList outputs) override {
+    ErrorCode setUp_(TensorList, TensorList outputs) override { alloc_f32(outputs[0]); return MLLM_NO_ERROR; }
+    ErrorCode execute_(TensorList inputs, TensorList outputs) override {
         const int D = inputs[0]->dimension(), S = inputs[0]->sequence(), R = inputs[1]->sequence();
         const float *dst = (const float *)dptr(inputs[0]), *src = (const float *)dptr(inputs[1]);
         float *out = (float *)dptr(outputs[0]);
