@@ -131,8 +131,10 @@ void HIPBackend::drain_idle() {
 // ---- the lazy window (see HIPBackend.hpp) ------------------------------------------------------------------------------------------------------------------------
 // The runs one launch covers, as strings over the Ops' kinds (N RMSNORM, L LINEAR, S SILU, M F_TTMUL, A F_TTADD, R ROPE, K KVCACHE append, F F_FA2).  The window only ever holds a
 // prefix of one of them: an Op that cannot extend the prefix sends it to the device first, an Op that completes a run nothing can extend sends the run at once.
-static const char *const kRuns[] = {"NLLL", "NLSLM", "ANLLL", "ANLSLM", "LA", "LLL", "RRKKF"};
-static char kind_char(HIPBackend::LazyOp::Kind k) { return "NLSMARKF"[(int)k]; }
+// (lower case: the prefill forms -- n = RMSNORM / LAYERNORM on M >= 16 rows, l = a Linear on them: the norm writes the packed Q8_K operand once and every Linear behind it
+// reads that, instead of one quantiser pass per Linear)
+static const char *const kRuns[] = {"NLLL", "NLSLM", "ANLLL", "ANLSLM", "LA", "LLL", "RRKKF", "nlll", "nlSlM", "lll"};
+static char kind_char(HIPBackend::LazyOp::Kind k) { return "NLSMARKFnl"[(int)k]; }
 bool HIPBackend::window_extends(LazyOp::Kind k) const {
     char w[16];
     size_t n = 0;
@@ -175,6 +177,15 @@ void HIPBackend::emit_single(const LazyOp &o) {
     case LazyOp::ADD: defer("mllm_hip_add", mllm_hip_add, o.a, o.b, o.out, o.n, stream_); break;
     case LazyOp::ROPE: defer("mllm_hip_rope_apply", mllm_hip_rope_apply, o.a, (int64_t)o.H * o.D, o.sin, o.cos, o.ld_tab, (void *)o.out, (int)MLLM_HIP_F32, (int64_t)o.H * o.D, o.S, o.H, o.D, stream_); break;
     case LazyOp::KVSTORE: defer("mllm_hip_store_f16", mllm_hip_store_f16, o.a, (int64_t)o.n, o.dst16, (int64_t)o.n, o.S, (int)o.n, stream_); break;
+    case LazyOp::NORM_M:
+        if (o.layer_norm) defer("mllm_hip_layernorm", mllm_hip_layernorm, o.a, o.w, o.b, o.out, (int8_t *)nullptr, (float *)nullptr, (int16_t *)nullptr, o.M, (int)o.n, o.eps, stream_);
+        else defer("mllm_hip_rmsnorm", mllm_hip_rmsnorm, o.a, o.w, o.out, (int8_t *)nullptr, (float *)nullptr, (int16_t *)nullptr, o.M, (int)o.n, o.eps, o.unit_offset, stream_);
+        break;
+    case LazyOp::LINEAR_M:
+        defer("mllm_hip_quantize_q8k_packed", mllm_hip_quantize_q8k_packed, o.a, o.ws, o.M, o.K, stream_);
+        defer("mllm_hip_linear_q4kp_packed", mllm_hip_linear_q4kp_packed, o.Wpacked, o.w, (const void *)o.ws, (void *)o.out, (int)MLLM_HIP_F32, (int64_t)o.n, (const float *)nullptr, o.M,
+              (int)o.n, o.K, stream_);
+        break;
     case LazyOp::FA2:
         defer("mllm_hip_fa2", mllm_hip_fa2, o.a, (int64_t)o.H * o.D, o.kp, (int64_t)o.Hkv * o.D, o.vp, (int64_t)o.Hkv * o.D, o.kvdt, o.out, (int64_t)o.H * o.D, 1, o.Sk, o.H, o.Hkv, o.D,
               o.causal, (const int *)nullptr, (void *)nullptr, stream_);
@@ -269,6 +280,49 @@ size_t HIPBackend::emit_group(size_t i) {
             if (mllm_hip_row_fused_supported(&a) && safe(a)) return launch(a, cnt);
         }
     }
+    // prefill: [RMSNORM / LAYERNORM ->] LINEAR x 1..3 on the same M >= 16 rows: ONE packed Q8_K operand (written by the norm itself, else by one quantiser pass) for all of them
+    {
+        size_t j = i;
+        const LazyOp *norm = nullptr;
+        if (L[j].kind == LazyOp::NORM_M && j + 1 < n && L[j + 1].kind == LazyOp::LINEAR_M && L[j + 1].a == L[j].out && L[j + 1].K == (int)L[j].n && L[j + 1].M == L[j].M && L[j].n % 256 == 0) norm = &L[j++];
+        if (L[j].kind == LazyOp::LINEAR_M) {
+            const LazyOp &first = L[j];
+            size_t cnt = 1;
+            while (cnt < 3 && j + cnt < n && L[j + cnt].kind == LazyOp::LINEAR_M && L[j + cnt].a == first.a && L[j + cnt].K == first.K && L[j + cnt].M == first.M) ++cnt;
+            // the MLP's run on prefill rows: gate, SILU, up, F_TTMUL -- the up projection reads the packed operand the norm wrote for the gate (nothing in between touches it)
+            if (norm && cnt == 1 && j + 3 < n && L[j + 1].kind == LazyOp::SILU && L[j + 2].kind == LazyOp::LINEAR_M && L[j + 2].a == first.a && L[j + 2].K == first.K &&
+                L[j + 2].M == first.M && L[j + 3].kind == LazyOp::MUL) {
+                if (norm->layer_norm) defer("mllm_hip_layernorm_packed", mllm_hip_layernorm_packed, norm->a, norm->w, norm->b, norm->out, first.ws, norm->M, (int)norm->n, norm->eps, stream_);
+                else defer("mllm_hip_rmsnorm_packed", mllm_hip_rmsnorm_packed, norm->a, norm->w, norm->out, first.ws, norm->M, (int)norm->n, norm->eps, norm->unit_offset, stream_);
+                for (size_t k = 0; k < 4; ++k) {
+                    const LazyOp &l = L[j + k];
+                    if (l.kind == LazyOp::LINEAR_M)
+                        defer("mllm_hip_linear_q4kp_packed", mllm_hip_linear_q4kp_packed, l.Wpacked, l.w, (const void *)first.ws, (void *)l.out, (int)MLLM_HIP_F32, (int64_t)l.n,
+                              (const float *)nullptr, l.M, (int)l.n, l.K, stream_);
+                    else emit_single(l);
+                }
+                ++fused_launches_;
+                fused_ops_ += 5;
+                return 5;
+            }
+            if (norm || cnt > 1) {
+                // (no output of these launches may be the rows the later GEMMs still read: the packed operand is a scratch block of the backend's, the norm's input is read by the
+                // norm's launch only, and a Linear's output cannot be the block of the rows it shares with its neighbours -- they are alive)
+                if (norm) {
+                    if (norm->layer_norm) defer("mllm_hip_layernorm_packed", mllm_hip_layernorm_packed, norm->a, norm->w, norm->b, norm->out, first.ws, norm->M, (int)norm->n, norm->eps, stream_);
+                    else defer("mllm_hip_rmsnorm_packed", mllm_hip_rmsnorm_packed, norm->a, norm->w, norm->out, first.ws, norm->M, (int)norm->n, norm->eps, norm->unit_offset, stream_);
+                } else defer("mllm_hip_quantize_q8k_packed", mllm_hip_quantize_q8k_packed, first.a, first.ws, first.M, first.K, stream_);
+                for (size_t k = 0; k < cnt; ++k) {
+                    const LazyOp &l = L[j + k];
+                    defer("mllm_hip_linear_q4kp_packed", mllm_hip_linear_q4kp_packed, l.Wpacked, l.w, (const void *)first.ws, (void *)l.out, (int)MLLM_HIP_F32, (int64_t)l.n, (const float *)nullptr,
+                          l.M, (int)l.n, l.K, stream_);
+                }
+                ++fused_launches_;
+                fused_ops_ += (long)((norm ? 1 : 0) + cnt);
+                return (norm ? 1 : 0) + cnt;
+            }
+        }
+    }
     // ROPE(q), ROPE(k), KVCACHE(k) of the rotated k, KVCACHE(v), F_FA2 of one position over the slabs those appends extend: mllm_hip_fa2_decode_step
     if (o.kind == LazyOp::ROPE && i + 4 < n && L[i + 1].kind == LazyOp::ROPE && L[i + 2].kind == LazyOp::KVSTORE && L[i + 3].kind == LazyOp::KVSTORE && L[i + 4].kind == LazyOp::FA2) {
         const LazyOp &rq = o, &rk = L[i + 1], &sk = L[i + 2], &sv = L[i + 3], &fa = L[i + 4];
@@ -314,6 +368,8 @@ size_t HIPBackend::emit_group(size_t i) {
 
 HIPBackend::~HIPBackend() {
     try { drain(); } catch (...) {}
+    for (auto &kv : rope_hf_) { try { dev_release(kv.second); } catch (...) {} }
+    rope_hf_.clear();
     stop_.store(true, std::memory_order_release);
     if (worker_.joinable()) worker_.join();
     drain_idle();
@@ -463,6 +519,18 @@ HIPBackend::RopeTables HIPBackend::mrope_tables(const std::shared_ptr<Tensor> &p
     mrope_key_.pos = h; mrope_key_.serial = forward_serial_; mrope_key_.theta = theta; mrope_key_.D = D; mrope_key_.section = section;
     mrope_ = RopeTables{ds, dc, S, half};
     return mrope_;
+}
+const float *HIPBackend::rope_hf_tables(float theta, int D, int max_pos) {
+    const auto key = std::make_tuple(theta, D, max_pos);
+    auto it = rope_hf_.find(key);
+    if (it != rope_hf_.end()) return it->second;
+    std::vector<float> s((size_t)max_pos * D), c((size_t)max_pos * D);
+    check(mllm_hip_rope_table_hf(theta, D, max_pos, s.data(), c.data()), "mllm_hip_rope_table_hf");
+    float *tab = (float *)dev_alloc((size_t)2 * max_pos * D * 4);
+    upload(tab, s.data(), s.size() * 4);
+    upload(tab + (size_t)max_pos * D, c.data(), c.size() * 4);
+    rope_hf_[key] = tab;
+    return tab;
 }
 void HIPBackend::set_vision_tables(void *angles_handle, const float *sin, const float *cos, int N, int half) { vision_[angles_handle] = RopeTables{sin, cos, N, half}; }
 bool HIPBackend::vision_tables(const void *angles_handle, RopeTables *out) const {

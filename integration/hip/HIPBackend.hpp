@@ -145,7 +145,7 @@ public:
     // runs are contiguous, so the order of all device work is the program's.  Anything that is not a LazyOp (another Op's defer, an upload, a drain) flushes the window first.
     // MLLM_HIP_NO_FUSE=1 emits every Op on its own (A/B measurements).
     struct LazyOp {
-        enum Kind : int { NORM, LINEAR, SILU, MUL, ADD, ROPE, KVSTORE, FA2 } kind;
+        enum Kind : int { NORM, LINEAR, SILU, MUL, ADD, ROPE, KVSTORE, FA2, NORM_M, LINEAR_M } kind;      // _M: the M >= 16 (prefill) forms: RMSNORM / LAYERNORM rows, packed-GEMM Linears
         const float *a = nullptr, *b = nullptr;      // inputs (b: second operand of ADD / MUL)
         float *out = nullptr;
         int64_t n = 0;                               // elements (SILU / MUL / ADD), row width (NORM, KVSTORE), out_features (LINEAR)
@@ -157,6 +157,9 @@ public:
         const float *sin = nullptr, *cos = nullptr;  // ROPE
         int ld_tab = 0, S = 0, H = 0, D = 0;
         uint16_t *dst16 = nullptr;                   // KVSTORE: the slab rows to append to
+        int M = 1;                                   // NORM_M / LINEAR_M: rows
+        const void *Wpacked = nullptr;               // LINEAR_M: the packed GEMM operand (mllm_hip_q4k_prepack); ws = the packed-activation scratch of its own call
+        int layer_norm = 0, unit_offset = 0;         // NORM_M: LAYERNORM (b = its bias, may be null) / RMSNorm with add_unit_offset
         const void *kp = nullptr, *vp = nullptr;     // FA2 (one query row): K / V views [Sk][Hkv * D]; a = q, H = Hq
         int Sk = 0, Hkv = 0, causal = 0, kvdt = 0;
     };
@@ -191,6 +194,9 @@ public:
     // sin / cos device tables of the current M-RoPE position ids, built once per forward and shared by every MULTIMODALROPE Op (2 per layer)
     struct RopeTables { const float *sin = nullptr, *cos = nullptr; int S = 0, half = 0; };
     RopeTables mrope_tables(const std::shared_ptr<Tensor> &position_ids, float theta, int D, const std::vector<int> &section);
+    // CPURoPE's static half-split table [2][max_pos][D] (sines, then cosines) on the device: ONE per (theta, D, max_pos) for the whole backend -- every ROPE Op of a model asks for
+    // the same one (two per layer), and building it is max_pos * D libm calls on the caller's thread
+    const float *rope_hf_tables(float theta, int D, int max_pos);
     // sin / cos of a VISIONROPE angle table, keyed by the table's device handle (set by the VISIONROPE Op that made it)
     void set_vision_tables(void *angles_handle, const float *sin, const float *cos, int N, int half);
     bool vision_tables(const void *angles_handle, RopeTables *out) const;
@@ -227,6 +233,7 @@ private:
     size_t mrope_bytes_ = 0;
     RopeTables mrope_;
     std::unordered_map<const void *, RopeTables> vision_;
+    std::map<std::tuple<float, int, int>, float *> rope_hf_;
     std::unordered_map<std::string, std::pair<void *, size_t>> maps_;      // .mllm path -> read-only mmap (load_from_file)
     // single-producer / single-consumer ring of deferred calls
     struct Deferred {

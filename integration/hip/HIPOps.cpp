@@ -92,8 +92,9 @@ public:
                 HIPQ(mllm_hip_linear, weight_.device_memory().handle, MLLM_HIP_Q4_K, bias, x, y, MLLM_HIP_F32, out_, M, out_, in_, ws, b->stream());
             } else {
                 void *xpack = b->scratch(1, mllm_hip_q4k_prepack_bytes(M, in_));
-                HIPQ(mllm_hip_quantize_q8k_packed, x, xpack, M, in_, b->stream());
-                HIPQ(mllm_hip_linear_q4kp_packed, packed_, bias, xpack, y, MLLM_HIP_F32, out_, nullptr, M, out_, in_, b->stream());
+                HIPBackend::LazyOp o;      // the window lets the Linears on one set of rows share one packed operand, written by the norm in front of them when there is one
+                o.kind = HIPBackend::LazyOp::LINEAR_M; o.a = x; o.out = (float *)y; o.n = out_; o.w = bias; o.Wpacked = packed_; o.K = in_; o.M = M; o.ws = xpack;
+                b->lazy(o);
             }
             break;
         }
@@ -210,7 +211,12 @@ public:
         const int M = rows_of(inputs[0]);
         if (M == 0) return MLLM_NO_ERROR;
         const float *w = (const float *)weight_.device_memory().handle;
-        if (layer_) HIPQ(mllm_hip_layernorm, (const float *)dptr(inputs[0]), w, has_bias_ ? (const float *)bias_.device_memory().handle : nullptr, (float *)dptr(outputs[0]), nullptr,
+        if (M >= 16 && dim_ % 256 == 0) {      // prefill rows: the window may let the norm write the packed operand of the Linears behind it
+            HIPBackend::LazyOp o;
+            o.kind = HIPBackend::LazyOp::NORM_M; o.a = (const float *)dptr(inputs[0]); o.out = (float *)dptr(outputs[0]); o.n = dim_; o.w = w; o.eps = eps_; o.M = M;
+            o.layer_norm = layer_ ? 1 : 0; o.unit_offset = unit_offset_ ? 1 : 0; o.b = layer_ && has_bias_ ? (const float *)bias_.device_memory().handle : nullptr;
+            hb()->lazy(o);
+        } else if (layer_) HIPQ(mllm_hip_layernorm, (const float *)dptr(inputs[0]), w, has_bias_ ? (const float *)bias_.device_memory().handle : nullptr, (float *)dptr(outputs[0]), nullptr,
                                               nullptr, nullptr, M, dim_, eps_, hb()->stream());
         else if (M == 1 && !unit_offset_) {
             HIPBackend::LazyOp o;
@@ -254,13 +260,8 @@ public:
             need(t.S == S, "MULTIMODALROPE: position_ids hold a different number of positions than the input");
             ds = t.sin; dc = t.cos;
         } else {
-            if (table_dim_ != D) {      // CPURoPE's static table, built once per head size and kept on the device: [max_pos][D]
-                std::vector<float> s((size_t)max_pos_ * D), c((size_t)max_pos_ * D);
-                HIPCHK(mllm_hip_rope_table_hf(theta_, D, max_pos_, s.data(), c.data()));
-                if (tab_) b->dev_release(tab_);
-                tab_ = (float *)b->dev_alloc((size_t)2 * max_pos_ * D * 4);
-                b->upload(tab_, s.data(), s.size() * 4);
-                b->upload(tab_ + (size_t)max_pos_ * D, c.data(), c.size() * 4);
+            if (table_dim_ != D) {      // CPURoPE's static table [max_pos][D]: one per (theta, D, max_pos) in the backend, shared by every ROPE Op of the model
+                tab_ = b->rope_hf_tables(theta_, D, max_pos_);
                 table_dim_ = D;
             }
             ds = tab_ + (size_t)h_cnt_ * D;
@@ -283,7 +284,7 @@ private:
     int max_pos_;
     std::vector<int> section_;
     int h_cnt_ = 0, table_dim_ = 0;
-    float *tab_ = nullptr;
+    const float *tab_ = nullptr;      // the backend's (HIPBackend::rope_hf_tables)
 };
 
 // ---- VISIONROPE: CPUVisionRoPE (op/CPUVisionRoPE.cpp:12-147; dim, spatial_merge_size): grid (t, h, w) -> the angle table [1,1,N,dim].  The grid is a host-side
@@ -303,23 +304,29 @@ public:
     ErrorCode execute_(TensorList, TensorList outputs) override {
         auto *b = hb();
         const int N = g_[0] * g_[1] * g_[2], rd = 2 * (dim_ / 2);
-        std::vector<float> ang((size_t)N * rd), s((size_t)N * rd), c((size_t)N * rd);
-        HIPCHK(mllm_hip_vision_rope_angles(g_[0], g_[1], g_[2], merge_, rd, ang.data()));
-        HIPCHK(mllm_hip_vision_rope_table(g_[0], g_[1], g_[2], merge_, rd, s.data(), c.data()));
-        if ((size_t)N * rd > cap_) {
-            if (tab_) b->dev_release(tab_);
-            cap_ = (size_t)N * rd;
-            tab_ = (float *)b->dev_alloc(2 * cap_ * 4);
+        // the tables of a grid are a pure function of (t, h, w): 82 k libm sines and cosines for a 448 x 448 image, about 2 ms of the caller's thread per forward -- kept for the
+        // grid they were made for (angles, sines, cosines in one device block: [3][cap_]); the Op's output is filled from the device copy
+        if (g_[0] != made_[0] || g_[1] != made_[1] || g_[2] != made_[2]) {
+            std::vector<float> ang((size_t)N * rd), s((size_t)N * rd), c((size_t)N * rd);
+            HIPCHK(mllm_hip_vision_rope_angles(g_[0], g_[1], g_[2], merge_, rd, ang.data()));
+            HIPCHK(mllm_hip_vision_rope_table(g_[0], g_[1], g_[2], merge_, rd, s.data(), c.data()));
+            if ((size_t)N * rd > cap_) {
+                if (tab_) b->dev_release(tab_);
+                cap_ = (size_t)N * rd;
+                tab_ = (float *)b->dev_alloc(3 * cap_ * 4);
+            }
+            b->upload(tab_, s.data(), s.size() * 4);
+            b->upload(tab_ + cap_, c.data(), c.size() * 4);
+            b->upload(tab_ + 2 * cap_, ang.data(), ang.size() * 4);
+            for (int i = 0; i < 3; ++i) made_[i] = g_[i];
         }
-        b->upload(dptr(outputs[0]), ang.data(), ang.size() * 4);
-        b->upload(tab_, s.data(), s.size() * 4);
-        b->upload(tab_ + cap_, c.data(), c.size() * 4);
+        HIPQ(mllm_hip_copy_2d_f32, (const float *)(tab_ + 2 * cap_), (int64_t)rd, (float *)dptr(outputs[0]), (int64_t)rd, N, rd, b->stream());
         b->set_vision_tables(dptr(outputs[0]), tab_, tab_ + cap_, N, rd);
         return MLLM_NO_ERROR;
     }
 
 private:
-    int dim_, merge_, g_[3] = {0, 0, 0};
+    int dim_, merge_, g_[3] = {0, 0, 0}, made_[3] = {0, 0, 0};
     float *tab_ = nullptr;
     size_t cap_ = 0;
 };

@@ -5,6 +5,7 @@
 // All are row- or element-parallel: one 64-lane wave owns one 256-value quant block (4 consecutive values per lane,
 // 16-B coalesced loads), reductions are wavefront shuffles, nothing is staged through LDS except cross-wave sums.
 #include <algorithm>
+#include <vector>
 #include <cmath>
 #include <cstring>
 
@@ -1325,13 +1326,28 @@ extern "C" int mllm_hip_vision_rope_angles(int t, int h, int w, int merge, int r
 // CPUVisionRoPEFunc.hpp:21-60 evaluates std::sin / std::cos of the angle per use: tabulated here.  Tables [t*h*w][rot_dim]
 extern "C" int mllm_hip_vision_rope_table(int t, int h, int w, int merge, int rot_dim, float *sin_host, float *cos_host) {
     if (!sin_host || !cos_host) return MLLM_HIP_ERR_ARG;
-    const int rc = mllm_hip_vision_rope_angles(t, h, w, merge, rot_dim, cos_host);      // angles parked in the cos table, replaced in place
-    if (rc != MLLM_HIP_OK) return rc;
-    const size_t n = (size_t)t * (h / merge) * (w / merge) * merge * merge * (size_t)(rot_dim / 2) * 2;
-    for (size_t i = 0; i < n; ++i) {
-        const float a = cos_host[i];
-        sin_host[i] = sinf(a);
-        cos_host[i] = cosf(a);
-    }
+    const int q = rot_dim / 2;
+    if (q <= 0 || q > 256 || merge <= 0 || t < 0 || h < 0 || w < 0) return MLLM_HIP_ERR_SHAPE;
+    // an angle is (float)position * inv[i] with position < max(h, w): max(h, w) * q distinct values (640 for a 448 x 448 image) instead of t * h * w * rot_dim libm calls (82 k,
+    // about 2 ms of the caller's thread) -- the same float goes into the same sinf / cosf, so the tables are the same bits
+    float inv[256];
+    for (int i = 0; i < q; ++i) inv[i] = 1.0f / powf(10000.0f, (2.0f * i) / (float)rot_dim);
+    const int np = std::max(h, w);
+    std::vector<float> sv((size_t)np * q), cv((size_t)np * q);
+    for (int pos = 0; pos < np; ++pos)
+        for (int i = 0; i < q; ++i) { const float a = (float)pos * inv[i]; sv[(size_t)pos * q + i] = sinf(a); cv[(size_t)pos * q + i] = cosf(a); }
+    const int nhb = h / merge, nwb = w / merge;
+    size_t p = 0;
+    for (int ti = 0; ti < t; ++ti)
+        for (int bh = 0; bh < nhb; ++bh)
+            for (int bw = 0; bw < nwb; ++bw)
+                for (int jh = 0; jh < merge; ++jh)
+                    for (int jw = 0; jw < merge; ++jw, ++p) {
+                        const int ph = bh * merge + jh, pw = bw * merge + jw;
+                        for (int i = 0; i < q; ++i) {
+                            sin_host[p * rot_dim + i] = sv[(size_t)ph * q + i]; cos_host[p * rot_dim + i] = cv[(size_t)ph * q + i];
+                            sin_host[p * rot_dim + q + i] = sv[(size_t)pw * q + i]; cos_host[p * rot_dim + q + i] = cv[(size_t)pw * q + i];
+                        }
+                    }
     return MLLM_HIP_OK;
 }

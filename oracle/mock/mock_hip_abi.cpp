@@ -91,6 +91,14 @@ int mllm_hip_layernorm(const float *x, const float *w, const float *b, float *y,
     rd(x, (size_t)M * dim * 4); rd(w, (size_t)dim * 4); if (b) rd(b, (size_t)dim * 4); wr(y, (size_t)M * dim * 4);
     return 0;
 }
+int mllm_hip_rmsnorm_packed(const float *x, const float *w, float *y, void *xpack, int M, int dim, float, int, void *) {
+    rd(x, (size_t)M * dim * 4); rd(w, (size_t)dim * 4); if (y) wr(y, (size_t)M * dim * 4); wr(xpack, mllm_hip_q4k_prepack_bytes(M, dim));
+    return 0;
+}
+int mllm_hip_layernorm_packed(const float *x, const float *w, const float *b, float *y, void *xpack, int M, int dim, float, void *) {
+    rd(x, (size_t)M * dim * 4); rd(w, (size_t)dim * 4); if (b) rd(b, (size_t)dim * 4); if (y) wr(y, (size_t)M * dim * 4); wr(xpack, mllm_hip_q4k_prepack_bytes(M, dim));
+    return 0;
+}
 int mllm_hip_silu(const float *x, float *y, int64_t n, void *) { rd(x, n * 4); wr(y, n * 4); return 0; }
 int mllm_hip_silu_rows(const float *x, float *y, int64_t rows, int dim, void *) { rd(x, rows * dim * 4); wr(y, rows * dim * 4); return 0; }
 int mllm_hip_act_lut(const float *x, float *y, int64_t n, const uint16_t *lut, void *) { rd(x, n * 4); rd(lut, 65536 * 2); wr(y, n * 4); return 0; }

@@ -124,3 +124,24 @@ def test_ops_module_refuses_without_gpu():
     from mllm_amd import ops
     with pytest.raises(lib.MllmHipError):
         ops.require_gpu()
+
+
+def test_vision_rope_tables_equal_libm_per_element():
+    """mllm_hip_vision_rope_table memoises sinf / cosf per (position, frequency) -- 640 libm calls for a 448 x 448 image instead of 82 k; every table entry still equals libm's
+    sinf / cosf of the angle mllm_hip_vision_rope_angles gives for it (CPUVisionRoPEFunc.hpp:21-60 evaluates them per use), bit for bit, square and non-square grids."""
+    import ctypes as C
+
+    from mllm_amd import lib
+    l = lib.load()
+    libm = C.CDLL("libm.so.6")
+    libm.sinf.restype = libm.cosf.restype = C.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [C.c_float]
+    for (t, h, w, rd) in ((1, 32, 32, 40), (1, 6, 10, 40), (2, 4, 18, 16)):
+        n = t * h * w * rd
+        ang, s, c = (np.empty(n, dtype=np.float32) for _ in range(3))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert l.mllm_hip_vision_rope_angles(t, h, w, 2, rd, p(ang)) == 0
+        assert l.mllm_hip_vision_rope_table(t, h, w, 2, rd, p(s), p(c)) == 0
+        idx = np.unique(np.concatenate([np.arange(0, n, 97), np.arange(n - 64, n)]))
+        for i in idx:
+            assert s[i] == np.float32(libm.sinf(float(ang[i]))) and c[i] == np.float32(libm.cosf(float(ang[i]))), (t, h, w, i)
