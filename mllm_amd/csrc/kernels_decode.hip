@@ -389,15 +389,18 @@ struct KvWarm {
 // ------------------------------------------------------------------------------------------------------------------------
 // dec_qkv: x (or the embedding row of state->token for layer 0) -> RMSNorm -> Q8_K -> Wqkv rows (+bias) -> qkv fp32
 // ------------------------------------------------------------------------------------------------------------------------
-template <int NSTEPS, int ROWS, bool EMBED, int NV, int WPB>
-__global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
-                                                      const uint8_t *__restrict__ emb_qs, const uint16_t *__restrict__ emb_d, int vocab,
-                                                      const float *__restrict__ norm_w, float eps, const uint8_t *__restrict__ W,
-                                                      const float *__restrict__ bias, float *__restrict__ y, int N, int K, KvWarm kw) {
+// PAIRS (the merged q|k|v + attention + o-projection launch): the rows go out as {value, DecodeState::serial} pairs for the attention's workgroups of the same launch;
+// wg / grid = this role's workgroup index and count (the stand-alone kernel passes its own block index and grid size)
+template <int NSTEPS, int ROWS, bool EMBED, int NV, int WPB, bool PAIRS>
+__device__ __forceinline__ void dec_qkv_body(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
+                                             const uint8_t *__restrict__ emb_qs, const uint16_t *__restrict__ emb_d, int vocab, const float *__restrict__ norm_w, float eps,
+                                             const uint8_t *__restrict__ W, const float *__restrict__ bias, float *__restrict__ y, unsigned long long *__restrict__ ypairs, int N, int K,
+                                             KvWarm kw, int wg, int grid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[WPB];
     const ActLds a = carve_act(smem, K);
-    const int lane = threadIdx.x & 63, wave = blockIdx.x * WPB + (threadIdx.x >> 6), nb = K >> 8;
+    const int lane = threadIdx.x & 63, wave = wg * WPB + (threadIdx.x >> 6), nb = K >> 8;
+    const unsigned serial = PAIRS ? (unsigned)state->serial : 0u;
     const int T_warm = kw.kslab ? state->T : 0;      // a scalar load (uniform address): in flight under the prologue, waited for on lgkmcnt only
     int rows[ROWS];
 #pragma unroll
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
                 v.y = (float)((int)((b4 >> (8 + sh)) & 0xF) - 8) * d;
                 v.z = (float)((int)((b4 >> (16 + sh)) & 0xF) - 8) * d;
                 v.w = (float)((int)((b4 >> (24 + sh)) & 0xF) - 8) * d;
-                if (blockIdx.x == 0) *reinterpret_cast<float4 *>(x_out + d0) = v;
+                if (wg == 0) *reinterpret_cast<float4 *>(x_out + d0) = v;
             }
             xv[i] = v;
         }
@@ -445,10 +448,10 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
     // A speed matter only: nothing depends on where a workgroup runs.  The requests go out behind the weight rows and are consumed (xor) at the very end.
     uint32_t warm = 0;
     uint4 wq[KvWarm::PER_THREAD];
-    const int kvh_w = blockIdx.x & 7;
+    const int kvh_w = wg & 7;
     const bool warms = kw.kslab && kvh_w < kw.Hkv && T_warm > 0;
     if (warms) {
-        const int rank = blockIdx.x >> 3, nrank = (gridDim.x - kvh_w + 7) >> 3, T = min(T_warm, kw.cache_limit - 1);
+        const int rank = wg >> 3, nrank = (grid - kvh_w + 7) >> 3, T = min(T_warm, kw.cache_limit - 1);
         const int rowk = kw.D * 2 / 16, nk = T * rowk, rowv = (T + 7) >> 3, nv = kw.D * rowv;
 #pragma unroll
         for (int i = 0; i < KvWarm::PER_THREAD; ++i) {
@@ -466,14 +469,26 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
             const int rw = wave * ROWS + rr;
-            if (rw < N) y[rw] = bias ? out[rr] + bias[rw] : out[rr];
+            if (rw < N) {
+                const float r = bias ? out[rr] + bias[rw] : out[rr];
+                if constexpr (PAIRS) __hip_atomic_store(ypairs + rw, ((unsigned long long)serial << 32) | (unsigned long long)__float_as_uint(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else y[rw] = r;
+            }
         }
     }
     if (warms) {
 #pragma unroll
         for (int i = 0; i < KvWarm::PER_THREAD; ++i) warm ^= wq[i].x ^ wq[i].y ^ wq[i].z ^ wq[i].w;
-        if (kw.sink) kw.sink[blockIdx.x * (64 * WPB) + threadIdx.x] = warm;      // never set: the loads need a consumer the compiler can see
+        if (kw.sink) kw.sink[wg * (64 * WPB) + threadIdx.x] = warm;      // never set: the loads need a consumer the compiler can see
     }
+}
+
+template <int NSTEPS, int ROWS, bool EMBED, int NV, int WPB>
+__global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
+                                                      const uint8_t *__restrict__ emb_qs, const uint16_t *__restrict__ emb_d, int vocab,
+                                                      const float *__restrict__ norm_w, float eps, const uint8_t *__restrict__ W,
+                                                      const float *__restrict__ bias, float *__restrict__ y, int N, int K, KvWarm kw) {
+    dec_qkv_body<NSTEPS, ROWS, EMBED, NV, WPB, false>(state, x, x_out, emb_qs, emb_d, vocab, norm_w, eps, W, bias, y, nullptr, N, K, kw, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -995,11 +1010,14 @@ __device__ __forceinline__ void warm_weights(const WeightWarm *__restrict__ wt, 
 }
 // PAIRS (the merged attention + o-projection launch): the output row is stored as {value, DecodeState::serial} pairs for the o-projection workgroups of the same launch
 // to poll (dec_proj_body<.., POLL>); grid_attn = the workgroups of the launch that belong to the attention (the o-projection's come behind them)
-template <int D, int DS, bool PAIRS>
+// QPOLL: q | k | v arrive as pairs from the q|k|v role of the same launch (qkv_pairs); the speculative cache fetches go out first, the poll sits where the values are needed
+template <int D, int DS, bool PAIRS, bool QPOLL = false>
 __device__ __forceinline__ void dec_attn_pipe_body(const DecodeState *__restrict__ state, const float *__restrict__ qkv, const float *__restrict__ sin_t,
                                                    const float *__restrict__ cos_t, uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab,
                                                    float *__restrict__ out, unsigned long long *__restrict__ out_pairs, int Hq, int Hkv, int cache_limit, int vt_ld, int flags,
-                                                   int attn_groups, const WeightWarm *__restrict__ ww, int grid_attn) {
+                                                   int attn_groups, const WeightWarm *__restrict__ ww, int grid_attn, int wg = -1,
+                                                   const unsigned long long *__restrict__ qkv_pairs = nullptr, int *__restrict__ poll_err = nullptr) {
+    if (wg < 0) wg = (int)blockIdx.x;
     constexpr int HALF = D / 2, DV = D / DS, NWK = (DV + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) uint16_t knew[D];
@@ -1007,7 +1025,7 @@ __device__ __forceinline__ void dec_attn_pipe_body(const DecodeState *__restrict
     const int gsize = Hq / Hkv, per_kv = gsize * DS;
     int kvh, sub;
     if (flags & 1) {
-        const int col = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int col = wg & 7, idx = wg >> 3;
         kvh = (idx / per_kv) * 8 + col; sub = idx % per_kv;
         // warming workgroups (only when the layer has a table): the extra ones behind the attention's grid, and -- on an XCD column no K/V head lives on -- the attention slots too
         const bool col_dead = col >= Hkv;
@@ -1017,7 +1035,7 @@ __device__ __forceinline__ void dec_attn_pipe_body(const DecodeState *__restrict
             warm_weights(ww, smem, col, slot, nw);
             return;
         }
-    } else { kvh = blockIdx.x / per_kv; sub = blockIdx.x % per_kv; }
+    } else { kvh = wg / per_kv; sub = wg % per_kv; }
     if (kvh >= Hkv) return;
     const int gh = sub / DS, vdim0 = (sub % DS) * DV;
     const int head = kvh * gsize + gh;
@@ -1030,9 +1048,14 @@ __device__ __forceinline__ void dec_attn_pipe_body(const DecodeState *__restrict
     const int T_raw = state->T;
     const unsigned serial = PAIRS ? (unsigned)state->serial : 0u;
     float qa = 0.0f, qb = 0.0f, sn = 0.0f, cs = 0.0f;
-    if (tid < HALF) { const float *qp = qkv + head * D; qa = qp[tid]; qb = qp[tid + HALF]; sn = sin_t[tid]; cs = cos_t[tid]; }
-    else if (tid < D) { const float *kp = qkv + HD + kvh * D; qa = kp[tid - HALF]; qb = kp[tid]; sn = sin_t[tid - HALF]; cs = cos_t[tid - HALF]; }
-    else if (tid < 2 * D) qa = qkv[HD + KVD + kvh * D + (tid - D)];
+    if constexpr (!QPOLL) {
+        if (tid < HALF) { const float *qp = qkv + head * D; qa = qp[tid]; qb = qp[tid + HALF]; sn = sin_t[tid]; cs = cos_t[tid]; }
+        else if (tid < D) { const float *kp = qkv + HD + kvh * D; qa = kp[tid - HALF]; qb = kp[tid]; sn = sin_t[tid - HALF]; cs = cos_t[tid - HALF]; }
+        else if (tid < 2 * D) qa = qkv[HD + KVD + kvh * D + (tid - D)];
+    } else {
+        if (tid < HALF) { sn = sin_t[tid]; cs = cos_t[tid]; }
+        else if (tid < D) { sn = sin_t[tid - HALF]; cs = cos_t[tid - HALF]; }
+    }
     const uint64_t etab_v = expf_tab_fetch();
     __builtin_amdgcn_sched_barrier(0);
     PipeRegs<D, DV> R;
@@ -1055,6 +1078,21 @@ __device__ __forceinline__ void dec_attn_pipe_body(const DecodeState *__restrict
         pipe_fetch_v<D, DV>(R, vslab, vt_ld, kvh * D + vdim0, pw, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (QPOLL) {      // this thread's one or two values of the q | k | v row, from the q|k|v role's pairs
+        const unsigned epoch = (unsigned)state->serial;
+        const int ia = tid < HALF ? head * D + tid : (tid < D ? HD + kvh * D + tid - HALF : HD + KVD + kvh * D + (tid - D));
+        const int ib = tid < D ? ia + HALF : ia;
+        if (tid < 2 * D) {
+            int polls = 0;
+            for (;;) {
+                const unsigned long long ea = __hip_atomic_load(qkv_pairs + ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long eb = __hip_atomic_load(qkv_pairs + ib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(ea >> 32) == epoch && (unsigned)(eb >> 32) == epoch) { qa = __uint_as_float((unsigned)ea); qb = __uint_as_float((unsigned)eb); break; }
+                if (++polls > (1 << 18)) { __hip_atomic_store(poll_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    }
     if (tid < HALF) {
         L.qs[tid] = __fmaf_rn(qa, cs, -(qb * sn));
         L.qs[tid + HALF] = __fmaf_rn(qa, sn, qb * cs);
@@ -1102,6 +1140,32 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_attn_oproj_kernel(const Decod
     else dec_proj_body<1, 2, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, (int)blockIdx.x - P.grid_attn, P.W, P.residual, P.y, P.N, P.K);
 }
 
+
+// q|k|v projection + attention + o-projection of a layer in ONE launch: workgroups [0, grid_q) run dec_qkv_kernel<1, 2, EMBED, 1, 8>'s body and publish q | k | v as pairs, the
+// attention's workgroups behind them send their speculative cache fetches and poll those pairs, the o-projection's behind those poll the attention's output.  Producers always
+// have the lower workgroup indices.
+struct QkvFront { const float *x; float *x_out; const uint8_t *emb_qs; const uint16_t *emb_d; const float *norm_w; const uint8_t *W; const float *bias; unsigned long long *pairs;
+                  float eps; int vocab, N, K, grid_q; KvWarm kw; };
+template <int D, int DS, bool EMBED>
+__global__ __launch_bounds__(DEC_PIPE_NT) void dec_qkv_attn_oproj_kernel(const DecodeState *__restrict__ state, const float *__restrict__ sin_t, const float *__restrict__ cos_t,
+                                                                         uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab, int Hq, int Hkv, int cache_limit, int vt_ld, int flags,
+                                                                         int attn_groups, const WeightWarm *__restrict__ ww, const QkvFront F, const OProjRole P) {
+    const int b = (int)blockIdx.x;
+    if (b < F.grid_q) {
+        if (threadIdx.x >= 512) return;
+        dec_qkv_body<1, 2, EMBED, 1, 8, true>(state, F.x, F.x_out, F.emb_qs, F.emb_d, F.vocab, F.norm_w, F.eps, F.W, F.bias, nullptr, F.pairs, F.N, F.K, F.kw, b, F.grid_q);
+        return;
+    }
+    if (b < F.grid_q + P.grid_attn) {
+        dec_attn_pipe_body<D, DS, true, true>(state, nullptr, sin_t, cos_t, kslab, vslab, nullptr, P.pairs, Hq, Hkv, cache_limit, vt_ld, flags, attn_groups, ww, P.grid_attn,
+                                              b - F.grid_q, F.pairs, P.poll_err);
+        return;
+    }
+    if (threadIdx.x >= 512) return;
+    const int wo = b - F.grid_q - P.grid_attn;
+    if (P.rows == 1) dec_proj_body<1, 1, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, P.residual, P.y, P.N, P.K);
+    else dec_proj_body<1, 2, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, P.residual, P.y, P.N, P.K);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // dec_head: x -> RMSNorm -> Q8_0 -> tied lm_head rows (Q4_0 planes) -> logits, plus this workgroup's (max, first index)
@@ -1676,6 +1740,16 @@ bool decode_merges_o(const DecodeCtx &c) {
     if ((c.heads * c.D) > 2048 || (c.heads * c.D) % 256) return false;      // the projection's register form (dec_proj_kernel<1, ..>: rows of at most eight super-blocks)
     return (c.D == 128 ? merged_o_lds<128>(c) : merged_o_lds<64>(c)) <= (size_t)(160 * 1024 - 2 * c.D * 2 - 64);
 }
+// ... and the q|k|v projection in front of it (merge_o = 3): hidden sizes the projection's register form covers, a q|k|v grid that keeps the XCD columns of the launch
+template <int D>
+static size_t merged_front_lds(const DecodeCtx &c) { return std::max(merged_o_lds<D>(c), fused_lds_bytes<1, 2>(c.H, false, 8)); }
+static bool decode_merges_front(const DecodeCtx &c, const DecodeLayer &L, int li) {
+    // (not layer 0: its q|k|v role also writes the embedding row that the o-projection adds back -- a plain store another workgroup of the same launch would read)
+    if (li == 0 || c.merge_o != 3 || !c.qkv_pairs || !decode_merges_o(c) || c.H > 2048 || c.H % 256) return false;
+    const int grid_q = ((L.qkv_N + 1) / 2 + 7) / 8;
+    if (grid_q & 7) return false;
+    return (c.D == 128 ? merged_front_lds<128>(c) : merged_front_lds<64>(c)) <= (size_t)(160 * 1024 - 2 * c.D * 2 - 64);
+}
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st) {
     if ((c.D != 128 && c.D != 64) || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
     float *x = c.x0, *t = c.x1;
@@ -1684,6 +1758,30 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
     switch (which) {
     case 0:
     {
+        if (decode_merges_front(c, L, li)) {
+            uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.kv_heads * c.D * c.vt_ld;
+            const int flags = c.attn_flags, ds = 2;
+            const int grid_a0 = (flags & 1) ? dec_attn_grid(c.heads, c.kv_heads, ds) : c.heads * ds, attn_groups = grid_a0 / 8;
+            const WeightWarm *ww = (flags & 1) && !(flags & 4) && c.warm_tab ? c.warm_tab + li : nullptr;
+            const int grid_attn = grid_a0 + (ww ? 8 * std::max(8, WeightWarm::GROUPS - attn_groups) : 0);      // the attention's workgroups and, behind them, the warming ones
+            const int grid_q = ((L.qkv_N + 1) / 2 + 7) / 8;
+            const int rows = 1, Ko = c.heads * c.D, grid_o = ((c.H + rows - 1) / rows + 7) / 8;
+            KvWarm kw{nullptr, nullptr, nullptr, c.kv_heads, c.D, c.kv_heads * c.D, c.vt_ld, c.cache_limit};
+            if ((flags & 8) && (flags & 1) && c.kv_heads <= 8) { kw.kslab = kl; kw.vslab = vl; }
+            const QkvFront F{x, x, c.emb_qs, c.emb_d, L.in_norm, L.Wqkv, L.bqkv, c.qkv_pairs + (size_t)li * L.qkv_N, c.eps, c.vocab, L.qkv_N, c.H, grid_q, kw};
+            const OProjRole P{L.Wo, x, t, c.attn_pairs + (size_t)li * Ko, c.poll_err, c.H, Ko, grid_attn, rows};
+            const size_t plds = c.D == 128 ? merged_front_lds<128>(c) : merged_front_lds<64>(c);
+#define FRONT_CASE(DD, EMB)                                                                                                                                   \
+    {                                                                                                                                                         \
+        rc = allow_lds(dec_qkv_attn_oproj_kernel<DD, 2, EMB>, plds);                                                                                          \
+        if (rc) return rc;                                                                                                                                    \
+        hipLaunchKernelGGL((dec_qkv_attn_oproj_kernel<DD, 2, EMB>), dim3(grid_q + grid_attn + grid_o), dim3(DEC_PIPE_NT), plds, st, c.state, c.cur_sin, c.cur_cos, kl, vl, c.heads, \
+                           c.kv_heads, c.cache_limit, c.vt_ld, flags, attn_groups, ww, F, P);                                                                 \
+    }
+            if (c.D == 128) FRONT_CASE(128, false) else FRONT_CASE(64, false)
+#undef FRONT_CASE
+            return MH_LAUNCH_OK("dec_qkv_attn_oproj");
+        }
         // bit 3 of the attention flags (set by default): dec_qkv warms the L2 with the layer's cache rows for the attention launch that follows
         const int aflags = c.attn_flags;
         KvWarm kw{nullptr, nullptr, nullptr, c.kv_heads, c.D, c.kv_heads * c.D, c.vt_ld, c.cache_limit};
@@ -1695,6 +1793,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         return rc;
     }
     case 1: {
+        if (decode_merges_front(c, L, li)) return MLLM_HIP_OK;      // done inside the q|k|v launch
         uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.kv_heads * c.D * c.vt_ld;
         const int nslots = decode_lds_slots(c.cache_limit, c.D, DEC_ATTN_NT, 2, true);
         const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
