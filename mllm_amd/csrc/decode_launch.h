@@ -48,6 +48,7 @@ struct DecodeCtx {
     // merged attention + o-projection launch (option "merge_o"): the attention's output row travels as {value, epoch} pairs, one row per layer, epoch = DecodeState::serial;
     // the o-projection's workgroups ride in the attention's launch, fetch their weight rows at once and poll the pairs (profiles/r04_seam_overlap_microbench.md)
     unsigned long long *attn_pairs;     // [n_layers][heads * D], all-ones when the state is armed
+    unsigned long long *x_pairs;        // [n_layers][H]: a layer's output row for the next layer's q|k|v role (and the o-projection's residual) when both ride in the down projection's launch (merge_o = 4)
     unsigned long long *qkv_pairs;      // [n_layers][(heads + 2 kv_heads) * D]: q | k | v for the attention role when the q|k|v projection rides in the same launch (merge_o = 3)
     int *poll_err;                      // set when a poll gave up (bounded spins): the step's results are then invalid and the host reports it
     int merge_o;

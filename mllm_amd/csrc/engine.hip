@@ -206,7 +206,7 @@ struct mllm_hip_model {
     float *pin_img = nullptr; size_t pin_img_bytes = 0;
     // fused decode path (kernels_decode.hip): device-side step state, per-step rotary rows, captured graph
     DecodeState *d_state = nullptr;
-    unsigned long long *qkv_pairs = nullptr;
+    unsigned long long *qkv_pairs = nullptr, *x_pairs = nullptr;
     unsigned long long *attn_pairs = nullptr;      // merged attention + o-projection launch: the attention's output rows as {value, epoch} pairs, [layers][heads * D]
     int *poll_err = nullptr;
     int *pin_err = nullptr;                        // page-locked word the flag is copied to with the step's other results
@@ -457,8 +457,8 @@ static int create_impl(M *m, const MllmFile &f) {
         EH(m->dalloc((uint8_t **)&m->fa_ws, wsb));
     }
     EH(m->dalloc(&m->d_state, sizeof(DecodeState)));
-    EH(m->dalloc(&m->attn_pairs, (size_t)c.layers * m->HD * 8)); EH(m->dalloc(&m->poll_err, 4)); EH(m->dalloc(&m->qkv_pairs, (size_t)c.layers * m->QKV * 8));
-    HH(hipMemsetAsync(m->qkv_pairs, 0xFF, (size_t)c.layers * m->QKV * 8, m->st));
+    EH(m->dalloc(&m->attn_pairs, (size_t)c.layers * m->HD * 8)); EH(m->dalloc(&m->poll_err, 4)); EH(m->dalloc(&m->qkv_pairs, (size_t)c.layers * m->QKV * 8)); EH(m->dalloc(&m->x_pairs, (size_t)c.layers * H * 8));
+    HH(hipMemsetAsync(m->qkv_pairs, 0xFF, (size_t)c.layers * m->QKV * 8, m->st)); HH(hipMemsetAsync(m->x_pairs, 0xFF, (size_t)c.layers * H * 8, m->st));
     HH(hipMemsetAsync(m->attn_pairs, 0xFF, (size_t)c.layers * m->HD * 8, m->st)); HH(hipMemsetAsync(m->poll_err, 0, 4, m->st));
     HH(hipHostMalloc((void **)&m->pin_err, 4)); *m->pin_err = 0;
     EH(m->dalloc(&m->dec_sin, (size_t)T * (m->D / 2) * 4)); EH(m->dalloc(&m->dec_cos, (size_t)T * (m->D / 2) * 4));
@@ -472,7 +472,7 @@ static int create_impl(M *m, const MllmFile &f) {
         d.Whead = (const uint8_t *)m->head.wd;
         d.x0 = m->h0; d.x1 = m->h1; d.qkv = m->qkv; d.act = m->act; d.logits = m->logits; d.fa_ws = (float *)m->fa_ws; d.part_val = m->part_val;
         d.part_idx = m->part_idx; d.tok_dev = m->tok_dev; d.history = m->history; d.rope_sin = m->dec_sin; d.rope_cos = m->dec_cos; d.cur_sin = m->cur_sin; d.cur_cos = m->cur_cos;
-        d.attn_pairs = m->attn_pairs; d.qkv_pairs = m->qkv_pairs; d.poll_err = m->poll_err; d.merge_o = option(OPT_MERGE_O) < 0 || option(OPT_MERGE_O) > 3 ? 3 : option(OPT_MERGE_O);      // 3 (default): q|k|v + attention + o-projection in one launch; 2: attention + o-projection; 1: that with two rows per wave; 0: five launches      // 2 (default): one row per wave of the projection role; 1: two (the stand-alone kernel's split)      // default on; option "merge_o" = 0 keeps the two launches      // as it stood when the model was created (the captured graph holds the choice)
+        d.attn_pairs = m->attn_pairs; d.qkv_pairs = m->qkv_pairs; d.x_pairs = m->x_pairs; d.poll_err = m->poll_err; d.merge_o = option(OPT_MERGE_O) < 0 || option(OPT_MERGE_O) > 4 ? 4 : option(OPT_MERGE_O);      // 4 (default): a layer's down projection + the next layer's q|k|v + attention + o-projection in one launch; 3: q|k|v + attention + o-projection; 2: attention + o-projection; 1: that with two rows per wave; 0: five launches per layer      // 2 (default): one row per wave of the projection role; 1: two (the stand-alone kernel's split)      // default on; option "merge_o" = 0 keeps the two launches      // as it stood when the model was created (the captured graph holds the choice)
         d.kslab = m->kslab; d.vslab = m->vslab; d.vt_ld = m->vt_ld; d.n_layers = c.layers; d.normed = m->normed; d.x80_qs = m->x80_qs; d.x80_d = m->x80_d;
         for (auto &L : m->layers) {
             DecodeLayer dl;
@@ -1015,7 +1015,7 @@ static int arm_decode(M *m) {
     HH(hipMemcpy(&tok, m->tok_dev, 4, hipMemcpyDeviceToHost));
     DecodeState st0 = {m->cache_len, 0, tok, 0};
     HH(hipMemcpy(m->d_state, &st0, sizeof(st0), hipMemcpyHostToDevice));
-    if (m->dctx.merge_o) { HH(hipMemset(m->attn_pairs, 0xFF, (size_t)m->c.layers * m->HD * 8)); HH(hipMemset(m->qkv_pairs, 0xFF, (size_t)m->c.layers * m->QKV * 8)); }      // no pair of an earlier run may carry an epoch this run will count up to      // no pair of an earlier run may carry an epoch this run will count up to
+    if (m->dctx.merge_o) { HH(hipMemset(m->attn_pairs, 0xFF, (size_t)m->c.layers * m->HD * 8)); HH(hipMemset(m->qkv_pairs, 0xFF, (size_t)m->c.layers * m->QKV * 8)); HH(hipMemset(m->x_pairs, 0xFF, (size_t)m->c.layers * m->c.hidden * 8)); }      // no pair of an earlier run may carry an epoch this run will count up to      // no pair of an earlier run may carry an epoch this run will count up to
     return 0;
 }
 

@@ -391,11 +391,12 @@ struct KvWarm {
 // ------------------------------------------------------------------------------------------------------------------------
 // PAIRS (the merged q|k|v + attention + o-projection launch): the rows go out as {value, DecodeState::serial} pairs for the attention's workgroups of the same launch;
 // wg / grid = this role's workgroup index and count (the stand-alone kernel passes its own block index and grid size)
-template <int NSTEPS, int ROWS, bool EMBED, int NV, int WPB, bool PAIRS>
+// XPOLL (four-role launch): the input row itself arrives as pairs from the previous layer's down-projection role (xpairs); the weight rows go out first
+template <int NSTEPS, int ROWS, bool EMBED, int NV, int WPB, bool PAIRS, bool XPOLL = false>
 __device__ __forceinline__ void dec_qkv_body(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
                                              const uint8_t *__restrict__ emb_qs, const uint16_t *__restrict__ emb_d, int vocab, const float *__restrict__ norm_w, float eps,
                                              const uint8_t *__restrict__ W, const float *__restrict__ bias, float *__restrict__ y, unsigned long long *__restrict__ ypairs, int N, int K,
-                                             KvWarm kw, int wg, int grid) {
+                                             KvWarm kw, int wg, int grid, const unsigned long long *__restrict__ xpairs = nullptr, int *__restrict__ poll_err = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[WPB];
     const ActLds a = carve_act(smem, K);
@@ -433,6 +434,28 @@ __device__ __forceinline__ void dec_qkv_body(const DecodeState *__restrict__ sta
         }
     }
     float4 wv[NV];
+    if constexpr (XPOLL) {
+        static_assert(NSTEPS == 1 && NV == 1 && !EMBED, "the polled form: short rows, one quant block per wave");
+        issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+        load_row<NV, WPB>(wv, norm_w, K);
+        __builtin_amdgcn_sched_barrier(0);
+        const int d = threadIdx.x * 4;
+        xv[0] = make_float4(0, 0, 0, 0);
+        if (d < K) {
+            const unsigned long long *p = xpairs + d;
+            unsigned long long e0, e1, e2, e3;
+            int polls = 0;
+            for (;;) {
+                e0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); e1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); e3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(e0 >> 32) == serial && (unsigned)(e1 >> 32) == serial && (unsigned)(e2 >> 32) == serial && (unsigned)(e3 >> 32) == serial) break;
+                if (++polls > (1 << 18)) { __hip_atomic_store(poll_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            xv[0] = make_float4(__uint_as_float((unsigned)e0), __uint_as_float((unsigned)e1), __uint_as_float((unsigned)e2), __uint_as_float((unsigned)e3));
+        } else wv[0] = make_float4(0, 0, 0, 0);
+        wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
+    } else {
     if (EMBED) load_row<NV, WPB>(wv, norm_w, K);
     else load_rows2<NV, WPB>(xv, wv, x, norm_w, K);
     __builtin_amdgcn_sched_barrier(0);
@@ -441,6 +464,7 @@ __device__ __forceinline__ void dec_qkv_body(const DecodeState *__restrict__ sta
 #endif
     wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
     if (!(MLLM_HIP_EARLY_ROWS && NSTEPS == 1)) issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);   // long rows after the prologue: see dec_gateup_kernel
+    }
     __builtin_amdgcn_sched_barrier(0);
     STAMPV(15, (unsigned long long)(__builtin_amdgcn_s_getreg(0x1814) & 15));
     // Warm THIS XCD's L2 with the cache rows the attention kernel -- the next launch -- reads through one CU per head: its workgroups for K/V head k carry
@@ -775,7 +799,8 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_blk_kernel(const float *_
 // sets *poll_err and the workgroup goes on with what it has (the host reports the step as failed).
 template <int NSTEPS, int ROWS, int WPB, bool POLL>
 __device__ __forceinline__ void dec_proj_body(const float *__restrict__ xin, const unsigned long long *__restrict__ xpairs, unsigned epoch, int *__restrict__ poll_err, int wg,
-                                              const uint8_t *__restrict__ W, const float *__restrict__ residual, float *__restrict__ y, int N, int K) {
+                                              const uint8_t *__restrict__ W, const float *__restrict__ residual, float *__restrict__ y, int N, int K,
+                                              const unsigned long long *__restrict__ res_pairs = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ActLds a = carve_act(smem, K);
     constexpr int NQ = (NSTEPS * 8 + WPB - 1) / WPB;
@@ -834,7 +859,12 @@ __device__ __forceinline__ void dec_proj_body(const float *__restrict__ xin, con
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
             const int rw = wave * ROWS + rr;
-            if (rw < N) y[rw] = residual ? out[rr] + residual[rw] : out[rr];
+            if (rw < N) {
+                // res_pairs (four-role launch): the residual row was written by the down-projection role of THIS launch -- read it from its pairs (all of them have been seen
+                // with this epoch by the q|k|v role before the attention could run), not through a plain load
+                const float rsd = POLL && res_pairs ? __uint_as_float((unsigned)__hip_atomic_load(res_pairs + rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : (residual ? residual[rw] : 0.0f);
+                y[rw] = (residual || (POLL && res_pairs)) ? out[rr] + rsd : out[rr];
+            }
         }
     }
 }
@@ -854,9 +884,10 @@ static inline int pjb_rows_per_wg(int N, int K) { return std::max(1, std::min(st
 static inline size_t pjb_lds_bytes(int K, int rpw) {
     return ((gub_act_bytes(K) + 15) & ~(size_t)15) + pjb_stage_bytes(rpw, K / 256) + (size_t)rpw * (K / 256) * Q4K_SLOTS * 8;
 }
-template <int WPB, int NQ>
-__global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__restrict__ xin, const uint8_t *__restrict__ W, const float *__restrict__ residual,
-                                                                float *__restrict__ y, int N, int K, int RPW) {
+// OUTP (the down-projection role of the four-role launch): besides y the rows go out as {value, epoch} pairs for the next layer's q|k|v role of the same launch
+template <int WPB, int NQ, bool OUTP>
+__device__ __forceinline__ void dec_proj_blk_body(const float *__restrict__ xin, const uint8_t *__restrict__ W, const float *__restrict__ residual, float *__restrict__ y, int N,
+                                                  int K, int RPW, int wg, unsigned long long *__restrict__ ypairs, unsigned epoch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nb = K >> 8;
     ActLds a;
@@ -866,7 +897,7 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__r
     a.xf = nullptr;
     a.qstride = GUB_QSTRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = min((int)blockIdx.x * RPW, N - RPW);     // the last workgroup re-does rows of its neighbour (same values)
+    const int row0 = min(wg * RPW, N - RPW);     // the last workgroup re-does rows of its neighbour (same values)
     char *stage = smem + ((gub_act_bytes(K) + 15) & ~(size_t)15);
     float2 *tab = reinterpret_cast<float2 *>(stage + pjb_stage_bytes(RPW, nb));
     float4 v[NQ];
@@ -911,9 +942,18 @@ __global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__r
         const int nr = RPW - 4 * wid < 4 ? RPW - 4 * wid : 4;
         const float res = q4k_chain(tab + (size_t)4 * wid * nb * Q4K_SLOTS, nb, nb, nr, lane);
         const int rw = row0 + 4 * wid + (lane >> 4);
-        if ((lane & 15) == 8 && (lane >> 4) < nr) y[rw] = residual ? res + residual[rw] : res;
+        if ((lane & 15) == 8 && (lane >> 4) < nr) {
+            const float r = residual ? res + residual[rw] : res;
+            y[rw] = r;
+            if constexpr (OUTP) __hip_atomic_store(ypairs + rw, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     GSTAMP2(7);
+}
+template <int WPB, int NQ>
+__global__ __launch_bounds__(64 * WPB) void dec_proj_blk_kernel(const float *__restrict__ xin, const uint8_t *__restrict__ W, const float *__restrict__ residual,
+                                                                float *__restrict__ y, int N, int K, int RPW) {
+    dec_proj_blk_body<WPB, NQ, false>(xin, W, residual, y, N, K, RPW, (int)blockIdx.x, nullptr, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1165,6 +1205,39 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_qkv_attn_oproj_kernel(const D
     const int wo = b - F.grid_q - P.grid_attn;
     if (P.rows == 1) dec_proj_body<1, 1, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, P.residual, P.y, P.N, P.K);
     else dec_proj_body<1, 2, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, P.residual, P.y, P.N, P.K);
+}
+
+// Layer l's down projection and layer l + 1's q|k|v projection + attention + o-projection in ONE launch.  The down projection's 256 workgroups fill the chip (the launch's LDS
+// size leaves one workgroup per CU); as they leave, the q|k|v role's workgroups are dispatched, send their weight rows and poll the layer's output row (pairs), and so on down
+// the chain -- what disappears is the drain / launch gap between the two kernels.  The o-projection's residual is that same output row: read from the pairs, not through a plain
+// load of what another workgroup of this launch stored.
+struct DownRole { const float *xin; const uint8_t *W; const float *residual; float *y; unsigned long long *ypairs; int N, K, rpw, grid_d; };
+template <int D, int DS, int NQ>
+__global__ __launch_bounds__(DEC_PIPE_NT) void dec_down_front_kernel(const DecodeState *__restrict__ state, const float *__restrict__ sin_t, const float *__restrict__ cos_t,
+                                                                     uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab, int Hq, int Hkv, int cache_limit, int vt_ld, int flags,
+                                                                     int attn_groups, const WeightWarm *__restrict__ ww, const DownRole Dn, const QkvFront F, const OProjRole P) {
+    int b = (int)blockIdx.x;
+    if (b < Dn.grid_d) {
+        if (threadIdx.x >= 512) return;
+        dec_proj_blk_body<8, NQ, true>(Dn.xin, Dn.W, Dn.residual, Dn.y, Dn.N, Dn.K, Dn.rpw, b, Dn.ypairs, (unsigned)state->serial);
+        return;
+    }
+    b -= Dn.grid_d;
+    if (b < F.grid_q) {
+        if (threadIdx.x >= 512) return;
+        dec_qkv_body<1, 2, false, 1, 8, true, true>(state, nullptr, nullptr, F.emb_qs, F.emb_d, F.vocab, F.norm_w, F.eps, F.W, F.bias, nullptr, F.pairs, F.N, F.K, F.kw, b, F.grid_q,
+                                                    Dn.ypairs, P.poll_err);
+        return;
+    }
+    if (b < F.grid_q + P.grid_attn) {
+        dec_attn_pipe_body<D, DS, true, true>(state, nullptr, sin_t, cos_t, kslab, vslab, nullptr, P.pairs, Hq, Hkv, cache_limit, vt_ld, flags, attn_groups, ww, P.grid_attn,
+                                              b - F.grid_q, F.pairs, P.poll_err);
+        return;
+    }
+    if (threadIdx.x >= 512) return;
+    const int wo = b - F.grid_q - P.grid_attn;
+    if (P.rows == 1) dec_proj_body<1, 1, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, nullptr, P.y, P.N, P.K, Dn.ypairs);
+    else dec_proj_body<1, 2, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, nullptr, P.y, P.N, P.K, Dn.ypairs);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1745,10 +1818,23 @@ template <int D>
 static size_t merged_front_lds(const DecodeCtx &c) { return std::max(merged_o_lds<D>(c), fused_lds_bytes<1, 2>(c.H, false, 8)); }
 static bool decode_merges_front(const DecodeCtx &c, const DecodeLayer &L, int li) {
     // (not layer 0: its q|k|v role also writes the embedding row that the o-projection adds back -- a plain store another workgroup of the same launch would read)
-    if (li == 0 || c.merge_o != 3 || !c.qkv_pairs || !decode_merges_o(c) || c.H > 2048 || c.H % 256) return false;
+    if (li == 0 || c.merge_o < 3 || !c.qkv_pairs || !decode_merges_o(c) || c.H > 2048 || c.H % 256) return false;
     const int grid_q = ((L.qkv_N + 1) / 2 + 7) / 8;
     if (grid_q & 7) return false;
     return (c.D == 128 ? merged_front_lds<128>(c) : merged_front_lds<64>(c)) <= (size_t)(160 * 1024 - 2 * c.D * 2 - 64);
+}
+// ... and the previous layer's down projection in front of those (merge_o = 4): layer li's down projection carries layer li + 1's q|k|v + attention + o-projection
+template <int D>
+static size_t merged_chain_lds(const DecodeCtx &c) { return std::max(merged_front_lds<D>(c), pjb_lds_bytes(c.I, pjb_rows_per_wg(c.H, c.I))); }
+static bool decode_merges_chain(const DecodeCtx &c, const DecodeLayer *layers, int li) {
+    if (c.merge_o != 4 || !c.x_pairs || li < 0 || li + 1 >= c.n_layers || c.I % 256) return false;
+    DecodeCtx f = c;
+    f.merge_o = 3;
+    if (!decode_merges_front(f, layers[li + 1], li + 1)) return false;
+    const int NS = (c.I / 256 + 7) / 8, rpw = pjb_rows_per_wg(c.H, c.I), grid_d = (c.H + rpw - 1) / rpw;
+    const int pjb_min_ns = option(OPT_PJB_MIN_NS) >= 0 ? option(OPT_PJB_MIN_NS) : 3;
+    if (!(NS >= pjb_min_ns && NS <= 5 && layers[li].Wdown_raw && option(OPT_NO_PJB) <= 0 && c.H >= rpw) || (grid_d & 7)) return false;
+    return (c.D == 128 ? merged_chain_lds<128>(c) : merged_chain_lds<64>(c)) <= (size_t)(160 * 1024 - 2 * c.D * 2 - 64);
 }
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st) {
     if ((c.D != 128 && c.D != 64) || c.heads % c.kv_heads) return MLLM_HIP_ERR_SHAPE;
@@ -1758,6 +1844,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
     switch (which) {
     case 0:
     {
+        if (decode_merges_chain(c, layers, li - 1)) return MLLM_HIP_OK;      // this layer's q|k|v + attention + o-projection rode in the previous layer's down-projection launch
         if (decode_merges_front(c, L, li)) {
             uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.kv_heads * c.D * c.vt_ld;
             const int flags = c.attn_flags, ds = 2;
@@ -1793,7 +1880,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         return rc;
     }
     case 1: {
-        if (decode_merges_front(c, L, li)) return MLLM_HIP_OK;      // done inside the q|k|v launch
+        if (decode_merges_chain(c, layers, li - 1) || decode_merges_front(c, L, li)) return MLLM_HIP_OK;      // done inside the q|k|v launch (or the previous down-projection's)
         uint16_t *kl = c.kslab + (size_t)li * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)li * c.kv_heads * c.D * c.vt_ld;
         const int nslots = decode_lds_slots(c.cache_limit, c.D, DEC_ATTN_NT, 2, true);
         const size_t lds = decode_lds_bytes(c.cache_limit, c.D, DEC_ATTN_NT, 2, nslots, true);
@@ -1862,6 +1949,35 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
         NS_DISPATCH(c.H, rc = launch_gateup<NS>(L, c, t, st));
         return rc;
     case 4:
+        if (decode_merges_chain(c, layers, li)) {
+            const int ln = li + 1;
+            const DecodeLayer &Ln = layers[ln];
+            uint16_t *kl = c.kslab + (size_t)ln * c.cache_limit * c.kv_heads * c.D, *vl = c.vslab + (size_t)ln * c.kv_heads * c.D * c.vt_ld;
+            const int flags = c.attn_flags, ds = 2;
+            const int grid_a0 = (flags & 1) ? dec_attn_grid(c.heads, c.kv_heads, ds) : c.heads * ds, attn_groups = grid_a0 / 8;
+            const WeightWarm *ww = (flags & 1) && !(flags & 4) && c.warm_tab ? c.warm_tab + ln : nullptr;
+            const int grid_attn = grid_a0 + (ww ? 8 * std::max(8, WeightWarm::GROUPS - attn_groups) : 0);
+            const int grid_q = ((Ln.qkv_N + 1) / 2 + 7) / 8, rows = 1, Ko = c.heads * c.D, grid_o = ((c.H + rows - 1) / rows + 7) / 8;
+            const int rpw = pjb_rows_per_wg(c.H, c.I), grid_d = (c.H + rpw - 1) / rpw;
+            KvWarm kw{nullptr, nullptr, nullptr, c.kv_heads, c.D, c.kv_heads * c.D, c.vt_ld, c.cache_limit};
+            if ((flags & 8) && (flags & 1) && c.kv_heads <= 8) { kw.kslab = kl; kw.vslab = vl; }
+            const DownRole Dn{c.act, L.Wdown_raw, t, x, c.x_pairs + (size_t)li * c.H, c.H, c.I, rpw, grid_d};
+            const QkvFront F{nullptr, nullptr, c.emb_qs, c.emb_d, Ln.in_norm, Ln.Wqkv, Ln.bqkv, c.qkv_pairs + (size_t)ln * Ln.qkv_N, c.eps, c.vocab, Ln.qkv_N, c.H, grid_q, kw};
+            const OProjRole P{Ln.Wo, nullptr, t, c.attn_pairs + (size_t)ln * Ko, c.poll_err, c.H, Ko, grid_attn, rows};
+            const size_t plds = c.D == 128 ? merged_chain_lds<128>(c) : merged_chain_lds<64>(c);
+#define CHAIN_CASE(DD, NSV)                                                                                                                                   \
+    {                                                                                                                                                         \
+        rc = allow_lds(dec_down_front_kernel<DD, 2, NSV>, plds);                                                                                              \
+        if (rc) return rc;                                                                                                                                    \
+        hipLaunchKernelGGL((dec_down_front_kernel<DD, 2, NSV>), dim3(grid_d + grid_q + grid_attn + grid_o), dim3(DEC_PIPE_NT), plds, st, c.state, c.cur_sin, c.cur_cos, kl, vl,      \
+                           c.heads, c.kv_heads, c.cache_limit, c.vt_ld, flags, attn_groups, ww, Dn, F, P);                                                    \
+    }
+            const int NSd = (c.I / 256 + 7) / 8;
+            if (c.D == 128) { if (NSd == 3) CHAIN_CASE(128, 3) else if (NSd == 4) CHAIN_CASE(128, 4) else CHAIN_CASE(128, 5) }
+            else { if (NSd == 3) CHAIN_CASE(64, 3) else if (NSd == 4) CHAIN_CASE(64, 4) else CHAIN_CASE(64, 5) }
+#undef CHAIN_CASE
+            return MH_LAUNCH_OK("dec_down_front");
+        }
         NS_DISPATCH(c.I, rc = (launch_proj<NS>(L.Wdown, L.Wdown_raw, c.act, t, x, c.H, c.I, st)));
         return rc;
     }

@@ -141,7 +141,7 @@ def test_one_token_prompt_is_a_prefill(tiny_model):
 
 
 def test_merged_attention_and_o_projection_launch_changes_nothing(tiny_gold, tmp_path):
-    """The decode step's q|k|v projection, attention and o-projection share one launch by default (option merge_o = 3: the attention's workgroups ride behind the projection's and
+    """A layer's down projection and the next layer's q|k|v projection, attention and o-projection share one launch by default (option merge_o = 4; 3: without the down projection: the attention's workgroups ride behind the projection's and
     poll its q | k | v rows, the o-projection's ride behind the attention's and poll its output row, each handed over as {value, epoch} pairs; 2 / 1: attention + o-projection only;
     0: five launches per layer): ids and every logit of 24 steps equal the reference's golden run in every form, and a second generation on the re-armed state (epochs start
     over) repeats the first."""
@@ -150,7 +150,7 @@ def test_merged_attention_and_o_projection_launch_changes_nothing(tiny_gold, tmp
     path = weights.qwen2vl_file(cfg, cache_dir=str(tmp_path))
     pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
     try:
-        for mode in (0, 1, 2, 3):
+        for mode in (0, 1, 2, 3, 4):
             lib.set_option("merge_o", mode)
             m = lib.Qwen2VL(cfg, path)
             for _ in range(2):
