@@ -1827,7 +1827,7 @@ static bool decode_merges_front(const DecodeCtx &c, const DecodeLayer &L, int li
 template <int D>
 static size_t merged_chain_lds(const DecodeCtx &c) { return std::max(merged_front_lds<D>(c), pjb_lds_bytes(c.I, pjb_rows_per_wg(c.H, c.I))); }
 static bool decode_merges_chain(const DecodeCtx &c, const DecodeLayer *layers, int li) {
-    if (c.merge_o != 4 || !c.x_pairs || li < 0 || li + 1 >= c.n_layers || c.I % 256) return false;
+    if (c.merge_o < 4 || !c.x_pairs || li < 0 || li + 1 >= c.n_layers || c.I % 256) return false;
     DecodeCtx f = c;
     f.merge_o = 3;
     if (!decode_merges_front(f, layers[li + 1], li + 1)) return false;
