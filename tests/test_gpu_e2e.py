@@ -171,6 +171,33 @@ def test_merged_attention_and_o_projection_launch_changes_nothing(tiny_gold, tmp
         lib.set_option("merge_o", -1)
 
 
+def test_decode_without_the_captured_graph(tmp_path):
+    """MLLM_HIP_NO_GRAPH=1 (what the profiling scripts set): the decode step's launches -- the shared ones included -- issued one by one instead of replayed from the captured
+    hipGraph give the same ids and logits (own process: the variable is read when the model is created)."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, os, sys\n"
+        "from mllm_amd import lib, synth\n"
+        "from mllm_amd import synthfile as weights\n"
+        "cfg = synth.qwen2vl_tiny()\n"
+        "g = np.load(os.path.join(sys.argv[1], 'qwen2vl_tiny.npz'))\n"
+        "m = lib.Qwen2VL(cfg, weights.qwen2vl_file(cfg, cache_dir=sys.argv[2]))\n"
+        "pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)\n"
+        "tok, logits, _ = m.prefill(ids, pix, grid)\n"
+        "toks, rows = [tok], [logits]\n"
+        "for s in range(1, 12):\n"
+        "    tok, logits, _ = m.decode(tok); toks.append(tok); rows.append(logits)\n"
+        "assert toks == g['tokens'][:12].tolist() and np.array_equal(np.stack(rows), g['logits'][:12])\n"
+        "gen, _ = m.generate(tok, 8)\n"
+        "assert gen.tolist() == g['tokens'][12:20].tolist()\n"
+        "print('eager ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, os.path.join(root, "tests", "golden"), str(tmp_path)], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, MLLM_HIP_NO_GRAPH="1", PYTHONPATH=root))
+    assert out.returncode == 0 and "eager ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
 def test_generate_equals_stepwise_decode_and_clear_kvcache_resets(tiny_model):
     cfg, m = tiny_model
     pix, grid, ids = synth.qwen2vl_inputs(cfg, (8, 8), 6)
