@@ -10,7 +10,7 @@ cfg = synth.qwen2vl_2b()
 path = weights.qwen2vl_file(cfg)
 pix, grid, ids = synth.qwen2vl_inputs(cfg, (32, 32), 24)
 res = {}
-for mo, mq in ((0, 0), (4, 0), (5, 0), (4, 0), (5, 0)):
+for mo, mq in ((0, 0), (4, 0), (40, 0), (4, 0), (40, 0)):
     lib.set_option("merge_o", mo)
     m = lib.Qwen2VL(cfg, path)
     tok, logits, _ = m.prefill(ids, pix, grid)
