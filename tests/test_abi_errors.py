@@ -177,3 +177,40 @@ def test_linear_refuses_a_residual_with_an_fp16_output(L):
     for fn, args in ((L.mllm_hip_linear_q4kp_packed, (P, NULL, P, P, C.c_int(1), C.c_int64(64), P, C.c_int(16), C.c_int(64), C.c_int(256), NULL)),
                      (L.mllm_hip_linear_q4k_q8k, (P, NULL, P, P, P, P, C.c_int(1), C.c_int64(64), P, C.c_int(1), C.c_int(64), C.c_int(256), NULL))):
         assert fn(*args) == ERR_DTYPE
+
+
+def test_fused_run_entry_points_validate_before_launch(L):
+    """The lazy window's fused launches: shapes the kernels do not cover are refused by the launch AND by the host-side *_supported check the adapter asks first."""
+    from mllm_amd.ops import _RowFused
+    f, sup = L.mllm_hip_row_fused_launch, L.mllm_hip_row_fused_supported
+    assert f(NULL, NULL) == ERR_ARG and sup(NULL) == 0
+
+    def args(K=512, nseg=1, mode=0, N=(64, 64, 64), W=True, y=True, mul=True, post=False):
+        a = _RowFused()
+        a.xa, a.K, a.nseg, a.mode = 0x1000, K, nseg, mode
+        for i in range(min(nseg, 3)):
+            a.seg[i].W = 0x1000 if W else 0
+            a.seg[i].y = 0x1000 if y else 0
+            a.seg[i].N = N[i]
+            if post:
+                a.seg[i].post_out = 0x1000      # ... without post_add
+        if mode == 1 and mul:
+            a.mul_out = 0x1000
+        return a
+    for bad in (args(K=300), args(K=0), args(K=11264), args(nseg=0), args(nseg=4), args(W=False), args(y=False), args(post=True), args(mode=2), args(mode=1, nseg=1),
+                args(mode=1, nseg=2, N=(64, 32, 0)), args(mode=1, nseg=2, mul=False), args(nseg=2, N=(64, 0, 0))):
+        assert sup(C.byref(bad)) == 0 and f(C.byref(bad), NULL) in (ERR_SHAPE, ERR_ARG)
+    assert sup(C.byref(args())) == 1 and sup(C.byref(args(nseg=3))) == 1 and sup(C.byref(args(mode=1, nseg=2))) == 1
+    st = L.mllm_hip_fa2_decode_step_supported
+    assert st(C.c_int(10), C.c_int(12), C.c_int(2), C.c_int(128)) == 1 and st(C.c_int(0), C.c_int(4), C.c_int(4), C.c_int(64)) == 1
+    assert st(C.c_int(10), C.c_int(12), C.c_int(5), C.c_int(128)) == 0          # heads not a multiple of the K/V heads
+    assert st(C.c_int(10), C.c_int(12), C.c_int(2), C.c_int(80)) == 0           # head size the step kernel is not built for
+    assert st(C.c_int(-1), C.c_int(12), C.c_int(2), C.c_int(128)) == 0
+    assert st(C.c_int(200000), C.c_int(12), C.c_int(2), C.c_int(128)) == 0      # the score arrays of that many keys do not fit a CU's LDS
+    step = L.mllm_hip_fa2_decode_step
+    assert step(NULL, P, P, P, P, P, P, P, P, P, P, C.c_int(3), P, C.c_int(4), C.c_int(2), C.c_int(64), NULL) == ERR_ARG
+    r2 = L.mllm_hip_rope2_store2
+    assert r2(P, P, P, C.c_int(32), P, C.c_int(4), P, P, P, C.c_int(32), P, P, P, P, C.c_int(2), C.c_int(0), C.c_int(64), NULL) == OK        # no positions: nothing to do
+    assert r2(P, P, P, C.c_int(32), P, C.c_int(4), P, P, P, C.c_int(32), P, P, P, P, C.c_int(2), C.c_int(1), C.c_int(63), NULL) == ERR_SHAPE
+    assert r2(P, P, P, C.c_int(32), P, C.c_int(0), P, P, P, C.c_int(32), P, P, P, P, C.c_int(2), C.c_int(1), C.c_int(64), NULL) == ERR_SHAPE
+    assert L.mllm_hip_silu_rows(P, P, C.c_int64(0), C.c_int(13), NULL) == OK
