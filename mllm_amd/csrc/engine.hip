@@ -205,6 +205,9 @@ struct mllm_hip_model {
     hipEvent_t vup[2] = {nullptr, nullptr}, vfree[2] = {nullptr, nullptr};
     float *pin_img = nullptr; size_t pin_img_bytes = 0;
     // fused decode path (kernels_decode.hip): device-side step state, per-step rotary rows, captured graph
+    std::vector<float> mrope_host_s, mrope_host_c;      // forward_llm's M-RoPE tables on the host (kept alive across the asynchronous copies)
+    hipEvent_t mrope_host_free = nullptr;
+    int vrope_grid[3] = {0, 0, 0};                      // the grid m->vsin / m->vcos were made for
     DecodeState *d_state = nullptr;
     unsigned long long *qkv_pairs = nullptr, *x_pairs = nullptr;
     unsigned long long *attn_pairs = nullptr;      // merged attention + o-projection launch: the attention's output rows as {value, epoch} pairs, [layers][heads * D]
@@ -543,6 +546,7 @@ extern "C" int mllm_hip_model_create(const mllm_hip_model_config *cfg, const cha
         m->QKV = m->HD + 2 * m->KVD;
     }
     if (hipStreamCreate(&m->st) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&m->mrope_host_free, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&m->pin_tok), 2 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess || m->ld.init() != 0) {
         mllm_hip_model_destroy(m); return MLLM_HIP_ERR_HIP;
     }
@@ -595,6 +599,7 @@ extern "C" void mllm_hip_model_destroy(mllm_hip_model *m) {
     if (m->pin_err) (void)hipHostFree(m->pin_err);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->mrope_host_free) (void)hipEventDestroy(m->mrope_host_free);
     if (m->st) (void)hipStreamDestroy(m->st);
     delete m;
 }
@@ -769,11 +774,15 @@ static int forward_vision(M *m, const float *pix, const int32_t *meta, float *ou
             return MLLM_HIP_ERR_SHAPE;
         }
         {   // rotary tables (CPUVisionRoPE): rot_dim = head_dim/2
-            std::vector<float> s((size_t)N * (VD / 2)), co((size_t)N * (VD / 2));
-            EH(mllm_hip_vision_rope_table(meta[0], meta[1], meta[2], c.v_merge, VD / 2, s.data(), co.data()));
-            HH(hipMemcpyAsync(m->vsin, s.data(), s.size() * 4, hipMemcpyHostToDevice, st));
-            HH(hipMemcpyAsync(m->vcos, co.data(), co.size() * 4, hipMemcpyHostToDevice, st));
-            HH(hipStreamSynchronize(st));
+            // a grid's tables are a pure function of (t, h, w): kept on the device for the grid they were made for (a serving loop sees the same few grids again and again)
+            if (meta[0] != m->vrope_grid[0] || meta[1] != m->vrope_grid[1] || meta[2] != m->vrope_grid[2]) {
+                std::vector<float> s((size_t)N * (VD / 2)), co((size_t)N * (VD / 2));
+                EH(mllm_hip_vision_rope_table(meta[0], meta[1], meta[2], c.v_merge, VD / 2, s.data(), co.data()));
+                HH(hipMemcpyAsync(m->vsin, s.data(), s.size() * 4, hipMemcpyHostToDevice, st));
+                HH(hipMemcpyAsync(m->vcos, co.data(), co.size() * 4, hipMemcpyHostToDevice, st));
+                HH(hipStreamSynchronize(st));
+                for (int i = 0; i < 3; ++i) m->vrope_grid[i] = meta[i];
+            }
         }
         EH(mllm_hip_patch_gemm_f32(pix, m->patch_w, nullptr, m->vx, R, PE, V, st));
         EH(vision_blocks(m, N, NB, 1e-6f, m->lut_qgelu, true));
@@ -853,6 +862,7 @@ static int ensure_vision_buffers(M *m, const int32_t *meta, int NB = 1) {
     EH(m->dalloc(&m->vemb, (size_t)orows * ocols * 4, L));
     if (m->vkind == V_QWEN2VL) {
         EH(m->dalloc(&m->vsin, (size_t)N * (VD / 2) * 4, L)); EH(m->dalloc(&m->vcos, (size_t)N * (VD / 2) * 4, L));
+        m->vrope_grid[0] = m->vrope_grid[1] = m->vrope_grid[2] = 0;      // new blocks: the tables have to be made again
         EH(m->dalloc(&m->vm0, (size_t)orows * MM * 4, L));
     } else {
         EH(m->dalloc(&m->vpatch, (size_t)N * 3 * c.v_patch * c.v_patch * 4, L));
@@ -877,11 +887,15 @@ static int forward_llm(M *m, int S, const float *pos3) {
     hipStream_t st = m->st;
     if (T0 + S > c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + %d > %d)\n", T0, S, c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
     if (m->mrope) {   // M-RoPE tables for these S positions
-        std::vector<float> s((size_t)S * half), co((size_t)S * half);
+        // the host tables live in the model (they must outlive the copies): no synchronisation here -- this point comes right behind the vision tower's launches in an
+        // image prefill, and waiting for the stream would leave the device idle while the LLM's launches are only being issued
+        std::vector<float> &s = m->mrope_host_s, &co = m->mrope_host_c;
+        if (!s.empty()) HH(hipEventSynchronize(m->mrope_host_free));      // the previous forward's copies out of these vectors have been made (long ago)
+        s.resize((size_t)S * half); co.resize((size_t)S * half);
         EH(mllm_hip_mrope_table(c.rope_theta, D, pos3, S, c.mrope_section, 3, s.data(), co.data()));
         HH(hipMemcpyAsync(m->rope_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice, st));
         HH(hipMemcpyAsync(m->rope_cos, co.data(), co.size() * 4, hipMemcpyHostToDevice, st));
-        HH(hipStreamSynchronize(st));  // host vectors go out of scope
+        HH(hipEventRecord(m->mrope_host_free, st));
     } else {
         HH(hipMemcpyAsync(m->rope_sin, m->hf_sin.data() + (size_t)T0 * half, (size_t)S * half * 4, hipMemcpyHostToDevice, st));
         HH(hipMemcpyAsync(m->rope_cos, m->hf_cos.data() + (size_t)T0 * half, (size_t)S * half * 4, hipMemcpyHostToDevice, st));
