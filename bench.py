@@ -374,6 +374,29 @@ def main():
         ach = b_l / (ms_l * 1e-3) / 1e9
         kernels.append({"kernel": label, "us_per_launch": round(ms_l * 1e3, 3), "algorithmic_bytes_per_launch": int(b_l), "achieved_GBps": round(ach, 1),
                         "frac": round(ach / 8000.0, 4), "traffic_bytes_per_launch": (traffic.get(tkey) or {}).get("fetch_bytes_per_launch") if cfgname == "qwen2vl" else None})
+    # ---- the step launch by launch: a few more greedy steps run eagerly with a HIP event either side of every launch (mllm_hip_model_time_step).  Since round 4 most of
+    # the token is ONE kind of launch -- a layer's down projection + the next layer's q|k|v + attention + o-projection handing their rows over in flight -- which cannot
+    # be timed alone (its roles poll each other); this is its live figure, to be read beside the kernel trace's duration of the same kernel in the captured graph
+    step_launches, room = [], cfg.cache_limit - (S + W + K) - 1
+    if rank == 0 and min(8, room) >= 2:
+        b = {k: m.time_kernel(w, 1)[1] for k, w in (("qkv", 10), ("kv", 11), ("o_proj", 12), ("gateup", 13), ("down", 14))}
+        b["attn"] = b["kv"]
+        per_layer = b["qkv"] + b["o_proj"] + b["gateup"] + b["down"]
+        kinds, _ = m.time_step(int(toks[-1]), min(8, room))
+        if "o_proj" not in kinds and "attn" in kinds:
+            b["attn"] = b["kv"] + b["o_proj"]
+        b["front"] = b["qkv"] + b["kv"] + b["o_proj"]
+        b["chain"] = b["down"] + b["front"]
+        b["head"] = wbytes - cfg.layers * per_layer
+        b["next"] = 0
+        what = {"chain": "dec_down_front: down projection of layer l + q|k|v, attention and o-projection of layer l + 1 as roles of one launch",
+                "front": "q|k|v + attention + o-projection as roles of one launch", "attn": "attention (+ the o-projection's workgroups when merged)",
+                "qkv": "RMSNorm + Q8_K + q|k|v GEMV", "o_proj": "o-projection GEMV + residual", "gateup": "RMSNorm + Q8_K + gate|up GEMV + SiLU*mul",
+                "down": "Q8_K + down GEMV + residual", "head": "model.norm + lm_head GEMV + argmax partials", "next": "argmax + state advance"}
+        for k, (us_l, n_l) in sorted(kinds.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            ach = b[k] / (us_l * 1e-6) / 1e9 if us_l > 0 else 0.0
+            step_launches.append({"launch": k, "what": what[k], "launches_per_token": n_l, "us_per_launch": round(us_l, 3), "us_per_token": round(us_l * n_l, 1),
+                                  "algorithmic_bytes_per_launch": int(b[k]), "achieved_GBps": round(ach, 1), "frac": round(ach / 8000.0, 4)})
     roofline = {"bound": "hbm", "achieved": round(tok_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(tok_gbs / 8000.0, 4),
                 "traffic": (traffic.get("whole_token") or {}).get("fetch_bytes_per_token") if cfgname == "qwen2vl" else None,
                 "scope": "whole decode token: algorithmic bytes = all Linear weights + lm_head + KV read at the mean context of the timed steps, over the device time of "
@@ -382,7 +405,12 @@ def main():
                 "traffic_note": "FETCH_SIZE x2 (L2 memory-side requests; Infinity-Cache hits are counted): every kernel's own figure is its algorithmic bytes within 2 %; the "
                                 "total is higher by the 17.1 MB per layer that the attention launch's warming workgroups request early (gate|up + o-projection rows), which the "
                                 "GEMV launches then find in the Infinity Cache (profiles/r04_pmc_fetch_size.md; mechanism: r03_warm_workgroups.md)",
-                "kernels": kernels}
+                "kernels": kernels,
+                "step_launches": step_launches,
+                "step_launches_note": "every launch of the decode step, HIP events (no system fence) either side of each on the engine's stream over eager steps: "
+                                      "event-to-event = the kernel plus the command processor's hand-over, 0.3-3 us above the kernel trace's duration of the same kernel "
+                                      "in profiles/r04_bench_kernel_stats.md; their sum sits the same way above us_per_token_device, which is the captured graph's",
+                "step_launches_us_per_token": round(sum(e["us_per_token"] for e in step_launches), 1) if step_launches else None}
 
     # ---- the prefill half of the metric: MFMA-bound.  Algorithmic FLOPs of the forward (2 M N K of every Linear, 4 H S^2 D of every attention; the vision
     # tower's 1.48 TF per 448 x 448 image + the S = 282 LLM prefill's 0.74 TF) over the median device time, against the dense bf16 MFMA peak; then the two kernels that

@@ -387,6 +387,13 @@ void *mllm_hip_model_stream(mllm_hip_model *m);
  * that every launch streams cold HBM; which: 10 qkv, 11 attention, 12 o-proj, 13 gate|up, 14 down (0..3: the stand-alone GEMV launcher on
  * gate|up, down, qkv, o).  Returns its algorithmic bytes per launch too. */
 int mllm_hip_model_time_kernel(mllm_hip_model *m, int which, int iters, float *ms_per_launch, int64_t *bytes_per_launch);
+/* The decode step launch by launch: `steps` greedy steps (the tokens mllm_hip_model_generate would produce; the cache advances the same way) run eagerly with a
+ * HIP event either side of every launch on the engine's stream.  us_by_kind[9] / launches_by_kind[9]: mean event-to-event microseconds of one launch of each kind and
+ * launches of that kind per step -- 0 q|k|v, 1 attention (+ o-projection workgroups when merged), 2 o-projection, 3 gate|up, 4 down, 5 the chain launch (down + the next
+ * layer's q|k|v + attention + o-projection; option merge_o = 4), 6 q|k|v + attention + o-projection, 7 model.norm + lm_head, 8 argmax + state advance.  The first step
+ * is not counted when steps > 1 (its launches wait for the host).  For bench.py's per-launch roofline of the step's dominant launch. */
+#define MLLM_HIP_STEP_KINDS 9
+int mllm_hip_model_time_step(mllm_hip_model *m, int32_t first_token, int steps, float *us_by_kind, int32_t *launches_by_kind, int32_t *last_token);
 /* The visual-token exchange of the sharded vision prefill behind the C ABI: every rank contributes `rows_per_rank` rows of `cols`
  * fp32 (its images' tower output, padded to the common count) and receives all ranks' rows in rank order -- one ncclAllGather (RCCL over
  * xGMI) on the engine's stream.  `comm` is an ncclComm_t the host created (mllm_hip_comm_* below); no torch types. */

@@ -63,7 +63,12 @@ bool decode_merges_o(const DecodeCtx &c);      // the step folds the o-projectio
 int decode_warm_table(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, int flags, WeightWarm *host_out);
 int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, int which, hipStream_t st);
 int argmax_row_launch(const DecodeCtx &c, const float *logits, int n, int *out, hipStream_t st);      // first-maximum argmax over the chip, partials in c.part_val / c.part_idx
-int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st);
+// Optional marks around every launch of a step (mllm_hip_model_time_step: the step run eagerly with a HIP event either side of each launch).  kind: 0 q|k|v, 1 attention
+// (with the o-projection's workgroups when they ride in it), 2 o-projection, 3 gate|up, 4 down, 5 the chain launch (down + the next layer's q|k|v + attention + o-projection),
+// 6 q|k|v + attention + o-projection as one launch, 7 model.norm + lm_head, 8 argmax / state advance.
+constexpr int STEP_KINDS = 9;
+struct StepMarks { int (*mark)(void *user, int kind, int after); void *user; };
+int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st, const StepMarks *marks = nullptr);
 
 // ---- batched decode (engine.hip: mllm_hip_model_batch_decode): the one Op of a step that is not row-wise, for all B sequences in one launch each ----
 // one sequence's KV slabs (bases of layer 0) and the tokens its cache holds BEFORE this step

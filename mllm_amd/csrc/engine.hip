@@ -1091,6 +1091,68 @@ extern "C" int mllm_hip_model_generate(mllm_hip_model *m, int32_t first_token, i
     return 0;
 }
 
+// The decode step once more, launch by launch: `steps` greedy steps run eagerly (no graph) with a HIP event either side of every launch on the engine's stream, the
+// event-to-event times summed per kind of launch (decode_launch.h StepMarks).  The cache advances exactly as under mllm_hip_model_generate (same tokens).  An interval holds
+// the kernel and what the command processor spends between the marker and the kernel, so a kind's figure sits a little above the kernel trace's duration of the same kernel
+// inside the captured graph; bench.py reports both the step's dominant launch from here and the whole token from the graph replay.
+namespace {
+struct StepTimer {
+    hipStream_t st;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> tag;
+    size_t n = 0;
+    unsigned flags = hipEventDisableSystemFence;
+    ~StepTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+int step_mark(void *user, int kind, int after) {
+    auto *t = static_cast<StepTimer *>(user);
+    if (t->n == t->ev.size()) {
+        hipEvent_t e;
+        // (no system-scope fence: a default event's marker writes the L2s back for the host between two kernels, 1.5-2.5 us per launch on top of the kernel; measured
+        //  on the 2 B step: sum of the intervals 944 us with default events, 825 with these, against 792-815 for the captured graph -- scratch/time_step_flags.py)
+        if (hipEventCreateWithFlags(&e, t->flags) != hipSuccess && hipEventCreate(&e) != hipSuccess) return MLLM_HIP_ERR_HIP;
+        t->ev.push_back(e);
+        t->tag.push_back(0);
+    }
+    t->tag[t->n] = kind * 2 + after;
+    if (hipEventRecord(t->ev[t->n], t->st) != hipSuccess) return MLLM_HIP_ERR_HIP;
+    ++t->n;
+    return 0;
+}
+}  // namespace
+extern "C" int mllm_hip_model_time_step(mllm_hip_model *m, int32_t first_token, int steps, float *us_by_kind, int32_t *launches_by_kind, int32_t *last_token) {
+    if (!m || !m->has_llm || m->cache_len <= 0 || steps <= 0 || !us_by_kind || !launches_by_kind) return MLLM_HIP_ERR_ARG;
+    if (m->cache_len + steps > m->c.cache_limit) { fprintf(stderr, "mllm_hip: KV cache overflow (%d + %d > %d)\n", m->cache_len, steps, m->c.cache_limit); return MLLM_HIP_ERR_SHAPE; }
+    if (m->needs_arm) { EH(arm_decode(m)); m->needs_arm = false; }
+    HH(hipMemcpy(&m->d_state->token, &first_token, 4, hipMemcpyHostToDevice));
+    StepTimer t;
+    t.st = m->st;
+    StepMarks marks = {step_mark, &t};
+    double us[STEP_KINDS] = {0};
+    int cnt[STEP_KINDS] = {0};
+    std::vector<size_t> first(steps + 1, 0);
+    HH(hipEventRecord(m->ev0, m->st));
+    for (int s = 0; s < steps; ++s) {      // all steps are queued before the one synchronisation: after the first step the host runs ahead of the device
+        first[s] = t.n;
+        if (int rc = decode_step_launch(m->dctx, m->dlayers.data(), (int)m->dlayers.size(), m->st, &marks)) return resync_after_error(m, rc);
+    }
+    first[steps] = t.n;
+    m->cache_len += steps;
+    m->last_pos += (float)steps;
+    EH(finish(m, nullptr, last_token, nullptr));
+    const int counted = steps > 1 ? steps - 1 : 1;      // the first step's launches wait for the host; it is left out when there is another
+    for (size_t i = first[steps > 1 ? 1 : 0]; i + 1 < t.n; i += 2) {
+        const int kind = t.tag[i] >> 1;
+        if ((t.tag[i] & 1) || t.tag[i + 1] != kind * 2 + 1) return MLLM_HIP_ERR_ARG;      // marks come in (before, after) pairs of one kind
+        float ms = 0;
+        HH(hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
+        us[kind] += (double)ms * 1e3;
+        cnt[kind] += 1;
+    }
+    for (int k = 0; k < STEP_KINDS; ++k) { us_by_kind[k] = cnt[k] ? (float)(us[k] / cnt[k]) : 0.0f; launches_by_kind[k] = cnt[k] / counted; }
+    return 0;
+}
+
 // ---- batched decode: B independent sequences share ONE pass over the weights per step ---------------------------------------------------------------------------
 // The reference's hook for this is KVCache_batch (mllm/Types.hpp:26-33: the KVCache Op's slab gets a batch dimension); its models then run [B, 1, S, H] activations
 // through the same Ops.  A decode token of this engine is launch- and latency-bound, not byte-bound, so B sequences stepped together cost little more

@@ -2000,28 +2000,55 @@ static int argmax_and_advance(const DecodeCtx &c, hipStream_t st) {
     return MH_LAUNCH_OK("dec_next");
 }
 
-int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st) {
+// which slot (layer, kernel) of the step is a launch of its own, and of which kind (StepMarks): the merged forms leave the slots they swallow empty
+static int step_slot_kind(const DecodeCtx &c, const DecodeLayer *layers, int li, int k) {
+    const bool chained = decode_merges_chain(c, layers, li - 1), front = !chained && decode_merges_front(c, layers[li], li);
+    switch (k) {
+    case 0: return chained ? -1 : (front ? 6 : 0);
+    case 1: return chained || front ? -1 : 1;
+    case 2: return chained || front || decode_merges_o(c) ? -1 : 2;
+    case 3: return 3;
+    default: return decode_merges_chain(c, layers, li) ? 5 : 4;
+    }
+}
+int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_layers, hipStream_t st, const StepMarks *marks) {
     float *x = c.x0;
     int rc = 0;
+#define MARK(kind, after) do { if (marks && (rc = marks->mark(marks->user, kind, after))) return rc; } while (0)
     for (int li = 0; li < n_layers; ++li)
         for (int k = 0; k < 5; ++k) {
+            const int kind = marks ? step_slot_kind(c, layers, li, k) : -1;
+            if (kind >= 0) MARK(kind, 0);
             rc = decode_kernel_launch(c, layers, li, k, st);
             if (rc) return rc;
+            if (kind >= 0) MARK(kind, 1);
         }
     if (c.Whead) {
         // Linear lm_head (LLaMA-style models): model.norm -> Q8_K -> Q4_K rows, the same fused kernel as the q|k|v projection; then argmax
+        MARK(7, 0);
         NS_DISPATCH(c.H, rc = launch_norm_gemv<NS>(c, c.final_norm, c.final_eps, c.Whead, nullptr, c.vocab, false, x, x, c.logits, st));
         if (rc) return rc;
-        return argmax_and_advance(c, st);
+        MARK(7, 1);
+        MARK(8, 0);
+        rc = argmax_and_advance(c, st);
+        if (rc) return rc;
+        MARK(8, 1);
+        return 0;
     }
     // tied lm_head + argmax
     if (c.H % 512 != 0 || c.H / 512 > 8) {
         // shapes the fused head kernel does not cover: the stand-alone launchers (same arithmetic), then advance the state
+        MARK(7, 0);
         rc = mllm_hip_rmsnorm(x, c.final_norm, c.normed, nullptr, nullptr, nullptr, 1, c.H, c.final_eps, 0, st);
         if (!rc) rc = mllm_hip_quantize_q80(c.normed, c.x80_qs, c.x80_d, 1, c.H, st);
         if (!rc) rc = mllm_hip_linear_q40_q80(c.emb_qs, c.emb_d, nullptr, c.x80_qs, c.x80_d, c.logits, c.vocab, 1, c.vocab, c.H, st);
         if (rc) return rc;
-        return argmax_and_advance(c, st);
+        MARK(7, 1);
+        MARK(8, 0);
+        rc = argmax_and_advance(c, st);
+        if (rc) return rc;
+        MARK(8, 1);
+        return 0;
     }
     const int head_wpc = option(OPT_HEAD_WPC) > 0 ? option(OPT_HEAD_WPC) : 8;   // waves per CU the row split aims at
     const int target_waves = 256 * head_wpc;
@@ -2031,13 +2058,20 @@ int decode_step_launch(const DecodeCtx &c, const DecodeLayer *layers, int n_laye
     if (blocks > c.max_parts) return MLLM_HIP_ERR_SHAPE;
     const size_t lds = (((size_t)c.H * 5 + (size_t)c.H / 32 * 4 + 15) & ~(size_t)15) + 4 * q40_tab_floats(c.H / 32) * sizeof(float);
 #define HEAD_CASE(B) case B: rc = allow_lds(dec_head_kernel<B>, lds); if (rc) return rc; hipLaunchKernelGGL((dec_head_kernel<B>), dim3(blocks), dim3(256), lds, st, x, c.final_norm, c.final_eps, c.emb_qs, c.emb_d, c.logits, c.part_val, c.part_idx, c.vocab, c.H, rpw); break;
+    MARK(7, 0);
     switch (c.H / 512) { HEAD_CASE(1) HEAD_CASE(2) HEAD_CASE(3) HEAD_CASE(4) HEAD_CASE(5) HEAD_CASE(6) HEAD_CASE(7) HEAD_CASE(8) }
 #undef HEAD_CASE
     rc = MH_LAUNCH_OK("dec_head");
     if (rc) return rc;
+    MARK(7, 1);
+    MARK(8, 0);
     hipLaunchKernelGGL(dec_next_kernel, dim3(1), dim3(256), 0, st, c.state, c.part_val, c.part_idx, blocks, c.tok_dev, c.history, c.rope_sin, c.rope_cos, c.cur_sin, c.cur_cos,
                        c.D / 2, c.cache_limit);
-    return MH_LAUNCH_OK("dec_next");
+    rc = MH_LAUNCH_OK("dec_next");
+    if (rc) return rc;
+    MARK(8, 1);
+    return 0;
+#undef MARK
 }
 }  // namespace mllm_hip
 

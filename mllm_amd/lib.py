@@ -327,6 +327,16 @@ class Model:
 
     time_gemv = time_kernel
 
+    STEP_KINDS = ("qkv", "attn", "o_proj", "gateup", "down", "chain", "front", "head", "next")
+
+    def time_step(self, first_token, steps=8):
+        """The decode step launch by launch (HIP events either side of every launch, eager): {kind: (us per launch, launches per step)}, last token."""
+        us = (C.c_float * 9)()
+        n = (C.c_int32 * 9)()
+        tok = C.c_int32()
+        check(load().mllm_hip_model_time_step(self._h, C.c_int32(int(first_token)), C.c_int(steps), us, n, C.byref(tok)), "time_step")
+        return {k: (float(us[i]), int(n[i])) for i, k in enumerate(self.STEP_KINDS) if n[i]}, tok.value
+
 
 class Qwen2VL(Model):
     """demo_qwen2_vl.cpp's model: the generic engine with the Qwen2-VL graph (pixel_values + grid_thw as the image)."""

@@ -60,6 +60,28 @@ def test_roofline_and_cpu_baseline_objects():
     assert c["kind"] in ("reference", "port") and c["unit"] == "tok/s" and c["cores"] >= 1
 
 
+def test_step_launches_recompute():
+    """Round 4: the decode step launch by launch (mllm_hip_model_time_step) -- every entry's rate follows from its bytes and its time, the launches add up to the step the
+    engine runs (60 on the 2 B model, 27 of them the chain launch), and their summed time sits above the captured graph's token by the markers' cost only."""
+    d = _line()
+    r = d["roofline"]
+    sl = r.get("step_launches")
+    assert sl, "the committed line predates step_launches"
+    for e in sl:
+        if e["algorithmic_bytes_per_launch"]:
+            ach = e["algorithmic_bytes_per_launch"] / (e["us_per_launch"] * 1e-6) / 1e9
+            assert abs(ach - e["achieved_GBps"]) <= 0.002 * ach + 0.1 and abs(ach / 8000.0 - e["frac"]) < 2e-4
+        assert abs(e["us_per_launch"] * e["launches_per_token"] - e["us_per_token"]) < 0.1
+    by = {e["launch"]: e for e in sl}
+    assert by["chain"]["launches_per_token"] == 27 and sum(e["launches_per_token"] for e in sl) == 60
+    assert sl[0]["launch"] == "chain"      # sorted by time per token: the chain launch is the step's dominant one
+    total = sum(e["us_per_token"] for e in sl)
+    assert abs(total - r["step_launches_us_per_token"]) < 0.5
+    assert r["us_per_token_device"] < total < 1.12 * r["us_per_token_device"]
+    # (the KV share is priced at the context these extra steps run at, past the timed steps' mean)
+    assert 0.99 * r["algorithmic_bytes_per_token"] < sum(e["algorithmic_bytes_per_launch"] * e["launches_per_token"] for e in sl) < 1.01 * r["algorithmic_bytes_per_token"]
+
+
 def test_prefill_roofline_and_host_cpus():
     """Round 4 on: the prefill half of the metric carries its own roofline object (MFMA-bound: algorithmic FLOPs of the forward over the median device time against the dense
     bf16 peak, and the GEMM / attention kernels each against the peak of the MFMA form they run on, with the PMC pass's matrix-pipe busy fraction), every fraction is

@@ -75,6 +75,25 @@ def test_full_image_prompt_bit_exact(full_model):
     assert [tok] + gen.tolist() == g["tokens"].tolist()
 
 
+def test_step_timed_launch_by_launch_is_the_same_step(full_model):
+    """mllm_hip_model_time_step (bench.py's per-launch figures): the decode step issued eagerly with an event either side of every launch produces the golden greedy ids,
+    and accounts for the step as the 2 B model runs it -- 27 chain launches (down + the next layer's q|k|v + attention + o-projection), 28 gate|up, layer 0's q|k|v and
+    attention (+ o-projection) and layer 27's down on their own, the head, the state advance: 60 launches."""
+    cfg, m = full_model
+    g = np.load(os.path.join(GOLD, "qwen2vl_2b_ref_text.npz"))
+    m.clear_kvcache()
+    tok, _, _ = m.prefill(g["ids"])
+    assert tok == int(g["tokens"][0])
+    gen, _ = m.generate(tok, 7)
+    assert gen.tolist() == g["tokens"][1:8].tolist()
+    kinds, last = m.time_step(int(gen[-1]), 9)
+    assert last == int(g["tokens"][16])
+    assert {k: n for k, (_, n) in kinds.items()} == {"chain": 27, "gateup": 28, "qkv": 1, "attn": 1, "down": 1, "head": 1, "next": 1}
+    assert all(0.5 < us < 200.0 for us, _ in kinds.values()), kinds
+    tok2, _, _ = m.decode(last)      # the graph replay carries on from the state the eager steps left
+    assert tok2 == int(g["tokens"][17])
+
+
 def test_pipelined_decode_attention_equals_the_unpipelined_kernel_over_a_long_context(tmp_path):
     """dec_attn_pipe_kernel (scores of later key blocks computed while the walk over the first ones runs; kernels_attn_core.h: fa2_decode_head_pipe) against
     dec_attn_kernel (attn_flags bit 2: phases A -> B -> C one after the other, the form pinned against the oracle to T = 1500 by test_fa2_on_the_engine_kv_layout):
