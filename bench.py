@@ -346,7 +346,7 @@ def main():
     # ---- decode: W warmup steps, then exactly K timed steps ----------------------------------------------------------
     K, W = args.steps, args.warmup
     if cfgname == "llava" and S + K + W + 1 > cfg.cache_limit:
-        K = max(8, cfg.cache_limit - S - W - 1)
+        K = max(8, cfg.cache_limit - S - W - 1 - 4)      # (four slots stay free for the launch-by-launch steps of roofline.step_launches)
     assert S + K + W + 1 <= cfg.cache_limit, "steps + warmup exceed the KV slab of the config"
     if W > 0:
         toks, _ = m.generate(tok, W)
