@@ -44,7 +44,7 @@ namespace mllm_hip {
 #endif
 constexpr bool g_nt = MLLM_HIP_NT != 0;
 
-#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB) || defined(MLLM_HIP_STAMPS_PJB)
+#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB) || defined(MLLM_HIP_STAMPS_PJB) || defined(MLLM_HIP_STAMPS_CHAIN)
 __device__ unsigned long long g_stamps[8192 * 16];
 #endif
 #ifdef MLLM_HIP_STAMPS
@@ -86,6 +86,12 @@ __device__ unsigned long long g_stamps[8192 * 16];
 #define STAMPV(i, v)
 #define STAMPT(i, t)
 #define STAMPB(i)
+#endif
+// the chain launch's roles (diagnostic build -DMLLM_HIP_STAMPS_CHAIN, scratch/stamps_chain.py): rows 2048 + workgroup, slot 0 entry, 1 exit, 2.. the role's milestones
+#if defined(MLLM_HIP_STAMPS_CHAIN)
+#define CSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { __builtin_amdgcn_sched_barrier(0); mllm_hip::g_stamps[(2048 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define CSTAMP(i)
 #endif
 // stamps of the gate|up GEMV only (diagnostic build with -DMLLM_HIP_STAMPS_GUB: scratch/stamps_gub.py); the attention's stamps stay silent in that build
 // (the same for the down projection with -DMLLM_HIP_STAMPS_PJB: scratch/stamps_pjb.py)
@@ -454,7 +460,9 @@ __device__ __forceinline__ void dec_qkv_body(const DecodeState *__restrict__ sta
             }
             xv[0] = make_float4(__uint_as_float((unsigned)e0), __uint_as_float((unsigned)e1), __uint_as_float((unsigned)e2), __uint_as_float((unsigned)e3));
         } else wv[0] = make_float4(0, 0, 0, 0);
+        CSTAMP(2);
         wg_rmsnorm_quant<NV, WPB>(xv, wv, K, eps, a, red);
+        CSTAMP(3);
     } else {
     if (EMBED) load_row<NV, WPB>(wv, norm_w, K);
     else load_rows2<NV, WPB>(xv, wv, x, norm_w, K);
@@ -834,6 +842,7 @@ __device__ __forceinline__ void dec_proj_body(const float *__restrict__ xin, con
                 v[i] = make_float4(__uint_as_float((unsigned)e0), __uint_as_float((unsigned)e1), __uint_as_float((unsigned)e2), __uint_as_float((unsigned)e3));
             }
         }
+        CSTAMP(2);
         wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
     } else {
 #pragma unroll
@@ -852,9 +861,11 @@ __device__ __forceinline__ void dec_proj_body(const float *__restrict__ xin, con
     }
     __syncthreads();
     STAMP(5);
+    if constexpr (POLL) CSTAMP(3);
     float out[ROWS];
     dot_rows<NSTEPS, ROWS>(L, a, nb, lane, wave_tab<NSTEPS, ROWS>(smem, K, false, wid), out);
     STAMP(7);
+    if constexpr (POLL) CSTAMP(4);
     if (lane == 63) {
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
@@ -925,10 +936,12 @@ __device__ __forceinline__ void dec_proj_blk_body(const float *__restrict__ xin,
     GSTAMP2(1);
     wave_quant_blocks<NQ, WPB>(v, lane, wid, nb, a);
     GSTAMP2(2);
+    if constexpr (OUTP) CSTAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GSTAMP2(3);
     __syncthreads();
     GSTAMP2(4);
+    if constexpr (OUTP) CSTAMP(3);
     if (RPW * nb > 64 && 2 * RPW * nb <= 64 * WPB) {      // a lane pair per super-block (see blk_emit_pair) once one wave no longer holds them all
         const int sb = tid >> 1;
         if (sb < RPW * nb) blk_emit_pair(stage + (size_t)sb * 144, a, sb % nb, tid & 1, tab + (size_t)sb * Q4K_SLOTS);
@@ -938,6 +951,7 @@ __device__ __forceinline__ void dec_proj_blk_body(const float *__restrict__ xin,
     GSTAMP2(5);
     __syncthreads();
     GSTAMP2(6);
+    if constexpr (OUTP) CSTAMP(4);
     if (4 * wid < RPW) {
         const int nr = RPW - 4 * wid < 4 ? RPW - 4 * wid : 4;
         const float res = q4k_chain(tab + (size_t)4 * wid * nb * Q4K_SLOTS, nb, nb, nr, lane);
@@ -1132,6 +1146,7 @@ __device__ __forceinline__ void dec_attn_pipe_body(const DecodeState *__restrict
                 __builtin_amdgcn_s_sleep(1);
             }
         }
+        CSTAMP(2);
     }
     if (tid < HALF) {
         L.qs[tid] = __fmaf_rn(qa, cs, -(qb * sn));
@@ -1148,7 +1163,9 @@ __device__ __forceinline__ void dec_attn_pipe_body(const DecodeState *__restrict
         kslab[(int64_t)T * KVD + kvh * D + tid] = knew[tid];
         vslab[(int64_t)(kvh * D + tid) * vt_ld + T] = vnew[tid];
     }
+    if constexpr (QPOLL) CSTAMP(3);
     fa2_decode_head_pipe<D, DV, DEC_PIPE_NT>(L, R, kslab, KVD, vslab, vt_ld, kvh * D, kvh * D + vdim0, Sk, cache_limit, knew, vnew + vdim0, T);
+    if constexpr (QPOLL) CSTAMP(4);
     if (tid < DV) {
         if constexpr (PAIRS) __hip_atomic_store(out_pairs + head * D + vdim0 + tid, ((unsigned long long)serial << 32) | (unsigned long long)__float_as_uint(L.ob[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else out[head * D + vdim0 + tid] = L.ob[tid];
@@ -1217,9 +1234,11 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_down_front_kernel(const Decod
                                                                      uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab, int Hq, int Hkv, int cache_limit, int vt_ld, int flags,
                                                                      int attn_groups, const WeightWarm *__restrict__ ww, const DownRole Dn, const QkvFront F, const OProjRole P) {
     int b = (int)blockIdx.x;
+    CSTAMP(0);
     if (b < Dn.grid_d) {
         if (threadIdx.x >= 512) return;
         dec_proj_blk_body<8, NQ, true>(Dn.xin, Dn.W, Dn.residual, Dn.y, Dn.N, Dn.K, Dn.rpw, b, Dn.ypairs, (unsigned)state->serial);
+        CSTAMP(1);
         return;
     }
     b -= Dn.grid_d;
@@ -1227,17 +1246,20 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_down_front_kernel(const Decod
         if (threadIdx.x >= 512) return;
         dec_qkv_body<1, 2, false, 1, 8, true, true>(state, nullptr, nullptr, F.emb_qs, F.emb_d, F.vocab, F.norm_w, F.eps, F.W, F.bias, nullptr, F.pairs, F.N, F.K, F.kw, b, F.grid_q,
                                                     Dn.ypairs, P.poll_err);
+        CSTAMP(1);
         return;
     }
     if (b < F.grid_q + P.grid_attn) {
         dec_attn_pipe_body<D, DS, true, true>(state, nullptr, sin_t, cos_t, kslab, vslab, nullptr, P.pairs, Hq, Hkv, cache_limit, vt_ld, flags, attn_groups, ww, P.grid_attn,
                                               b - F.grid_q, F.pairs, P.poll_err);
+        CSTAMP(1);
         return;
     }
     if (threadIdx.x >= 512) return;
     const int wo = b - F.grid_q - P.grid_attn;
     if (P.rows == 1) dec_proj_body<1, 1, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, nullptr, P.y, P.N, P.K, Dn.ypairs);
     else dec_proj_body<1, 2, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, nullptr, P.y, P.N, P.K, Dn.ypairs);
+    CSTAMP(1);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1390,7 +1412,7 @@ __global__ __launch_bounds__(256) void dec_next_kernel(DecodeState *__restrict__
         state->serial += 1;
     }
 }
-#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB) || defined(MLLM_HIP_STAMPS_PJB)
+#if defined(MLLM_HIP_STAMPS) || defined(MLLM_HIP_STAMPS_GUB) || defined(MLLM_HIP_STAMPS_PJB) || defined(MLLM_HIP_STAMPS_CHAIN)
 }  // namespace mllm_hip
 extern "C" int mllm_hip_debug_read_stamps(unsigned long long *host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(mllm_hip::g_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
