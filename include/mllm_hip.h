@@ -59,7 +59,8 @@ int mllm_hip_sync(void *stream);
  * value -1 = unset (built-in choice).  Names: vision_batch (images per tower pass), time_layers (layers mllm_hip_model_time_kernel cycles over), no_gub / no_pjb (the
  * 8-lanes-per-block GEMVs instead of one lane per super-block), pjb_min_ns, attn_flags, attn_ds (workgroups per head of the decode attention), head_wpc, gemm_order, no_lnf, merge_o (which kernels of the decode step share a launch, handing
  * their rows over as {value, epoch} pairs: 4 (default) a layer's down projection + the next layer's q|k|v + attention + o-projection; 3 q|k|v + attention + o-projection; 2 / 1 attention +
- * o-projection; 0 five launches per layer). */
+ * o-projection; 0 five launches per layer), chain_cont (0: the q|k|v role of the merge_o = 4 launch gets workgroups of its own; default: the first down-projection
+ * workgroups carry on as that role). */
 int mllm_hip_set_option(const char *name, int value);
 int mllm_hip_get_option(const char *name, int *value);
 /* one in-order stream per backend instance (hipStream_t as void*); the OpenCL backend's command queue, OpenCLBackend.cpp:476-477 */

@@ -941,9 +941,11 @@ static int finish(M *m, float *logits_host, int32_t *next_token, float *elapsed_
     if (m->dctx.merge_o) HH(hipMemcpyAsync(m->pin_err, m->poll_err, 4, hipMemcpyDeviceToHost, m->st));
     HH(hipStreamSynchronize(m->st));
     if (m->dctx.merge_o && *m->pin_err) {      // a polled hand-off inside a merged launch gave up: the results of the step(s) are not valid
+        const int site = *m->pin_err;
         *m->pin_err = 0;
         HH(hipMemset(m->poll_err, 0, 4));
-        set_error_msg("a merged decode launch timed out waiting for its producer workgroups (option merge_o)");
+        static const char *const who[] = {"?", "q|k|v role waiting for the layer input row", "o-projection role waiting for the attention's row", "attention role waiting for q|k|v"};
+        set_error_msg("a merged decode launch timed out waiting for its producer workgroups (option merge_o): %s", who[site >= 1 && site <= 3 ? site : 0]);
         return MLLM_HIP_ERR_ARG;
     }
     if (next_token) *next_token = m->pin_tok[1];

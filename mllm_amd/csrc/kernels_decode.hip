@@ -836,7 +836,7 @@ __device__ __forceinline__ void dec_proj_body(const float *__restrict__ xin, con
                     e2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); e3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const bool ok = (unsigned)(e0 >> 32) == epoch && (unsigned)(e1 >> 32) == epoch && (unsigned)(e2 >> 32) == epoch && (unsigned)(e3 >> 32) == epoch;
                     if (ok) break;
-                    if (++polls > (1 << 18)) { __hip_atomic_store(poll_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (++polls > (1 << 18)) { __hip_atomic_store(poll_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 v[i] = make_float4(__uint_as_float((unsigned)e0), __uint_as_float((unsigned)e1), __uint_as_float((unsigned)e2), __uint_as_float((unsigned)e3));
@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void dec_attn_pipe_body(const DecodeState *__restrict
                 const unsigned long long ea = __hip_atomic_load(qkv_pairs + ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long eb = __hip_atomic_load(qkv_pairs + ib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(ea >> 32) == epoch && (unsigned)(eb >> 32) == epoch) { qa = __uint_as_float((unsigned)ea); qb = __uint_as_float((unsigned)eb); break; }
-                if (++polls > (1 << 18)) { __hip_atomic_store(poll_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (++polls > (1 << 18)) { __hip_atomic_store(poll_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_qkv_attn_oproj_kernel(const D
 // size leaves one workgroup per CU); as they leave, the q|k|v role's workgroups are dispatched, send their weight rows and poll the layer's output row (pairs), and so on down
 // the chain -- what disappears is the drain / launch gap between the two kernels.  The o-projection's residual is that same output row: read from the pairs, not through a plain
 // load of what another workgroup of this launch stored.
-struct DownRole { const float *xin; const uint8_t *W; const float *residual; float *y; unsigned long long *ypairs; int N, K, rpw, grid_d; };
+struct DownRole { const float *xin; const uint8_t *W; const float *residual; float *y; unsigned long long *ypairs; int N, K, rpw, grid_d, cont; };
 template <int D, int DS, int NQ>
 __global__ __launch_bounds__(DEC_PIPE_NT) void dec_down_front_kernel(const DecodeState *__restrict__ state, const float *__restrict__ sin_t, const float *__restrict__ cos_t,
                                                                      uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab, int Hq, int Hkv, int cache_limit, int vt_ld, int flags,
@@ -1239,24 +1239,33 @@ __global__ __launch_bounds__(DEC_PIPE_NT) void dec_down_front_kernel(const Decod
         if (threadIdx.x >= 512) return;
         dec_proj_blk_body<8, NQ, true>(Dn.xin, Dn.W, Dn.residual, Dn.y, Dn.N, Dn.K, Dn.rpw, b, Dn.ypairs, (unsigned)state->serial);
         CSTAMP(1);
+        if (Dn.cont && b < F.grid_q) {      // the first grid_q down-projection workgroups carry on as the q|k|v role: no wait for a CU, no dispatch
+            __syncthreads();      // (the role reuses the LDS the down projection's last phase read)
+            dec_qkv_body<1, 2, false, 1, 8, true, true>(state, nullptr, nullptr, F.emb_qs, F.emb_d, F.vocab, F.norm_w, F.eps, F.W, F.bias, nullptr, F.pairs, F.N, F.K, F.kw, b, F.grid_q,
+                                                        Dn.ypairs, P.poll_err);
+            CSTAMP(5);
+        }
         return;
     }
     b -= Dn.grid_d;
-    if (b < F.grid_q) {
-        if (threadIdx.x >= 512) return;
-        dec_qkv_body<1, 2, false, 1, 8, true, true>(state, nullptr, nullptr, F.emb_qs, F.emb_d, F.vocab, F.norm_w, F.eps, F.W, F.bias, nullptr, F.pairs, F.N, F.K, F.kw, b, F.grid_q,
-                                                    Dn.ypairs, P.poll_err);
-        CSTAMP(1);
-        return;
+    if (!Dn.cont) {
+        if (b < F.grid_q) {
+            if (threadIdx.x >= 512) return;
+            dec_qkv_body<1, 2, false, 1, 8, true, true>(state, nullptr, nullptr, F.emb_qs, F.emb_d, F.vocab, F.norm_w, F.eps, F.W, F.bias, nullptr, F.pairs, F.N, F.K, F.kw, b, F.grid_q,
+                                                        Dn.ypairs, P.poll_err);
+            CSTAMP(1);
+            return;
+        }
+        b -= F.grid_q;
     }
-    if (b < F.grid_q + P.grid_attn) {
+    if (b < P.grid_attn) {
         dec_attn_pipe_body<D, DS, true, true>(state, nullptr, sin_t, cos_t, kslab, vslab, nullptr, P.pairs, Hq, Hkv, cache_limit, vt_ld, flags, attn_groups, ww, P.grid_attn,
-                                              b - F.grid_q, F.pairs, P.poll_err);
+                                              b, F.pairs, P.poll_err);
         CSTAMP(1);
         return;
     }
     if (threadIdx.x >= 512) return;
-    const int wo = b - F.grid_q - P.grid_attn;
+    const int wo = b - P.grid_attn;
     if (P.rows == 1) dec_proj_body<1, 1, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, nullptr, P.y, P.N, P.K, Dn.ypairs);
     else dec_proj_body<1, 2, 8, true>(nullptr, P.pairs, (unsigned)state->serial, P.poll_err, wo, P.W, nullptr, P.y, P.N, P.K, Dn.ypairs);
     CSTAMP(1);
@@ -1983,7 +1992,8 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
             const int rpw = pjb_rows_per_wg(c.H, c.I), grid_d = (c.H + rpw - 1) / rpw;
             KvWarm kw{nullptr, nullptr, nullptr, c.kv_heads, c.D, c.kv_heads * c.D, c.vt_ld, c.cache_limit};
             if ((flags & 8) && (flags & 1) && c.kv_heads <= 8) { kw.kslab = kl; kw.vslab = vl; }
-            const DownRole Dn{c.act, L.Wdown_raw, t, x, c.x_pairs + (size_t)li * c.H, c.H, c.I, rpw, grid_d};
+            const int cont = grid_q <= grid_d && option(OPT_CHAIN_CONT) != 0;      // the q|k|v role runs in the first down-projection workgroups once they are through (+1 %)
+            const DownRole Dn{c.act, L.Wdown_raw, t, x, c.x_pairs + (size_t)li * c.H, c.H, c.I, rpw, grid_d, cont};
             const QkvFront F{nullptr, nullptr, c.emb_qs, c.emb_d, Ln.in_norm, Ln.Wqkv, Ln.bqkv, c.qkv_pairs + (size_t)ln * Ln.qkv_N, c.eps, c.vocab, Ln.qkv_N, c.H, grid_q, kw};
             const OProjRole P{Ln.Wo, nullptr, t, c.attn_pairs + (size_t)ln * Ko, c.poll_err, c.H, Ko, grid_attn, rows};
             const size_t plds = c.D == 128 ? merged_chain_lds<128>(c) : merged_chain_lds<64>(c);
@@ -1991,7 +2001,7 @@ int decode_kernel_launch(const DecodeCtx &c, const DecodeLayer *layers, int li, 
     {                                                                                                                                                         \
         rc = allow_lds(dec_down_front_kernel<DD, 2, NSV>, plds);                                                                                              \
         if (rc) return rc;                                                                                                                                    \
-        hipLaunchKernelGGL((dec_down_front_kernel<DD, 2, NSV>), dim3(grid_d + grid_q + grid_attn + grid_o), dim3(DEC_PIPE_NT), plds, st, c.state, c.cur_sin, c.cur_cos, kl, vl,      \
+        hipLaunchKernelGGL((dec_down_front_kernel<DD, 2, NSV>), dim3(grid_d + (cont ? 0 : grid_q) + grid_attn + grid_o), dim3(DEC_PIPE_NT), plds, st, c.state, c.cur_sin, c.cur_cos, kl, vl,      \
                            c.heads, c.kv_heads, c.cache_limit, c.vt_ld, flags, attn_groups, ww, Dn, F, P);                                                    \
     }
             const int NSd = (c.I / 256 + 7) / 8;

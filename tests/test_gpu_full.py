@@ -94,6 +94,26 @@ def test_step_timed_launch_by_launch_is_the_same_step(full_model):
     assert tok2 == int(g["tokens"][17])
 
 
+def test_chain_launch_qkv_role_carried_on_or_on_its_own_workgroups():
+    """Option chain_cont: in the chain launch the next layer's q|k|v role either gets workgroups of its own (0) or is carried on by the first down-projection workgroups once
+    they are through (default).  Same arithmetic, same hand-overs: the golden ids and sampled logits of the reference's run either way."""
+    cfg = synth.qwen2vl_2b()
+    path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
+    g = np.load(os.path.join(GOLD, "qwen2vl_2b_ref_text.npz"))
+    try:
+        for mode in (0, 1):
+            lib.set_option("chain_cont", mode)
+            m = lib.Qwen2VL(cfg, path)
+            try:
+                toks, errs = _run(m, g, lambda: m.prefill(g["ids"]))
+                assert toks == g["tokens"].tolist(), mode
+                assert max(errs) == 0.0, (mode, errs)
+            finally:
+                m.close()
+    finally:
+        lib.set_option("chain_cont", -1)
+
+
 def test_pipelined_decode_attention_equals_the_unpipelined_kernel_over_a_long_context(tmp_path):
     """dec_attn_pipe_kernel (scores of later key blocks computed while the walk over the first ones runs; kernels_attn_core.h: fa2_decode_head_pipe) against
     dec_attn_kernel (attn_flags bit 2: phases A -> B -> C one after the other, the form pinned against the oracle to T = 1500 by test_fa2_on_the_engine_kv_layout):
