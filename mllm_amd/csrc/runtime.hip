@@ -29,7 +29,12 @@ int check_launch(const char *what, const char *file, int line) {
     }
     return MLLM_HIP_OK;
 }
-static int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};      // one entry per Option: all unset
+struct OptionTable {
+    int v[OPT_COUNT];
+    OptionTable() { for (int &x : v) x = -1; }      // every Option unset, however many there are
+};
+static OptionTable g_option_table;
+static int *const g_options = g_option_table.v;
 static const char *const g_option_names[OPT_COUNT] = {"vision_batch", "time_layers", "no_gub", "no_pjb", "pjb_min_ns", "attn_flags", "attn_ds", "head_wpc", "gemm_order", "no_lnf", "merge_o", "chain_cont"};
 int option(Option o) { return g_options[o]; }
 }  // namespace mllm_hip

@@ -165,9 +165,19 @@ def test_options_live_in_the_library_not_in_the_environment(L, monkeypatch):
     assert L.mllm_hip_set_option(NULL, C.c_int(1)) == ERR_ARG
     v = C.c_int(7)
     assert L.mllm_hip_get_option(b"attn_ds", C.byref(v)) == OK and v.value == -1
-    # the one environment variable the library still reads (profiling scripts: replay the decode step as plain launches)
     import os
     import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # every option the library knows starts unset (-1), the newest included (a fixed-length initialiser once left the last one at 0)
+    names = re.search(r'g_option_names\[OPT_COUNT\] = \{([^}]*)\}', open(os.path.join(root, "mllm_amd", "csrc", "runtime.hip")).read()).group(1)
+    names = [n.strip().strip('"') for n in names.split(",")]
+    assert "merge_o" in names and "chain_cont" in names
+    out = subprocess.run([sys.executable, "-c", "from mllm_amd import lib\nprint([lib.get_option(n) for n in %r])" % names], capture_output=True, text=True,
+                         cwd=root, env=dict(os.environ, PYTHONPATH=root))
+    assert out.returncode == 0 and out.stdout.strip() == str([-1] * len(names)), (out.stdout, out.stderr[-500:])
+    # the one environment variable the library still reads (profiling scripts: replay the decode step as plain launches)
     src = "".join(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mllm_amd", "csrc", f)).read()
                   for f in os.listdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mllm_amd", "csrc")) if f.endswith((".hip", ".h")))
     assert set(re.findall(r'getenv\("([A-Z_]+)"\)', src)) == {"MLLM_HIP_NO_GRAPH"}
