@@ -679,6 +679,7 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
                 const int vi = lane + 64 * i;
                 *reinterpret_cast<pipe_u32x4 *>(region + (size_t)(vi / G::ROWK) * G::KPITCH + (vi % G::ROWK) * 16) = R.k[i];
             }
+            if (b == pw) STAMPT(6, (NWK + 1) * 64);
             const int j = b * FP_B + key;
             float s = FA_NEG;
             {
@@ -693,6 +694,9 @@ __device__ __forceinline__ void fa2_decode_head_pipe(const PipeLds &L, PipeRegs<
 #pragma unroll
                     for (int i = 0; i < D / 8; ++i) kw[i] = *reinterpret_cast<const uint2 *>(kr + 16 * i);
                 }
+#ifdef MLLM_HIP_STAMPS
+                if (b == pw) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMPT(11, (NWK + 1) * 64); }
+#endif
 #pragma unroll
                 for (int i = 0; i < D / 8; ++i) {
                     const float4 a = *reinterpret_cast<const float4 *>(q + 8 * i);

@@ -21,14 +21,14 @@ st = buf.reshape(-1, 16).astype(np.int64)
 nz = [r for r in range(0, 1024) if st[r, 3] > 0 and st[r, 2] > 0]
 print('rows with walker stamps:', nz[:40], len(nz))
 base = 256      # chain_cont: the attention region follows the 256 down-projection workgroups
-live = nz[:24] if len(nz) >= 24 else [base + idx * 8 + col for idx in range(12) for col in range(2)]
+live = [r for r in nz if r >= base][:24]
 t0 = st[2048:2048 + 256, 0].min()      # the launch's first entry
 rel = lambda a: (a - t0) / 100.0
 A = st[live]; Cn = st[[2048 + r for r in live]]
 def line(name, col):
     c = rel(col); print('   %-46s min %6.2f  median %6.2f  max %6.2f us' % (name, c.min(), np.median(c), c.max()))
 line('entry', A[:, 1]); line('q|k|v pairs arrived (chain stamp)', Cn[:, 2]); line('prologue barrier passed', A[:, 0])
-line('producer 0: scores of its first block done', A[:, 8]); line('producer 0: carry taken', A[:, 9]); line('producer 0: block READY', A[:, 10])
+line('producer 0: key rows staged (ds_write issued)', A[:, 6]); line('producer 0: its key pieces read back', A[:, 11]); line('producer 0: scores of its first block done', A[:, 8]); line('producer 0: carry taken', A[:, 9]); line('producer 0: block READY', A[:, 10])
 line('producer 4: carry taken', A[:, 12]); line('producer 4: block READY', A[:, 13])
 line('walker: block 0 READY, first reads issued', A[:, 2]); line('walk done', A[:, 3]); line('logsum lane done', A[:, 7]); line('walker at the final barrier', A[:, 4]); line('end', A[:, 5])
 for r in live[:2]:
