@@ -18,8 +18,14 @@ for r in stats[:28]:
                                                                   float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 nx = [i for i, r in enumerate(trace) if "dec_next" in r["Kernel_Name"]]
 if len(nx) > 40:
-    dec = trace[nx[20] + 1:nx[-1] + 1]
-    ntok = len(nx) - 21
+    # the timed graph replays: from the 20th dec_next on, for as long as a token keeps the same number of launches (the bench's later legs -- kernels timed alone, the
+    # launch-by-launch steps -- also end in dec_next or sit between two of them and are left out)
+    per = [nx[i + 1] - nx[i] for i in range(len(nx) - 1)]
+    mode = collections.Counter(per[20:]).most_common(1)[0][0]
+    last = 20
+    while last < len(per) and per[last] == mode: last += 1
+    dec = trace[nx[20] + 1:nx[last] + 1]
+    ntok = last - 20
     t, c = collections.Counter(), collections.Counter()
     for r in dec:
         n = r["Kernel_Name"].split("(")[0][-60:]
