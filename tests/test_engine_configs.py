@@ -126,6 +126,13 @@ def test_engine_full_size_qwen15_matches_reference():
     tok, _, _ = m.prefill(g["qwen_ids"], want_logits=False)
     gen, _ = m.generate(tok, len(toks) - 1)
     assert gen.tolist() == toks[1:]
+    # the step launch by launch (bench.py's step_launches): same ids, and this shape's form of the step -- q|k|v + attention + o-projection as one launch from layer 1 on
+    # (11 super-blocks per down row: the chain launch does not apply), gate|up and down on their own
+    m.clear_kvcache()
+    tok, _, _ = m.prefill(g["qwen_ids"], want_logits=False)
+    kinds, last = m.time_step(tok, len(toks) - 1)
+    assert last == toks[-1]
+    assert {k: n for k, (_, n) in kinds.items()} == {"front": 23, "gateup": 24, "down": 24, "qkv": 1, "attn": 1, "head": 1, "next": 1}
     st = m.load_stats()
     assert st["file_bytes"] > 2.0e8 and st["total_ms"] > 0
     m.close()
@@ -146,6 +153,12 @@ def test_engine_full_size_tinyllama_matches_reference():
     tok, _, _ = m.prefill(g["ids"], want_logits=False)
     gen, _ = m.generate(tok, len(toks) - 1)          # the captured decode graph gives the same ids
     assert gen.tolist() == toks[1:]
+    # the step launch by launch: the chain launch applies here too (22 super-blocks per down row), D = 64 heads, the q|k|v role carried on by the down projection's workgroups
+    m.clear_kvcache()
+    tok, _, _ = m.prefill(g["ids"], want_logits=False)
+    kinds, last = m.time_step(tok, len(toks) - 1)
+    assert last == toks[-1]
+    assert {k: n for k, (_, n) in kinds.items()} == {"chain": 21, "gateup": 22, "down": 1, "qkv": 1, "attn": 1, "head": 1, "next": 1}
     m.close()
 
 
