@@ -114,6 +114,46 @@ def test_chain_launch_qkv_role_carried_on_or_on_its_own_workgroups():
         lib.set_option("chain_cont", -1)
 
 
+def test_shared_launches_with_a_second_engine_busy_on_the_same_gpu(full_model):
+    """The chain launch's roles wait for each other inside one launch; their producers are always dispatched first, so a role only ever waits for workgroups that are running or
+    done -- also when another stream's kernels hold CUs.  Here a second engine runs the vision tower back to back from another thread (its own stream: GEMMs and attention
+    kernels that fill the chip) while the first generates: the ids are those of the undisturbed run and no polled hand-over times out (generate would raise)."""
+    import threading
+    cfg, m = full_model
+    path = weights.qwen2vl_file(cfg, cache_dir=os.environ.get("MLLM_AMD_CACHE", "/tmp/mllm_amd_cache"))
+    g = np.load(os.path.join(GOLD, "qwen2vl_2b_ref_text.npz"))
+    m.clear_kvcache()
+    tok, _, _ = m.prefill(g["ids"])
+    alone, _ = m.generate(tok, 200)
+    assert alone[:len(g["tokens"]) - 1].tolist() == g["tokens"][1:].tolist()
+    other = lib.Qwen2VL(cfg, path)
+    pix, grid, _ = synth.qwen2vl_inputs(cfg, (32, 32), 24)
+    out = torch.empty((256, cfg.hidden), dtype=torch.float32, device="cuda")
+    stop, passes, errors = threading.Event(), [0], []
+
+    def tower():
+        try:
+            while not stop.is_set():
+                other.vision(pix, grid, out.data_ptr())
+                passes[0] += 1
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    th = threading.Thread(target=tower)
+    th.start()
+    try:
+        for _ in range(6):
+            m.clear_kvcache()
+            tok, _, _ = m.prefill(g["ids"])
+            busy, _ = m.generate(tok, 200)
+            assert np.array_equal(busy, alone)
+    finally:
+        stop.set()
+        th.join()
+        other.close()
+    assert not errors and passes[0] >= 6, (errors, passes)
+
+
 def test_pipelined_decode_attention_equals_the_unpipelined_kernel_over_a_long_context(tmp_path):
     """dec_attn_pipe_kernel (scores of later key blocks computed while the walk over the first ones runs; kernels_attn_core.h: fa2_decode_head_pipe) against
     dec_attn_kernel (attn_flags bit 2: phases A -> B -> C one after the other, the form pinned against the oracle to T = 1500 by test_fa2_on_the_engine_kv_layout):
