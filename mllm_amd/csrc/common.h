@@ -34,7 +34,7 @@ int dec_linear_row_q4k(const void *Wraw, const float *x, const float *addend, fl
 int row_fused_launch(const mllm_hip_row_fused &in, hipStream_t st);      // kernels_decode.hip: mllm_hip_row_fused_launch
 // kernels_elem.hip: the rotary of mllm_hip_rope_apply, fp32 in place, over rows that repeat one table every `period` rows
 int rope_apply_periodic(float *x, int64_t ldx, const float *sin_t, const float *cos_t, int ld_tab, int rows, int period, int H, int D, hipStream_t st);
-enum Option { OPT_VISION_BATCH, OPT_TIME_LAYERS, OPT_NO_GUB, OPT_NO_PJB, OPT_PJB_MIN_NS, OPT_ATTN_FLAGS, OPT_ATTN_DS, OPT_HEAD_WPC, OPT_GEMM_ORDER, OPT_NO_LNF, OPT_MERGE_O, OPT_CHAIN_CONT, OPT_COUNT };
+enum Option { OPT_VISION_BATCH, OPT_TIME_LAYERS, OPT_NO_GUB, OPT_NO_PJB, OPT_PJB_MIN_NS, OPT_ATTN_FLAGS, OPT_ATTN_DS, OPT_HEAD_WPC, OPT_GEMM_ORDER, OPT_NO_LNF, OPT_MERGE_O, OPT_CHAIN_CONT, OPT_GU_PERSIST, OPT_QKV_PERSIST, OPT_COUNT };
 int option(Option o);
 
 // ---- device helpers -------------------------------------------------------------------------------------------

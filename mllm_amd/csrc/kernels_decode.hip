@@ -398,15 +398,18 @@ struct KvWarm {
 // PAIRS (the merged q|k|v + attention + o-projection launch): the rows go out as {value, DecodeState::serial} pairs for the attention's workgroups of the same launch;
 // wg / grid = this role's workgroup index and count (the stand-alone kernel passes its own block index and grid size)
 // XPOLL (four-role launch): the input row itself arrives as pairs from the previous layer's down-projection role (xpairs); the weight rows go out first
-template <int NSTEPS, int ROWS, bool EMBED, int NV, int WPB, bool PAIRS, bool XPOLL = false>
+// LOOP (stand-alone launches of long rows with a grid smaller than the row count): the workgroup walks further row groups, `wave_stride` waves apart, behind its one prologue
+template <int NSTEPS, int ROWS, bool EMBED, int NV, int WPB, bool PAIRS, bool XPOLL = false, bool LOOP = false>
 __device__ __forceinline__ void dec_qkv_body(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
                                              const uint8_t *__restrict__ emb_qs, const uint16_t *__restrict__ emb_d, int vocab, const float *__restrict__ norm_w, float eps,
                                              const uint8_t *__restrict__ W, const float *__restrict__ bias, float *__restrict__ y, unsigned long long *__restrict__ ypairs, int N, int K,
-                                             KvWarm kw, int wg, int grid, const unsigned long long *__restrict__ xpairs = nullptr, int *__restrict__ poll_err = nullptr) {
+                                             KvWarm kw, int wg, int grid, const unsigned long long *__restrict__ xpairs = nullptr, int *__restrict__ poll_err = nullptr,
+                                             int wave_stride = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[WPB];
     const ActLds a = carve_act(smem, K);
-    const int lane = threadIdx.x & 63, wave = wg * WPB + (threadIdx.x >> 6), nb = K >> 8;
+    const int lane = threadIdx.x & 63, nb = K >> 8;
+    typename std::conditional<LOOP, int, const int>::type wave = wg * WPB + (threadIdx.x >> 6);
     const unsigned serial = PAIRS ? (unsigned)state->serial : 0u;
     const int T_warm = kw.kslab ? state->T : 0;      // a scalar load (uniform address): in flight under the prologue, waited for on lgkmcnt only
     int rows[ROWS];
@@ -495,6 +498,29 @@ __device__ __forceinline__ void dec_qkv_body(const DecodeState *__restrict__ sta
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LOOP) {
+        static_assert(!PAIRS && !XPOLL, "the walking form is the stand-alone kernel's");
+        for (;;) {
+            float out[ROWS];
+            dot_rows<NSTEPS, ROWS>(L, a, nb, lane, wave_tab<NSTEPS, ROWS>(smem, K, false, threadIdx.x >> 6), out);
+            const int cur = wave;
+            wave += wave_stride;
+            const bool more = wave_stride > 0 && wave * ROWS < N;
+            if (more) {      // the next group's rows go out before this group's results are written
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) rows[rr] = min(wave * ROWS + rr, N - 1);
+                issue_rows<NSTEPS, ROWS>(L, W, nb, rows, lane);
+            }
+            if (lane == 63) {
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    const int rw = cur * ROWS + rr;
+                    if (rw < N) y[rw] = bias ? out[rr] + bias[rw] : out[rr];
+                }
+            }
+            if (!more) break;
+        }
+    } else {
     float out[ROWS];
     dot_rows<NSTEPS, ROWS>(L, a, nb, lane, wave_tab<NSTEPS, ROWS>(smem, K, false, threadIdx.x >> 6), out);
     if (lane == 63) {
@@ -507,6 +533,7 @@ __device__ __forceinline__ void dec_qkv_body(const DecodeState *__restrict__ sta
                 else y[rw] = r;
             }
         }
+    }
     }
     if (warms) {
 #pragma unroll
@@ -522,6 +549,15 @@ __global__ __launch_bounds__(64 * WPB) void dec_qkv_kernel(const DecodeState *__
                                                       const float *__restrict__ bias, float *__restrict__ y, int N, int K, KvWarm kw) {
     dec_qkv_body<NSTEPS, ROWS, EMBED, NV, WPB, false>(state, x, x_out, emb_qs, emb_d, vocab, norm_w, eps, W, bias, y, nullptr, N, K, kw, (int)blockIdx.x, (int)gridDim.x);
 }
+// the walking form of the same kernel (long rows: launch_norm_gemv with NS >= 2)
+template <int NSTEPS, int ROWS, int NV, int WPB>
+__global__ __launch_bounds__(64 * WPB) void dec_qkv_walk_kernel(const DecodeState *__restrict__ state, const float *__restrict__ x, float *__restrict__ x_out,
+                                                           const uint8_t *__restrict__ emb_qs, const uint16_t *__restrict__ emb_d, int vocab,
+                                                           const float *__restrict__ norm_w, float eps, const uint8_t *__restrict__ W,
+                                                           const float *__restrict__ bias, float *__restrict__ y, int N, int K, KvWarm kw) {
+    dec_qkv_body<NSTEPS, ROWS, false, NV, WPB, false, false, true>(state, x, x_out, emb_qs, emb_d, vocab, norm_w, eps, W, bias, y, nullptr, N, K, kw, (int)blockIdx.x, (int)gridDim.x,
+                                                                   nullptr, nullptr, (int)gridDim.x * WPB);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // dec_gateup: tmp -> RMSNorm -> Q8_K -> rows (gate n, up n) -> act[n] = silu(gate) * up   (gate rows [0,I), up rows [I,2I))
@@ -532,7 +568,8 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_kernel(const float *__res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[WPB];
     const ActLds a = carve_act(smem, K);
-    const int lane = threadIdx.x & 63, wave = blockIdx.x * WPB + (threadIdx.x >> 6), nb = K >> 8;
+    const int lane = threadIdx.x & 63, nb = K >> 8;
+    int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
     int rows[2 * PAIRS];
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
@@ -557,18 +594,36 @@ __global__ __launch_bounds__(64 * WPB) void dec_gateup_kernel(const float *__res
     issue_rows<NSTEPS, 2 * PAIRS, PRE, 2 * PAIRS>(L, W, nb, rows, lane);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(4);
-    float out[2 * PAIRS];
-    dot_rows<NSTEPS, 2 * PAIRS>(L, a, nb, lane, wave_tab<NSTEPS, 2 * PAIRS>(smem, K, false, threadIdx.x >> 6), out);
-    STAMP(5);
-    if (lane == 63) {
+    // A grid smaller than the row count (option gu_persist: workgroups per CU) makes the workgroup walk further row groups behind the one prologue: the Q8_K image of the
+    // row is made once per workgroup instead of once per eight row pairs.  With the full grid the loop runs once.
+    const int stride = (int)gridDim.x * WPB;
+    for (;;) {
+        float out[2 * PAIRS];
+        dot_rows<NSTEPS, 2 * PAIRS>(L, a, nb, lane, wave_tab<NSTEPS, 2 * PAIRS>(smem, K, false, threadIdx.x >> 6), out);
+        STAMP(5);
+        const int cur = wave;
+        wave += stride;
+        const bool more = wave * PAIRS < I;
+        if (more) {      // the next group's rows go out before this group's results are written
 #pragma unroll
-        for (int p = 0; p < PAIRS; ++p) {
-            const int n = wave * PAIRS + p;
-            if (n < I) {
-                const float g = out[2 * p], u = out[2 * p + 1];
-                act[n] = (g / (1.0f + v_expf_dec(0.0f - g))) * u;   // mllm_v_silu then F_TTMUL
+            for (int p = 0; p < PAIRS; ++p) {
+                const int n = min(wave * PAIRS + p, I - 1);
+                rows[2 * p] = n;
+                rows[2 * p + 1] = I + n;
+            }
+            issue_rows<NSTEPS, 2 * PAIRS>(L, W, nb, rows, lane);
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int p = 0; p < PAIRS; ++p) {
+                const int n = cur * PAIRS + p;
+                if (n < I) {
+                    const float g = out[2 * p], u = out[2 * p + 1];
+                    act[n] = (g / (1.0f + v_expf_dec(0.0f - g))) * u;   // mllm_v_silu then F_TTMUL
+                }
             }
         }
+        if (!more) break;
     }
 }
 
@@ -1456,6 +1511,15 @@ static int launch_norm_gemv(const DecodeCtx &c, const float *norm_w, float eps, 
     const int waves = (N + ROWS - 1) / ROWS;
     const size_t lds = fused_lds_bytes<NS, ROWS>(c.H, false, WPB);
     constexpr int NV = (NS * 8 + WPB - 1) / WPB;   // quant blocks per wave
+    // long rows (LLaVA-1.5-7B: 12,288 one-row waves = 1,536 workgroups, each with its own RMSNorm + Q8_K of the 4,096-value row): a grid of qkv_persist workgroups per CU walks them
+    const int persist = option(OPT_QKV_PERSIST) >= 0 ? option(OPT_QKV_PERSIST) : (NS >= 2 ? 2 : 0);
+    if (!embed && NS >= 2 && persist > 0 && (waves + WPB - 1) / WPB > 256 * persist) {
+        int wrc = allow_lds(dec_qkv_walk_kernel<NS, ROWS, NV, WPB>, lds);
+        if (wrc) return wrc;
+        hipLaunchKernelGGL((dec_qkv_walk_kernel<NS, ROWS, NV, WPB>), dim3(256 * persist), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, norm_w, eps, W, bias, y,
+                           N, c.H, kw);
+        return MH_LAUNCH_OK("dec_qkv_walk");
+    }
     int rc = embed ? allow_lds(dec_qkv_kernel<NS, ROWS, true, NV, WPB>, lds) : allow_lds(dec_qkv_kernel<NS, ROWS, false, NV, WPB>, lds);
     if (rc) return rc;
     if (embed)
@@ -1497,7 +1561,11 @@ static int launch_gateup(const DecodeLayer &L, const DecodeCtx &c, const float *
     auto kern = dec_gateup_kernel<NS, PAIRS, (NS * 8 + WPB - 1) / WPB, WPB>;
     int rc = allow_lds(kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3((waves + WPB - 1) / WPB), dim3(64 * WPB), lds, st, x, L.post_norm, c.eps, L.Wgu, c.act, c.I, c.H);
+    int grid = (waves + WPB - 1) / WPB;
+    // workgroups per CU of the persistent form (LLaVA-1.5-7B: 1,376 -> 512 workgroups, each walking 2.7 row groups behind one prologue: 19.5 -> 15.2 us; 1 / 3 / 4 per CU: 17.3 - 17.6)
+    const int persist = option(OPT_GU_PERSIST) >= 0 ? option(OPT_GU_PERSIST) : (NS >= 2 ? 2 : 0);
+    if (persist > 0) grid = std::min(grid, 256 * persist);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, x, L.post_norm, c.eps, L.Wgu, c.act, c.I, c.H);
     return MH_LAUNCH_OK("dec_gateup");
 }
 template <int NS>

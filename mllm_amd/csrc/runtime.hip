@@ -35,7 +35,7 @@ struct OptionTable {
 };
 static OptionTable g_option_table;
 static int *const g_options = g_option_table.v;
-static const char *const g_option_names[OPT_COUNT] = {"vision_batch", "time_layers", "no_gub", "no_pjb", "pjb_min_ns", "attn_flags", "attn_ds", "head_wpc", "gemm_order", "no_lnf", "merge_o", "chain_cont"};
+static const char *const g_option_names[OPT_COUNT] = {"vision_batch", "time_layers", "no_gub", "no_pjb", "pjb_min_ns", "attn_flags", "attn_ds", "head_wpc", "gemm_order", "no_lnf", "merge_o", "chain_cont", "gu_persist", "qkv_persist"};
 int option(Option o) { return g_options[o]; }
 }  // namespace mllm_hip
 
