@@ -1512,8 +1512,9 @@ static int launch_norm_gemv(const DecodeCtx &c, const float *norm_w, float eps, 
     const size_t lds = fused_lds_bytes<NS, ROWS>(c.H, false, WPB);
     constexpr int NV = (NS * 8 + WPB - 1) / WPB;   // quant blocks per wave
     // long rows (LLaVA-1.5-7B: 12,288 one-row waves = 1,536 workgroups, each with its own RMSNorm + Q8_K of the 4,096-value row): a grid of qkv_persist workgroups per CU walks them
-    const int persist = option(OPT_QKV_PERSIST) >= 0 ? option(OPT_QKV_PERSIST) : (NS >= 2 ? 2 : 0);
-    if (!embed && NS >= 2 && persist > 0 && (waves + WPB - 1) / WPB > 256 * persist) {
+    // (short rows too when there are at least four times as many workgroups as the walking grid: the untied lm_heads -- TinyLlama 2,000, Qwen1.5 9,496 workgroups)
+    const int persist = option(OPT_QKV_PERSIST) >= 0 ? option(OPT_QKV_PERSIST) : (NS >= 2 || (waves + WPB - 1) / WPB >= 1024 ? 2 : 0);
+    if (!embed && persist > 0 && (waves + WPB - 1) / WPB > 256 * persist) {
         int wrc = allow_lds(dec_qkv_walk_kernel<NS, ROWS, NV, WPB>, lds);
         if (wrc) return wrc;
         hipLaunchKernelGGL((dec_qkv_walk_kernel<NS, ROWS, NV, WPB>), dim3(256 * persist), dim3(64 * WPB), lds, st, c.state, x, x_out, c.emb_qs, c.emb_d, c.vocab, norm_w, eps, W, bias, y,

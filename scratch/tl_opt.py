@@ -5,7 +5,8 @@ import numpy as np
 from mllm_amd import lib, synth
 from mllm_amd import mllmfile as mf
 from mllm_amd import synthfile as weights
-cfg = synth.tinyllama_11b(mf.Q4_K)
+import os
+cfg = synth.qwen15_05b() if os.environ.get("CFG") == "qwen15" else synth.tinyllama_11b(mf.Q4_K)
 path = weights.causal_lm_file(cfg, "/tmp/mllm_amd_cache"); ids = synth.causal_lm_ids(cfg, 64)
 name = sys.argv[1]
 for v in [int(a) for a in sys.argv[2:]]:
