@@ -60,7 +60,8 @@ int mllm_hip_sync(void *stream);
  * 8-lanes-per-block GEMVs instead of one lane per super-block), pjb_min_ns, attn_flags, attn_ds (workgroups per head of the decode attention), head_wpc, gemm_order, no_lnf, merge_o (which kernels of the decode step share a launch, handing
  * their rows over as {value, epoch} pairs: 4 (default) a layer's down projection + the next layer's q|k|v + attention + o-projection; 3 q|k|v + attention + o-projection; 2 / 1 attention +
  * o-projection; 0 five launches per layer), chain_cont (0: the q|k|v role of the merge_o = 4 launch gets workgroups of its own; default: the first down-projection
- * workgroups carry on as that role). */
+ * workgroups carry on as that role), gu_persist / qkv_persist (workgroups per CU of the walking form of the long-row gate|up and norm + GEMV kernels: a workgroup makes its
+ * Q8_K image once and walks several row groups; default 2 for rows of more than eight super-blocks and for untied lm_heads, 0 = one row group per workgroup). */
 int mllm_hip_set_option(const char *name, int value);
 int mllm_hip_get_option(const char *name, int *value);
 /* one in-order stream per backend instance (hipStream_t as void*); the OpenCL backend's command queue, OpenCLBackend.cpp:476-477 */
