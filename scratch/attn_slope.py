@@ -3,6 +3,8 @@ import sys
 sys.path.insert(0, '.')
 import numpy as np
 from mllm_amd import lib, synth
+import os
+if os.environ.get('MLLM_SO'): lib.SO_PATH = os.path.abspath(os.environ['MLLM_SO'])
 from mllm_amd import synthfile as weights
 cfg = synth.qwen2vl_2b(); path = weights.qwen2vl_file(cfg, cache_dir="/tmp/mllm_amd_cache")
 pix, grid, ids = synth.qwen2vl_inputs(cfg, (32, 32), 24)
